@@ -1,0 +1,154 @@
+/*
+ * sid_pm.h - C ABI of the MI355X (gfx950) pattern-matching operator.
+ *
+ * Drop-in boundary for ONE hot path of nansencenter/sea_ice_drift (v0.7.1): the
+ * per-grid-point rotated-template maximum-cross-correlation sweep that the reference
+ * runs through multiprocessing.Pool.  Everything here is plain pointers and sizes; no
+ * torch / HIP types appear in a signature (streams travel as void*).
+ *
+ * Reference interfaces replaced (file:line in /root/reference/sea_ice_drift/):
+ *
+ *   sid_pm_batch        pmlib.py:436-448 + :462   Pool(initargs=(c1,r1,c2fg,r2fg,brd,img1,img2,
+ *                                                 img_size,alpha0,kwargs)).map(use_mcc_mp, range(N))
+ *                                                 -> np.array(results) of shape (N,5)
+ *   per point           pmlib.py:176-212 use_mcc, :117-174 rotate_and_match,
+ *                       :89-115 get_template, :156 cv2.matchTemplate(TM_CCOEFF_NORMED),
+ *                       :36-59 get_hessian   (all fused into one HIP kernel)
+ *   sid_pm_create/...   pmlib.py:430-434 _init_pool (shared read-only state of the workers):
+ *                       here the state is device-resident and owned by a handle, so the
+ *                       operator is re-entrant (the reference's module globals, :33-34, are not)
+ *
+ * Ownership: every pointer argument is caller-owned and is not retained past the call,
+ * except device image pointers given to sid_pm_bind_pair, which must stay valid until
+ * the next bind/upload or sid_pm_destroy.  Device buffers created by the library belong
+ * to the handle and are freed by sid_pm_destroy.
+ *
+ * Errors: functions return SID_PM_OK (0) or a negative code; sid_pm_last_error() gives a
+ * thread-local message.  Per-point failure is never an error: exactly like the reference
+ * (pmlib.py:152-154) a point whose rotated template touches a 0 pixel yields NaN x 5
+ * (and -1 in out_ij); so does a search window that is not wholly inside image 2.
+ *
+ * Numerics: see DESIGN.md "NCC specification".  Integer outputs (peak row/col, angle
+ * index) are exact; r is the float32 the specification defines; h is float32 arithmetic
+ * as in NumPy, agreeing with the CPU oracle to 1e-5.
+ */
+#ifndef SID_PM_H
+#define SID_PM_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SID_PM_ABI_VERSION 1
+
+/* return codes */
+#define SID_PM_OK               0
+#define SID_PM_ERR_ARG         -1   /* bad argument (null pointer, n_angles < 1, ...)          */
+#define SID_PM_ERR_HIP         -2   /* a HIP runtime call failed                               */
+#define SID_PM_ERR_NOMEM       -3   /* host or device allocation failed                        */
+#define SID_PM_ERR_UNSUPPORTED -4   /* option or size outside what the kernels implement       */
+#define SID_PM_ERR_NODEVICE    -5   /* no gfx950 device visible                                */
+#define SID_PM_ERR_STATE       -6   /* call order violated (run before set_points, ...)        */
+
+/* flags = the reference's boolean kwargs (pmlib.py:36, :121) */
+#define SID_PM_HES_NORM 1u          /* hes_norm=True  (default in the reference)               */
+#define SID_PM_HES_SMTH 2u          /* hes_smth=True  (gaussian_filter sigma=1 before Hessian) */
+#define SID_PM_MCC_NORM 4u          /* mcc_norm=True                                           */
+
+typedef struct sid_pm_ctx sid_pm_ctx;
+
+int         sid_pm_abi_version(void);
+const char *sid_pm_strerror(int code);
+const char *sid_pm_last_error(void);
+int         sid_pm_device_count(int *count);
+
+/*
+ * One-shot, host buffers in / host buffers out: the whole Pool.map seam.
+ *   img1,img2        uint8 images, row-major, `stride` bytes between rows (>= cols)
+ *   c1,r1            [n] template centre on image 1 (float pixel coordinates)
+ *   c2fg,r2fg        [n] first-guess centre on image 2
+ *   border           [n] search half-width around the first guess (pixels)
+ *   img_size         template side s (reference default 35; 34 in the benchmark)
+ *   alpha0           scene rotation in degrees (pmlib.py:428)
+ *   angles           [n_angles] trial angles in degrees, in the reference's list order
+ *   rot              optional [n_angles][4] = {cos a, sin a, tcT0, tcT1} with
+ *                    a = radians(angle - alpha0), tcT = [tc,tc].dot([[cos,-sin],[sin,cos]]),
+ *                    tc = int(s/2.)+1 (pmlib.py:105-110), as the caller's NumPy computed them;
+ *                    NULL = derive with libm cos/sin (may differ from NumPy in the last bit)
+ *   out              [n][5] float64: c2, r2, angle, r, h            (pmlib.py:212)
+ *   out_ij           optional [n][3] int32: peak row, peak col, angle index (-1 = NaN point)
+ */
+int sid_pm_batch(const uint8_t *img1, int64_t rows1, int64_t cols1, int64_t stride1,
+                 const uint8_t *img2, int64_t rows2, int64_t cols2, int64_t stride2,
+                 const double *c1, const double *r1, const double *c2fg, const double *r2fg,
+                 const double *border, int64_t n, int img_size, double alpha0,
+                 const double *angles, const double *rot, int n_angles, uint32_t flags,
+                 double *out, int32_t *out_ij);
+
+/* ---- device-resident form: upload once, run many (bench.py, pair streaming, RCCL gather) ---- */
+
+int  sid_pm_create(int device, sid_pm_ctx **ctx);
+void sid_pm_destroy(sid_pm_ctx *ctx);
+
+/* HIP stream (hipStream_t as void*) all later work of this handle is enqueued on; NULL = default */
+int sid_pm_set_stream(sid_pm_ctx *ctx, void *hip_stream);
+
+/* Copy a host image pair into handle-owned device buffers (asynchronous on the stream;
+ * the host buffers must stay valid until sid_pm_sync).  `slot` 0/1 selects one of two
+ * device pairs so pair k+1 can upload while pair k is matched; sid_pm_select_pair picks
+ * the one the next run uses. */
+int sid_pm_upload_pair(sid_pm_ctx *ctx, int slot,
+                       const uint8_t *img1, int64_t rows1, int64_t cols1, int64_t stride1,
+                       const uint8_t *img2, int64_t rows2, int64_t cols2, int64_t stride2);
+int sid_pm_select_pair(sid_pm_ctx *ctx, int slot);
+
+/* Borrow images already in device memory (e.g. torch uint8 tensors). */
+int sid_pm_bind_pair(sid_pm_ctx *ctx,
+                     const uint8_t *d_img1, int64_t rows1, int64_t cols1, int64_t stride1,
+                     const uint8_t *d_img2, int64_t rows2, int64_t cols2, int64_t stride2);
+
+/* Host vectors of the n points + the sweep parameters.  Validates, orders the points by
+ * search-window size (largest first, for load balance), groups them by LDS footprint and
+ * uploads them; the points stay resident until the next call. */
+int sid_pm_set_points(sid_pm_ctx *ctx, const double *c1, const double *r1, const double *c2fg,
+                      const double *r2fg, const double *border, int64_t n, int img_size,
+                      double alpha0, const double *angles, const double *rot, int n_angles,
+                      uint32_t flags);
+
+/* Enqueue the kernels for the resident points on the resident pair (asynchronous). */
+int sid_pm_run(sid_pm_ctx *ctx);
+/* Wait for the stream. */
+int sid_pm_sync(sid_pm_ctx *ctx);
+/* Copy results to the host (waits for the stream).  out_ij may be NULL. */
+int sid_pm_fetch(sid_pm_ctx *ctx, double *out, int32_t *out_ij);
+/* Device pointers of the result arrays ([n][5] float64, [n][3] int32, original point
+ * order) for device-side consumers such as an RCCL gather.  Valid until set_points/destroy. */
+int sid_pm_device_results(sid_pm_ctx *ctx, double **d_out, int32_t **d_out_ij);
+
+/* Work accounting of the resident points, for roofline reporting (DESIGN.md "Measurement"):
+ *   info[0] = kernel launches per run          info[1] = valid points
+ *   info[2] = algorithmic MACs  sum K*Rh*Rw*s*s   info[3] = algorithmic HBM bytes
+ *   info[4] = max dynamic LDS bytes per block  info[5] = reserved                           */
+int sid_pm_work_info(sid_pm_ctx *ctx, double info[6]);
+
+/* ---- diagnostics used by the parity tests ---- */
+
+/* Intermediate results of one point: rotated templates [n_angles][s][s] (uint8), the NCC
+ * matrix of the winning angle and its raw Hessian magnitude [rh][rw] (float32, caller
+ * provides capacity `cap` floats each), shape in rh_rw[2].  Any output pointer may be NULL. */
+int sid_pm_debug_point(sid_pm_ctx *ctx, double c1, double r1, double c2fg, double r2fg,
+                       double border, int img_size, double alpha0, const double *angles,
+                       const double *rot, int n_angles, uint32_t flags,
+                       uint8_t *templates, float *ccm, float *hes, int64_t cap, int32_t rh_rw[2],
+                       double out5[5], int32_t ij3[3]);
+
+/* y[i] = 1.0 / sqrt(x[i]) evaluated on the device in IEEE double, the one transcendental
+ * step of the NCC specification; lets a test pin device vs host rounding. */
+int sid_pm_debug_rsqrt(sid_pm_ctx *ctx, const double *x, double *y, int64_t n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SID_PM_H */

@@ -1,0 +1,424 @@
+/*
+ * CPU oracle (plain C form) for the sea_ice_drift pattern-matching hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Used by tests/, __graft_entry__.smoke() and the
+ * cpu_baseline leg of bench.py as the checker / timed CPU baseline.  Nothing in
+ * sea_ice_drift_amd/ links, loads or calls this file.
+ *
+ * Restates /root/reference/sea_ice_drift/pmlib.py (v0.7.1):
+ *   sid_oracle_get_template    pmlib.py:89-115   (scipy affine_transform, order 0)
+ *   sid_oracle_match_template  pmlib.py:156      (cv2.matchTemplate TM_CCOEFF_NORMED;
+ *                                                 OpenCV un-vendored and absent:
+ *                                                 PARITY UNPINNED at this call, see
+ *                                                 oracle/pm_oracle.py for the spec)
+ *   sid_oracle_hessian         pmlib.py:36-59    (np.gradient x2, hypot, median, std)
+ *   sid_oracle_use_mcc         pmlib.py:117-212  (rotate_and_match + use_mcc)
+ *   sid_oracle_pm_batch        pmlib.py:436-448  (the Pool.map seam; OpenMP over points
+ *                                                 stands in for multiprocessing.Pool)
+ *
+ * Build: see oracle/Makefile (-ffp-contract=off: every double/float operation below
+ * is one IEEE rounding, which is what the spec and the HIP kernel assume).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define SID_FLAG_HES_NORM 1u
+#define SID_FLAG_HES_SMTH 2u
+#define SID_FLAG_MCC_NORM 4u
+
+/* ------------------------------------------------------------------ a1 */
+/* rot = {cos a, sin a, tcT0, tcT1} with tcT = [tc,tc].dot([[cos,-sin],[sin,cos]])
+ * (pmlib.py:105-110).  Returns the minimum sampled value (0 => invalid point). */
+int sid_oracle_get_template(const uint8_t *img, int64_t rows, int64_t cols, int64_t stride,
+                            double c, double r, const double *rot, int s, uint8_t *out)
+{
+    const double cosa = rot[0], sina = rot[1];
+    const double off0 = r - rot[2], off1 = c - rot[3];
+    const double msin = -sina;
+    int vmin = 255;
+    for (int i = 0; i < s; ++i) {
+        for (int j = 0; j < s; ++j) {
+            /* scipy NI_GeometricTransform: coordinate = 0.0; += i*M[h][0]; += j*M[h][1]; += shift */
+            double rr = 0.0 + (double)i * cosa;
+            rr = rr + (double)j * sina;
+            rr = rr + off0;
+            double cc = 0.0 + (double)i * msin;
+            cc = cc + (double)j * cosa;
+            cc = cc + off1;
+            uint8_t v = 0;
+            if (rr >= 0.0 && rr <= (double)(rows - 1) && cc >= 0.0 && cc <= (double)(cols - 1)) {
+                int64_t ri = (int64_t)floor(rr + 0.5), ci = (int64_t)floor(cc + 0.5);
+                v = img[ri * stride + ci];
+            }
+            out[i * s + j] = v;
+            if (v < vmin) vmin = v;
+        }
+    }
+    return vmin;
+}
+
+/* ------------------------------------------------------------------ a3 */
+/* Exact integer sums + the double normalisation of the spec.  Scratch: sit (int32 rh*rw),
+ * si/sii (int64 rh*rw).  out: float32 rh*rw. */
+static void match_template_core(const uint8_t *win, int wh, int ww, int64_t wstride,
+                                const uint8_t *tmpl, int s, float *out,
+                                int32_t *sit, int64_t *si, int64_t *sii, int have_sums)
+{
+    const int rh = wh - s + 1, rw = ww - s + 1;
+    const int64_t n = (int64_t)s * s;
+    if (!have_sums) {
+        /* box sums by column-sum sliding (exact) */
+        int64_t *cs = (int64_t *)malloc(sizeof(int64_t) * 2 * ww);
+        int64_t *cs2 = cs + ww;
+        for (int x = 0; x < ww; ++x) {
+            int64_t a = 0, b = 0;
+            for (int i = 0; i < s; ++i) { int64_t v = win[i * wstride + x]; a += v; b += v * v; }
+            cs[x] = a; cs2[x] = b;
+        }
+        for (int y = 0; y < rh; ++y) {
+            if (y > 0) {
+                for (int x = 0; x < ww; ++x) {
+                    int64_t o = win[(int64_t)(y - 1) * wstride + x], nn = win[(int64_t)(y + s - 1) * wstride + x];
+                    cs[x] += nn - o; cs2[x] += nn * nn - o * o;
+                }
+            }
+            int64_t a = 0, b = 0;
+            for (int j = 0; j < s; ++j) { a += cs[j]; b += cs2[j]; }
+            si[y * rw] = a; sii[y * rw] = b;
+            for (int x = 1; x < rw; ++x) {
+                a += cs[x + s - 1] - cs[x - 1]; b += cs2[x + s - 1] - cs2[x - 1];
+                si[y * rw + x] = a; sii[y * rw + x] = b;
+            }
+        }
+        free(cs);
+    }
+    int64_t s_t = 0, s_tt = 0;
+    for (int k = 0; k < s * s; ++k) { int64_t v = tmpl[k]; s_t += v; s_tt += v * v; }
+    const int64_t d_t = n * s_tt - s_t * s_t;
+    if (d_t == 0) {
+        for (int k = 0; k < rh * rw; ++k) out[k] = 1.0f;
+        return;
+    }
+    memset(sit, 0, sizeof(int32_t) * rh * rw);
+    for (int y = 0; y < rh; ++y) {
+        int32_t *acc = sit + y * rw;
+        for (int i = 0; i < s; ++i) {
+            const uint8_t *wrow = win + (int64_t)(y + i) * wstride;
+            const uint8_t *trow = tmpl + i * s;
+            for (int j = 0; j < s; ++j) {
+                const int32_t t = trow[j];
+                const uint8_t *w = wrow + j;
+                for (int x = 0; x < rw; ++x) acc[x] += t * (int32_t)w[x];
+            }
+        }
+    }
+    const double r_t = 1.0 / sqrt((double)d_t);
+    for (int k = 0; k < rh * rw; ++k) {
+        const int64_t numer = n * (int64_t)sit[k] - si[k] * s_t;
+        const int64_t d_i = n * sii[k] - si[k] * si[k];
+        float res;
+        if (2 * d_i <= n && d_i * (int64_t)(1 << 23) <= 10 * n * sii[k]) {
+            res = 0.0f;
+        } else {
+            const double r_i = 1.0 / sqrt((double)d_i);
+            double q = (double)numer * r_i;
+            q = q * r_t;
+            const double aq = fabs(q);
+            if (aq < 1.0) res = (float)q;
+            else if (aq < 1.125) res = q > 0 ? 1.0f : -1.0f;
+            else res = 0.0f;
+        }
+        out[k] = res;
+    }
+}
+
+int sid_oracle_match_template(const uint8_t *win, int wh, int ww, int64_t wstride,
+                              const uint8_t *tmpl, int s, float *out)
+{
+    const int rh = wh - s + 1, rw = ww - s + 1;
+    if (rh < 1 || rw < 1) return -1;
+    int32_t *sit = (int32_t *)malloc(sizeof(int32_t) * rh * rw);
+    int64_t *si = (int64_t *)malloc(sizeof(int64_t) * 2 * rh * rw);
+    match_template_core(win, wh, ww, wstride, tmpl, s, out, sit, si, si + (size_t)rh * rw, 0);
+    free(sit); free(si);
+    return 0;
+}
+
+/* ------------------------------------------------------------------ a5 */
+/* NumPy's float32 pairwise summation (numpy/_core/src/umath/loops_utils.h.src), so that
+ * std() below rounds like np.std on a contiguous float32 array. */
+static float pairwise_sum_f32(const float *a, int64_t n)
+{
+    if (n < 8) {
+        float res = 0.f;
+        for (int64_t i = 0; i < n; ++i) res += a[i];
+        return res;
+    } else if (n <= 128) {
+        float r[8];
+        int64_t i;
+        for (int j = 0; j < 8; ++j) r[j] = a[j];
+        for (i = 8; i < n - (n % 8); i += 8)
+            for (int j = 0; j < 8; ++j) r[j] += a[i + j];
+        float res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+        for (; i < n; ++i) res += a[i];
+        return res;
+    } else {
+        int64_t n2 = n / 2;
+        n2 -= n2 % 8;
+        return pairwise_sum_f32(a, n2) + pairwise_sum_f32(a + n2, n - n2);
+    }
+}
+
+static int cmp_f32(const void *a, const void *b)
+{
+    const float x = *(const float *)a, y = *(const float *)b;
+    return (x > y) - (x < y);
+}
+
+/* np.median and np.std of a float32 array (float32 results). tmp: n floats of scratch. */
+static void median_std_f32(const float *v, int64_t n, float *tmp, float *med, float *sd)
+{
+    memcpy(tmp, v, sizeof(float) * n);
+    qsort(tmp, n, sizeof(float), cmp_f32);
+    if (n & 1) *med = tmp[n / 2];
+    else *med = (tmp[n / 2 - 1] + tmp[n / 2]) / 2.0f;     /* np.mean of the two middles, float32 */
+    const float mean = pairwise_sum_f32(v, n) / (float)n;
+    for (int64_t k = 0; k < n; ++k) { const float x = v[k] - mean; tmp[k] = x * x; }
+    const float var = pairwise_sum_f32(tmp, n) / (float)n;
+    *sd = sqrtf(var);
+}
+
+static inline float grad1(const float *f, int64_t stride, int k, int n)
+{
+    if (k == 0) return f[stride] - f[0];
+    if (k == n - 1) return f[(int64_t)(n - 1) * stride] - f[(int64_t)(n - 2) * stride];
+    return (f[(int64_t)(k + 1) * stride] - f[(int64_t)(k - 1) * stride]) / 2.0f;
+}
+
+/* second application of the same 1-D gradient, evaluated at index k */
+static inline float grad2(const float *f, int64_t stride, int k, int n)
+{
+    if (k == 0) return grad1(f, stride, 1, n) - grad1(f, stride, 0, n);
+    if (k == n - 1) return grad1(f, stride, n - 1, n) - grad1(f, stride, n - 2, n);
+    return (grad1(f, stride, k + 1, n) - grad1(f, stride, k - 1, n)) / 2.0f;
+}
+
+/* raw Hessian magnitude, float32 (pmlib.py:51-55) */
+static void raw_hessian(const float *ccm, int rh, int rw, float *hes)
+{
+    for (int y = 0; y < rh; ++y)
+        for (int x = 0; x < rw; ++x) {
+            const float d2x = grad2(ccm + (int64_t)y * rw, 1, x, rw);
+            const float d2y = grad2(ccm + x, rw, y, rh);
+            hes[y * rw + x] = hypotf(d2x, d2y);
+        }
+}
+
+/* scipy.ndimage.gaussian_filter(ccm, 1) on float32: per axis a radius-4 kernel in double,
+ * 'reflect' boundary, result cast to float32 after each axis (pmlib.py:46-47). */
+static void gaussian_smooth_sigma1(const float *in, int rh, int rw, float *out, float *tmp)
+{
+    double w[9];
+    for (int k = -4; k <= 4; ++k) w[k + 4] = exp(-0.5 * (double)(k * k));
+    /* phi.sum() in NumPy's pairwise order for n = 9 */
+    const double sum = (((w[0] + w[1]) + (w[2] + w[3])) + ((w[4] + w[5]) + (w[6] + w[7]))) + w[8];
+    for (int k = 0; k < 9; ++k) w[k] /= sum;
+    /* scipy filters axis 0 first ... the kernel is symmetric so correlate == convolve */
+    for (int pass = 0; pass < 2; ++pass) {
+        const float *src = pass == 0 ? in : tmp;
+        float *dst = pass == 0 ? tmp : out;
+        const int n = pass == 0 ? rh : rw;            /* length along the filtered axis */
+        for (int y = 0; y < rh; ++y)
+            for (int x = 0; x < rw; ++x) {
+                const int p = pass == 0 ? y : x;
+                double acc = 0.0;
+                /* scipy's correlate1d for symmetric kernels: centre + pairs (left+right)*w */
+                {
+                    int q = p;
+                    acc = (double)src[pass == 0 ? (int64_t)q * rw + x : (int64_t)y * rw + q] * w[4];
+                }
+                for (int k = 4; k >= 1; --k) {               /* scipy adds the outermost pair first */
+                    int ql = p - k, qr = p + k;
+                    /* reflect: (d c b a | a b c d | d c b a) */
+                    while (ql < 0 || ql >= n) { if (ql < 0) ql = -ql - 1; if (ql >= n) ql = 2 * n - 1 - ql; }
+                    while (qr < 0 || qr >= n) { if (qr < 0) qr = -qr - 1; if (qr >= n) qr = 2 * n - 1 - qr; }
+                    const double l = src[pass == 0 ? (int64_t)ql * rw + x : (int64_t)y * rw + ql];
+                    const double r = src[pass == 0 ? (int64_t)qr * rw + x : (int64_t)y * rw + qr];
+                    acc += (l + r) * w[4 - k];
+                }
+                dst[(int64_t)y * rw + x] = (float)acc;
+            }
+    }
+}
+
+/* get_hessian(ccm)[iy, ix] (pmlib.py:36-59, :167).  scratch: 3*rh*rw floats. */
+float sid_oracle_hessian_at(const float *ccm, int rh, int rw, unsigned flags, int iy, int ix,
+                            float *scratch)
+{
+    const int64_t n = (int64_t)rh * rw;
+    float *hes = scratch, *tmp = scratch + n, *smth = scratch + 2 * n;
+    const float *src = ccm;
+    if (flags & SID_FLAG_HES_SMTH) { gaussian_smooth_sigma1(ccm, rh, rw, smth, tmp); src = smth; }
+    raw_hessian(src, rh, rw, hes);
+    float h = hes[(int64_t)iy * rw + ix];
+    if (flags & SID_FLAG_HES_NORM) {
+        float med, sd;
+        median_std_f32(hes, n, tmp, &med, &sd);
+        h = (h - med) / sd;
+    }
+    return h;
+}
+
+/* whole-matrix form for the unit tests */
+int sid_oracle_hessian(const float *ccm, int rh, int rw, unsigned flags, float *out)
+{
+    const int64_t n = (int64_t)rh * rw;
+    float *scratch = (float *)malloc(sizeof(float) * 3 * n);
+    float *tmp = scratch + n, *smth = scratch + 2 * n;
+    const float *src = ccm;
+    if (flags & SID_FLAG_HES_SMTH) { gaussian_smooth_sigma1(ccm, rh, rw, smth, tmp); src = smth; }
+    raw_hessian(src, rh, rw, out);
+    if (flags & SID_FLAG_HES_NORM) {
+        float med, sd;
+        median_std_f32(out, n, tmp, &med, &sd);
+        for (int64_t k = 0; k < n; ++k) out[k] = (out[k] - med) / sd;
+    }
+    free(scratch);
+    return 0;
+}
+
+/* -------------------------------------------------------- a2, a4, a6 */
+typedef struct {
+    uint8_t *tmpl;
+    float *res, *best, *scratch;
+    int32_t *sit;
+    int64_t *si;
+    size_t cap;                     /* capacity in placements */
+    int s;
+} sid_ws;
+
+static void ws_reserve(sid_ws *w, size_t nplace, int s)
+{
+    if (w->cap >= nplace && w->s >= s) return;
+    free(w->tmpl); free(w->res); free(w->best); free(w->scratch); free(w->sit); free(w->si);
+    w->tmpl = (uint8_t *)malloc((size_t)s * s);
+    w->res = (float *)malloc(sizeof(float) * nplace);
+    w->best = (float *)malloc(sizeof(float) * nplace);
+    w->scratch = (float *)malloc(sizeof(float) * 3 * nplace);
+    w->sit = (int32_t *)malloc(sizeof(int32_t) * nplace);
+    w->si = (int64_t *)malloc(sizeof(int64_t) * 2 * nplace);
+    w->cap = nplace; w->s = s;
+}
+
+static void ws_free(sid_ws *w)
+{
+    free(w->tmpl); free(w->res); free(w->best); free(w->scratch); free(w->sit); free(w->si);
+    memset(w, 0, sizeof(*w));
+}
+
+/* One grid point: use_mcc + rotate_and_match.  out5 = c2, r2, a, r, h ; ij3 = row, col, angle idx */
+static void use_mcc_ws(sid_ws *w, const uint8_t *img1, int64_t rows1, int64_t cols1, int64_t stride1,
+                       const uint8_t *img2, int64_t rows2, int64_t cols2, int64_t stride2,
+                       double c1, double r1, double c2fg, double r2fg, double border,
+                       int s, const double *angles, const double *rot, int n_angles,
+                       unsigned flags, double *out5, int32_t *ij3)
+{
+    const int hws = (int)((double)s / 2.);
+    /* Python int(): truncation toward zero (pmlib.py:201-202) */
+    const int64_t r0 = (int64_t)(r2fg - hws - border), r1e = (int64_t)(r2fg + hws + border + 1);
+    const int64_t c0 = (int64_t)(c2fg - hws - border), c1e = (int64_t)(c2fg + hws + border + 1);
+    for (int k = 0; k < 5; ++k) out5[k] = NAN;
+    if (ij3) { ij3[0] = ij3[1] = ij3[2] = -1; }
+    if (!(r0 >= 0 && c0 >= 0 && r1e <= rows2 && c1e <= cols2 && r1e - r0 >= s && c1e - c0 >= s)) return;
+    const int wh = (int)(r1e - r0), ww = (int)(c1e - c0);
+    const int rh = wh - s + 1, rw = ww - s + 1;
+    ws_reserve(w, (size_t)rh * rw, s);
+    const uint8_t *win = img2 + r0 * stride2 + c0;
+
+    float best_r = -INFINITY;
+    int best_k = -1, best_idx = -1;
+    for (int k = 0; k < n_angles; ++k) {
+        if (sid_oracle_get_template(img1, rows1, cols1, stride1, c1, r1, rot + 4 * k, s, w->tmpl) == 0)
+            return;                                             /* pmlib.py:152-154 -> NaN */
+        match_template_core(win, wh, ww, stride2, w->tmpl, s, w->res, w->sit, w->si,
+                            w->si + (size_t)rh * rw, k > 0);
+        int idx = 0; float mx = w->res[0];
+        for (int p = 1; p < rh * rw; ++p) if (w->res[p] > mx) { mx = w->res[p]; idx = p; }  /* first max */
+        if (mx > best_r) {                                      /* strict (pmlib.py:160) */
+            best_r = mx; best_k = k; best_idx = idx;
+            float *t = w->best; w->best = w->res; w->res = t;
+        }
+    }
+    if (best_k < 0) return;
+    const int iy = best_idx / rw, ix = best_idx % rw;
+    const float best_h = sid_oracle_hessian_at(w->best, rh, rw, flags, iy, ix, w->scratch);
+    const double dr = iy - (wh - s) / 2., dc = ix - (ww - s) / 2.;
+    float rr = best_r;
+    if (flags & SID_FLAG_MCC_NORM) {
+        float med, sd;
+        median_std_f32(w->best, (int64_t)rh * rw, w->scratch, &med, &sd);
+        rr = (best_r - med) / sd;
+    }
+    out5[0] = c2fg + dc; out5[1] = r2fg + dr; out5[2] = angles[best_k];
+    out5[3] = (double)rr; out5[4] = (double)best_h;
+    if (ij3) { ij3[0] = iy; ij3[1] = ix; ij3[2] = best_k; }
+}
+
+/* rot may be NULL: then cos/sin/tcT are derived here with libm (NumPy's own cos/sin can
+ * differ from libm in the last bit; tests pass rot computed by NumPy as the reference does). */
+static double *make_rot(const double *angles, int n_angles, double alpha0, int s, const double *rot_in)
+{
+    double *rot = (double *)malloc(sizeof(double) * 4 * n_angles);
+    if (rot_in) { memcpy(rot, rot_in, sizeof(double) * 4 * n_angles); return rot; }
+    const double tc = (double)((int)((double)s / 2.) + 1);
+    for (int k = 0; k < n_angles; ++k) {
+        const double a = (angles[k] - alpha0) * (M_PI / 180.0);
+        const double ca = cos(a), sa = sin(a);
+        rot[4 * k + 0] = ca; rot[4 * k + 1] = sa;
+        rot[4 * k + 2] = tc * ca + tc * sa;
+        rot[4 * k + 3] = tc * (-sa) + tc * ca;
+    }
+    return rot;
+}
+
+int sid_oracle_pm_batch(const uint8_t *img1, int64_t rows1, int64_t cols1, int64_t stride1,
+                        const uint8_t *img2, int64_t rows2, int64_t cols2, int64_t stride2,
+                        const double *c1, const double *r1, const double *c2fg, const double *r2fg,
+                        const double *border, int64_t n, int img_size, double alpha0,
+                        const double *angles, const double *rot_in, int n_angles, unsigned flags,
+                        int nthreads, double *out, int32_t *out_ij)
+{
+    if (n_angles < 1 || img_size < 2 || n < 0) return -1;
+    double *rot = make_rot(angles, n_angles, alpha0, img_size, rot_in);
+#ifdef _OPENMP
+    if (nthreads < 1) nthreads = omp_get_max_threads();
+#else
+    nthreads = 1;
+#endif
+#pragma omp parallel num_threads(nthreads)
+    {
+        sid_ws w; memset(&w, 0, sizeof(w));
+#pragma omp for schedule(dynamic, 4)
+        for (int64_t i = 0; i < n; ++i)
+            use_mcc_ws(&w, img1, rows1, cols1, stride1, img2, rows2, cols2, stride2,
+                       c1[i], r1[i], c2fg[i], r2fg[i], border[i], img_size, angles, rot, n_angles,
+                       flags, out + 5 * i, out_ij ? out_ij + 3 * i : NULL);
+        ws_free(&w);
+    }
+    free(rot);
+    return 0;
+}
+
+int sid_oracle_max_threads(void)
+{
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}

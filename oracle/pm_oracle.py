@@ -1,0 +1,281 @@
+"""CPU oracle (NumPy form) for the sea_ice_drift pattern-matching hot path.
+
+TEST INFRASTRUCTURE ONLY.  Nothing under ``sea_ice_drift_amd/`` may import this
+module: it exists so that ``tests/``, ``__graft_entry__.smoke()`` and the
+``cpu_baseline`` leg of ``bench.py`` can check the HIP path.  The product path
+fails loudly when the HIP library is missing; it never falls back to this code.
+
+It restates, function by function, the per-grid-point operator of
+``/root/reference/sea_ice_drift/pmlib.py`` (reference @ v0.7.1):
+
+====================  =====================  ===================================
+here                  reference              what
+====================  =====================  ===================================
+rotation_terms        pmlib.py:105-110       tc, cos/sin matrix, tc.dot(transform)
+get_template          pmlib.py:89-115        rotated nearest-neighbour template
+match_template        pmlib.py:156 (cv2)     TM_CCOEFF_NORMED, see below
+get_hessian           pmlib.py:36-59         float32 2nd-derivative magnitude
+rotate_and_match      pmlib.py:117-174       angle sweep, peak pick, Hessian
+use_mcc               pmlib.py:176-212       window slicing, displacement
+pm_batch              pmlib.py:436-448,462   the Pool.map seam -> (N,5) array
+====================  =====================  ===================================
+
+Parity status
+-------------
+* Everything except ``match_template`` is pinned against the reference's own
+  Python, imported in the build container (``oracle/ref_harness.py``) and frozen
+  as fixtures under ``tests/golden/`` by ``tests/golden/make_golden.py``.
+* ``match_template`` restates ``cv2.matchTemplate(..., cv2.TM_CCOEFF_NORMED)``.
+  OpenCV (un-vendored, version unpinned: reference README.md:32, .travis.yml:13)
+  is absent from this image and the reference's tests assert no number at that
+  call (tests.py:332-346), so **parity is unpinned at the cv2 boundary**.  The
+  restatement follows OpenCV's published algorithm (imgproc/templmatch.cpp,
+  ``common_matchTemplate``) with the raw correlation taken as exact integer sums
+  instead of OpenCV's float32 DFT, so it is deterministic and at least as
+  accurate; it is cross-checked against an independent float64 brute-force NCC.
+
+NCC specification (shared by this file, oracle/pm_oracle.c and the HIP kernel)
+------------------------------------------------------------------------------
+For a window placement with N = s*s pixels, exact integers::
+
+    S_I = sum W      S_II = sum W*W      S_T = sum T      S_TT = sum T*T
+    S_IT = sum W*T
+    numer = N*S_IT - S_I*S_T     dI = N*S_II - S_I**2     dT = N*S_TT - S_T**2
+
+then in IEEE double, one rounding per operation, no fused multiply-add::
+
+    rI = 1.0 / sqrt(double(dI))          (per placement)
+    rT = 1.0 / sqrt(double(dT))          (per template)
+    q  = (double(numer) * rI) * rT
+    R  = q if |q| < 1 ; copysign(1, q) if |q| < 1.125 ; else 0      (OpenCV's clamp)
+    R  = 0 where the window variance is negligible:
+         2*dI <= N  and  dI * 2**23 <= 10 * N * S_II
+         (OpenCV: diff2 <= min(0.5, 10*FLT_EPSILON*wndSum2), diff2 = dI/N)
+    R  = 1 everywhere when dT == 0 (OpenCV: constant template)
+    result = float32(R)
+"""
+from __future__ import annotations
+
+import numpy as np
+
+FLAG_HES_NORM = 1
+FLAG_HES_SMTH = 2
+FLAG_MCC_NORM = 4
+
+
+# --------------------------------------------------------------------------- a1
+def rotation_terms(angle_deg, img_size):
+    """(cos a, sin a, tcT0, tcT1) exactly as pmlib.py:105-110 builds them.
+
+    tc = int(s/2.)+1 for both axes; transform = [[cos,-sin],[sin,cos]];
+    tcT = tc.dot(transform) (kept as NumPy's own dot so rounding is NumPy's).
+    """
+    tc = int(img_size / 2.) + 1
+    tc = np.array([tc, tc])
+    a = np.radians(angle_deg)
+    transform = np.array([[np.cos(a), -np.sin(a)], [np.sin(a), np.cos(a)]])
+    tct = tc.dot(transform)
+    return float(transform[0, 0]), float(transform[1, 0]), float(tct[0]), float(tct[1])
+
+
+def get_template(img, c, r, a, s):
+    """Rotated s*s uint8 template around (c, r) on ``img`` (pmlib.py:89-115,
+    rot_order=0).  Closed form of scipy's NI_GeometricTransform at order 0 with
+    mode='constant', cval=0:  coordinate = (0.0 + i*M00) + j*M01 + off, sampled at
+    floor(coordinate + 0.5); a coordinate < 0 or > dim-1 yields 0.
+    """
+    cosa, sina, tct0, tct1 = rotation_terms(a, s)
+    off0 = np.float64(r) - tct0
+    off1 = np.float64(c) - tct1
+    ii = np.arange(s, dtype=np.float64)[:, None]
+    jj = np.arange(s, dtype=np.float64)[None, :]
+    # matrix passed to scipy is transform.T = [[cos, sin], [-sin, cos]]
+    rr = ((0.0 + ii * cosa) + jj * sina) + off0
+    cc = ((0.0 + ii * (-sina)) + jj * cosa) + off1
+    rows, cols = img.shape
+    inside = (rr >= 0) & (rr <= rows - 1) & (cc >= 0) & (cc <= cols - 1)
+    ri = np.floor(rr + 0.5).astype(np.int64)
+    ci = np.floor(cc + 0.5).astype(np.int64)
+    ri = np.clip(ri, 0, rows - 1)
+    ci = np.clip(ci, 0, cols - 1)
+    out = np.where(inside, img[ri, ci], 0).astype(np.uint8)
+    return out
+
+
+# --------------------------------------------------------------------------- a3
+def window_sums(image, s):
+    """Exact S_I and S_II for every placement of an s*s box (int64)."""
+    img = image.astype(np.int64)
+    def box(x):
+        ii = np.zeros((x.shape[0] + 1, x.shape[1] + 1), dtype=np.int64)
+        ii[1:, 1:] = x.cumsum(0).cumsum(1)
+        return ii[s:, s:] - ii[:-s, s:] - ii[s:, :-s] + ii[:-s, :-s]
+    return box(img), box(img * img)
+
+
+def raw_correlation(image, templ):
+    """Exact sum W*T for every placement (int64)."""
+    s0, s1 = templ.shape
+    rh, rw = image.shape[0] - s0 + 1, image.shape[1] - s1 + 1
+    img = image.astype(np.int64)
+    acc = np.zeros((rh, rw), dtype=np.int64)
+    for i in range(s0):
+        for j in range(s1):
+            t = int(templ[i, j])
+            if t:
+                acc += t * img[i:i + rh, j:j + rw]
+    return acc
+
+
+def match_template(image, templ, mtype=None):
+    """Restated cv2.matchTemplate(image, templ, cv2.TM_CCOEFF_NORMED) (pmlib.py:156).
+
+    Signature matches the reference's ``template_matcher`` plug point
+    (pmlib.py:119-120).  See the module docstring for the arithmetic.
+    """
+    s = templ.shape[0]
+    assert templ.shape[0] == templ.shape[1], 'square templates only on this path'
+    n = s * s
+    s_i, s_ii = window_sums(image, s)
+    s_it = raw_correlation(image, templ)
+    t64 = templ.astype(np.int64)
+    s_t = int(t64.sum())
+    s_tt = int((t64 * t64).sum())
+    d_t = n * s_tt - s_t * s_t
+    if d_t == 0:
+        return np.ones(s_it.shape, dtype=np.float32)
+    numer = n * s_it - s_i * s_t
+    d_i = n * s_ii - s_i * s_i
+    small = 2 * d_i <= n                      # guards the shift below against overflow
+    lowvar = small & (np.where(small, d_i, 0) * (1 << 23) <= 10 * n * s_ii)
+    with np.errstate(divide='ignore', invalid='ignore'):
+        r_i = 1.0 / np.sqrt(d_i.astype(np.float64))
+        r_t = 1.0 / np.sqrt(np.float64(d_t))
+        q = (numer.astype(np.float64) * r_i) * r_t
+    aq = np.abs(q)
+    res = np.where(aq < 1.0, q, np.where(aq < 1.125, np.copysign(1.0, q), 0.0))
+    res = np.where(lowvar, 0.0, res)
+    return res.astype(np.float32)
+
+
+def ncc_bruteforce_f64(image, templ):
+    """Independent zero-mean NCC in float64 (definition, not OpenCV's algebra);
+    used only to cross-check match_template in tests."""
+    s = templ.shape[0]
+    rh, rw = image.shape[0] - s + 1, image.shape[1] - s + 1
+    t = templ.astype(np.float64)
+    t = t - t.mean()
+    tn = np.sqrt((t * t).sum())
+    out = np.zeros((rh, rw))
+    for y in range(rh):
+        for x in range(rw):
+            w = image[y:y + s, x:x + s].astype(np.float64)
+            w = w - w.mean()
+            d = np.sqrt((w * w).sum()) * tn
+            out[y, x] = (w * t).sum() / d if d > 0 else 0.0
+    return out
+
+
+# --------------------------------------------------------------------------- a5
+def _gradient_f32(f, axis):
+    """1-D second-order central difference with one-sided edges, float32, the
+    arithmetic np.gradient applies with unit spacing (pmlib.py:51-54)."""
+    f = np.asarray(f, dtype=np.float32)
+    f = np.moveaxis(f, axis, 0)
+    g = np.empty_like(f)
+    g[1:-1] = (f[2:] - f[:-2]) / np.float32(2.0)
+    g[0] = f[1] - f[0]
+    g[-1] = f[-1] - f[-2]
+    return np.moveaxis(g, 0, axis)
+
+
+def raw_hessian(ccm):
+    """hypot(d2/dx2, d2/dy2) in float32 (pmlib.py:51-55)."""
+    ccm = np.asarray(ccm, dtype=np.float32)
+    d2x = _gradient_f32(_gradient_f32(ccm, 1), 1)
+    d2y = _gradient_f32(_gradient_f32(ccm, 0), 0)
+    return np.hypot(d2x, d2y)
+
+
+def get_hessian(ccm, hes_norm=True, hes_smth=False):
+    """pmlib.py:36-59."""
+    ccm = np.asarray(ccm, dtype=np.float32)
+    if hes_smth:
+        from scipy import ndimage as nd
+        ccm = nd.gaussian_filter(ccm, 1)
+    hes = raw_hessian(ccm)
+    if hes_norm:
+        hes = (hes - np.median(hes)) / np.std(hes)
+    return hes
+
+
+# ----------------------------------------------------------------------- a2,a4,a6
+def rotate_and_match(img1, c1, r1, img_size, image2, alpha0, angles=(-3, 0, 3),
+                     mcc_norm=False, hes_norm=True, hes_smth=False, full=False):
+    """pmlib.py:117-174.  Returns (dc, dr, best_a, best_r, best_h) and, with
+    full=True, also (best_ij, best_angle_index, best_result, best_template)."""
+    nan = np.nan
+    best_r = -np.inf
+    best = None
+    for k, angle in enumerate(angles):
+        template = get_template(img1, c1, r1, angle - alpha0, img_size)
+        if template.min() == 0:                                   # pmlib.py:152-154
+            if full:
+                return (nan, nan, nan, nan, nan), ((-1, -1), -1, None, None)
+            return nan, nan, nan, nan, nan
+        result = match_template(image2, template)
+        ij = np.unravel_index(np.argmax(result), result.shape)   # first max, row-major
+        if result.max() > best_r:                                 # strict: first angle wins ties
+            best_r = result.max()
+            best = (angle, result, template, ij, k)
+    best_a, best_result, best_template, best_ij, best_k = best
+    best_h = get_hessian(best_result, hes_norm=hes_norm, hes_smth=hes_smth)[best_ij]
+    dr = best_ij[0] - (image2.shape[0] - img_size) / 2.
+    dc = best_ij[1] - (image2.shape[1] - img_size) / 2.
+    if mcc_norm:
+        best_r = (best_r - np.median(best_result)) / np.std(best_result)
+    out = (dc, dr, best_a, best_r, best_h)
+    if full:
+        return out, ((int(best_ij[0]), int(best_ij[1])), best_k, best_result, best_template)
+    return out
+
+
+def window_bounds(c2fg, r2fg, border, img_size):
+    """Row/col slice limits of the search window (pmlib.py:200-202)."""
+    hws = int(img_size / 2.)
+    return (int(r2fg - hws - border), int(r2fg + hws + border + 1),
+            int(c2fg - hws - border), int(c2fg + hws + border + 1))
+
+
+def use_mcc(c1, r1, c2fg, r2fg, border, img1, img2, img_size, alpha0, full=False, **kw):
+    """pmlib.py:176-212.  A window that is not wholly inside img2 (never produced by
+    the reference's validity mask, pmlib.py:417-426) yields NaN*5."""
+    r0, r1_, c0, c1_ = window_bounds(c2fg, r2fg, border, img_size)
+    ok = (0 <= r0 and 0 <= c0 and r1_ <= img2.shape[0] and c1_ <= img2.shape[1]
+          and r1_ - r0 >= img_size and c1_ - c0 >= img_size)
+    if not ok:
+        nan = np.nan
+        return ((nan,) * 5, ((-1, -1), -1, None, None)) if full else (nan,) * 5
+    image = img2[r0:r1_, c0:c1_]
+    res = rotate_and_match(img1, c1, r1, img_size, image, alpha0, full=full, **kw)
+    (dc, dr, a, r, h) = res[0] if full else res
+    out = (c2fg + dc, r2fg + dr, a, r, h)
+    return (out, res[1]) if full else out
+
+
+# --------------------------------------------------------------------------- a7
+def pm_batch(img1, img2, c1, r1, c2fg, r2fg, border, img_size, alpha0, angles,
+             flags=FLAG_HES_NORM):
+    """The batch seam of pmlib.py:436-448 + :462 : (N,5) float64 and (N,3) int32
+    [best row, best col, best angle index] (-1 for NaN points)."""
+    n = len(c1)
+    out = np.full((n, 5), np.nan)
+    ij = np.full((n, 3), -1, dtype=np.int32)
+    kw = dict(angles=list(angles), hes_norm=bool(flags & FLAG_HES_NORM),
+              hes_smth=bool(flags & FLAG_HES_SMTH), mcc_norm=bool(flags & FLAG_MCC_NORM))
+    for i in range(n):
+        res, (bij, bk, _, _) = use_mcc(c1[i], r1[i], c2fg[i], r2fg[i], border[i], img1, img2,
+                                       img_size, alpha0, full=True, **kw)
+        out[i] = res
+        ij[i] = (bij[0], bij[1], bk)
+    return out, ij
