@@ -1,0 +1,255 @@
+"""ctypes binding of libsid_pm.so (the C ABI of include/sid_pm.h).
+
+This is the only way the Python host code reaches the GPU.  There is no CPU fallback:
+if the HIP library is missing or no gfx950 device is visible, calls raise.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libsid_pm.so')
+
+HES_NORM = 1
+HES_SMTH = 2
+MCC_NORM = 4
+
+ABI_VERSION = 1
+
+# every symbol include/sid_pm.h declares
+SYMBOLS = (
+    'sid_pm_abi_version', 'sid_pm_strerror', 'sid_pm_last_error', 'sid_pm_device_count',
+    'sid_pm_batch', 'sid_pm_create', 'sid_pm_destroy', 'sid_pm_set_stream', 'sid_pm_upload_pair',
+    'sid_pm_select_pair', 'sid_pm_bind_pair', 'sid_pm_set_points', 'sid_pm_run', 'sid_pm_sync',
+    'sid_pm_fetch', 'sid_pm_device_results', 'sid_pm_work_info', 'sid_pm_debug_point',
+    'sid_pm_debug_rsqrt',
+)
+
+_u8p = C.POINTER(C.c_uint8)
+_f64p = C.POINTER(C.c_double)
+_f32p = C.POINTER(C.c_float)
+_i32p = C.POINTER(C.c_int32)
+_lib = None
+
+
+class SidPmError(RuntimeError):
+    def __init__(self, code, msg):
+        RuntimeError.__init__(self, 'sid_pm error %d: %s' % (code, msg))
+        self.code = code
+
+
+def lib():
+    """Load libsid_pm.so once; raise with build instructions if it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            '%s not found: build it with `make -C %s` (hipcc --offload-arch=gfx950) or '
+            '`python -c "import __graft_entry__ as g; g.build()"`. There is no CPU fallback.'
+            % (LIB_PATH, os.path.join(_HERE, 'csrc')))
+    L = C.CDLL(LIB_PATH)
+    img = [_u8p, C.c_int64, C.c_int64, C.c_int64]
+    ptr = [C.c_void_p, C.c_int64, C.c_int64, C.c_int64]
+    L.sid_pm_abi_version.restype = C.c_int
+    L.sid_pm_strerror.restype = C.c_char_p
+    L.sid_pm_strerror.argtypes = [C.c_int]
+    L.sid_pm_last_error.restype = C.c_char_p
+    L.sid_pm_device_count.argtypes = [C.POINTER(C.c_int)]
+    L.sid_pm_batch.argtypes = img + img + [_f64p] * 5 + [C.c_int64, C.c_int, C.c_double, _f64p, _f64p,
+                                                        C.c_int, C.c_uint32, _f64p, _i32p]
+    L.sid_pm_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
+    L.sid_pm_destroy.argtypes = [C.c_void_p]
+    L.sid_pm_destroy.restype = None
+    L.sid_pm_set_stream.argtypes = [C.c_void_p, C.c_void_p]
+    L.sid_pm_upload_pair.argtypes = [C.c_void_p, C.c_int] + img + img
+    L.sid_pm_select_pair.argtypes = [C.c_void_p, C.c_int]
+    L.sid_pm_bind_pair.argtypes = [C.c_void_p] + ptr + ptr
+    L.sid_pm_set_points.argtypes = [C.c_void_p] + [_f64p] * 5 + [C.c_int64, C.c_int, C.c_double, _f64p, _f64p,
+                                                                C.c_int, C.c_uint32]
+    L.sid_pm_run.argtypes = [C.c_void_p]
+    L.sid_pm_sync.argtypes = [C.c_void_p]
+    L.sid_pm_fetch.argtypes = [C.c_void_p, _f64p, _i32p]
+    L.sid_pm_device_results.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]
+    L.sid_pm_work_info.argtypes = [C.c_void_p, _f64p]
+    L.sid_pm_debug_point.argtypes = [C.c_void_p] + [C.c_double] * 5 + [C.c_int, C.c_double, _f64p, _f64p, C.c_int,
+                                                                      C.c_uint32, _u8p, _f32p, _f32p, C.c_int64,
+                                                                      _i32p, _f64p, _i32p]
+    L.sid_pm_debug_rsqrt.argtypes = [C.c_void_p, _f64p, _f64p, C.c_int64]
+    for name in SYMBOLS:
+        getattr(L, name)                      # AttributeError here = header/library mismatch
+    if L.sid_pm_abi_version() != ABI_VERSION:
+        raise ImportError('libsid_pm.so ABI %d != binding ABI %d' % (L.sid_pm_abi_version(), ABI_VERSION))
+    _lib = L
+    return L
+
+
+def _check(rc):
+    if rc != 0:
+        L = lib()
+        msg = L.sid_pm_last_error() or L.sid_pm_strerror(rc)
+        raise SidPmError(rc, msg.decode() if isinstance(msg, bytes) else str(msg))
+
+
+def device_count():
+    n = C.c_int(0)
+    rc = lib().sid_pm_device_count(C.byref(n))
+    return n.value if rc == 0 else 0
+
+
+def _u8(a):
+    a = np.asarray(a)
+    if a.dtype != np.uint8 or a.ndim != 2:
+        raise TypeError('images must be 2-D uint8 arrays (reference contract: lib.py:27-59)')
+    if a.strides[1] != 1:
+        a = np.ascontiguousarray(a)
+    return a
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _p(a, t):
+    return a.ctypes.data_as(t)
+
+
+def flags_from_kwargs(hes_norm=True, hes_smth=False, mcc_norm=False):
+    return (HES_NORM if hes_norm else 0) | (HES_SMTH if hes_smth else 0) | (MCC_NORM if mcc_norm else 0)
+
+
+def pm_batch(img1, img2, c1, r1, c2fg, r2fg, border, img_size, alpha0, angles, rot=None, flags=HES_NORM):
+    """One-shot host call == the Pool.map seam (pmlib.py:436-448).  -> (N,5) f64, (N,3) i32."""
+    img1, img2 = _u8(img1), _u8(img2)
+    v = [_f64(x) for x in (c1, r1, c2fg, r2fg, border)]
+    n = len(v[0])
+    angles = _f64(angles)
+    rotp = None
+    if rot is not None:
+        rot = _f64(rot)
+        rotp = _p(rot, _f64p)
+    out = np.empty((n, 5), dtype=np.float64)
+    ij = np.empty((n, 3), dtype=np.int32)
+    _check(lib().sid_pm_batch(_p(img1, _u8p), img1.shape[0], img1.shape[1], img1.strides[0],
+                              _p(img2, _u8p), img2.shape[0], img2.shape[1], img2.strides[0],
+                              *[_p(x, _f64p) for x in v], n, int(img_size), float(alpha0),
+                              _p(angles, _f64p), rotp, len(angles), int(flags), _p(out, _f64p), _p(ij, _i32p)))
+    return out, ij
+
+
+class PMContext(object):
+    """Device-resident handle: images and points stay in HBM between runs."""
+
+    def __init__(self, device=0):
+        self._h = C.c_void_p()
+        _check(lib().sid_pm_create(int(device), C.byref(self._h)))
+        self.device = int(device)
+        self.n = 0
+        self._keep = []
+
+    def close(self):
+        if getattr(self, '_h', None) is not None and self._h.value:
+            lib().sid_pm_destroy(self._h)
+            self._h = C.c_void_p()
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def set_stream(self, stream_handle):
+        _check(lib().sid_pm_set_stream(self._h, C.c_void_p(int(stream_handle) if stream_handle else 0)))
+
+    def upload_pair(self, img1, img2, slot=0):
+        img1, img2 = _u8(img1), _u8(img2)
+        self._keep = [img1, img2]                     # async copy: keep the host buffers alive
+        _check(lib().sid_pm_upload_pair(self._h, int(slot),
+                                        _p(img1, _u8p), img1.shape[0], img1.shape[1], img1.strides[0],
+                                        _p(img2, _u8p), img2.shape[0], img2.shape[1], img2.strides[0]))
+
+    def select_pair(self, slot):
+        _check(lib().sid_pm_select_pair(self._h, int(slot)))
+
+    def bind_pair_ptr(self, p1, rows1, cols1, stride1, p2, rows2, cols2, stride2):
+        _check(lib().sid_pm_bind_pair(self._h, C.c_void_p(int(p1)), rows1, cols1, stride1,
+                                      C.c_void_p(int(p2)), rows2, cols2, stride2))
+
+    def bind_pair_tensors(self, t1, t2):
+        """Borrow two CUDA/HIP uint8 torch tensors (2-D, unit inner stride)."""
+        for t in (t1, t2):
+            if t.dim() != 2 or t.stride(1) != 1 or str(t.dtype) != 'torch.uint8' or not t.is_cuda:
+                raise TypeError('need 2-D uint8 device tensors with unit inner stride')
+        self._keep = [t1, t2]
+        self.bind_pair_ptr(t1.data_ptr(), t1.shape[0], t1.shape[1], t1.stride(0),
+                           t2.data_ptr(), t2.shape[0], t2.shape[1], t2.stride(0))
+
+    def set_points(self, c1, r1, c2fg, r2fg, border, img_size, alpha0, angles, rot=None, flags=HES_NORM):
+        v = [_f64(x) for x in (c1, r1, c2fg, r2fg, border)]
+        n = len(v[0])
+        if any(len(x) != n for x in v):
+            raise ValueError('point vectors differ in length')
+        angles = _f64(angles)
+        rotp = None
+        if rot is not None:
+            rot = _f64(rot)
+            if rot.shape != (len(angles), 4):
+                raise ValueError('rot must be [n_angles, 4]')
+            rotp = _p(rot, _f64p)
+        _check(lib().sid_pm_set_points(self._h, *[_p(x, _f64p) for x in v], n, int(img_size), float(alpha0),
+                                       _p(angles, _f64p), rotp, len(angles), int(flags)))
+        self.n = n
+
+    def run(self):
+        _check(lib().sid_pm_run(self._h))
+
+    def sync(self):
+        _check(lib().sid_pm_sync(self._h))
+
+    def fetch(self, want_ij=True):
+        out = np.empty((self.n, 5), dtype=np.float64)
+        ij = np.empty((self.n, 3), dtype=np.int32) if want_ij else None
+        _check(lib().sid_pm_fetch(self._h, _p(out, _f64p), _p(ij, _i32p) if want_ij else None))
+        return (out, ij) if want_ij else out
+
+    def device_results(self):
+        a, b = C.c_void_p(), C.c_void_p()
+        _check(lib().sid_pm_device_results(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def work_info(self):
+        info = np.zeros(6, dtype=np.float64)
+        _check(lib().sid_pm_work_info(self._h, _p(info, _f64p)))
+        return dict(launches=int(info[0]), valid_points=int(info[1]), macs=float(info[2]),
+                    hbm_bytes=float(info[3]), max_lds_bytes=int(info[4]))
+
+    def debug_point(self, c1, r1, c2fg, r2fg, border, img_size, alpha0, angles, rot=None, flags=HES_NORM,
+                    cap=256 * 256):
+        angles = _f64(angles)
+        rotp = None
+        if rot is not None:
+            rot = _f64(rot)
+            rotp = _p(rot, _f64p)
+        K, s = len(angles), int(img_size)
+        tm = np.zeros((K, s, s), dtype=np.uint8)
+        ccm = np.zeros(cap, dtype=np.float32)
+        hes = np.zeros(cap, dtype=np.float32)
+        shape = np.zeros(2, dtype=np.int32)
+        out5 = np.zeros(5, dtype=np.float64)
+        ij3 = np.zeros(3, dtype=np.int32)
+        _check(lib().sid_pm_debug_point(self._h, float(c1), float(r1), float(c2fg), float(r2fg), float(border), s,
+                                        float(alpha0), _p(angles, _f64p), rotp, K, int(flags), _p(tm, _u8p),
+                                        _p(ccm, _f32p), _p(hes, _f32p), cap, _p(shape, _i32p), _p(out5, _f64p),
+                                        _p(ij3, _i32p)))
+        rh, rw = int(shape[0]), int(shape[1])
+        n = rh * rw
+        return dict(templates=tm, ccm=ccm[:n].reshape(rh, rw), hes=hes[:n].reshape(rh, rw), out=out5, ij=ij3)
+
+    def debug_rsqrt(self, x):
+        x = _f64(x)
+        y = np.empty_like(x)
+        _check(lib().sid_pm_debug_rsqrt(self._h, _p(x, _f64p), _p(y, _f64p), x.size))
+        return y

@@ -1,0 +1,525 @@
+// pm_capi.hip - host side of the C ABI declared in include/sid_pm.h.
+//
+// Replaces the reference's process pool (pmlib.py:430-448): the "shared_args" of the
+// workers become device-resident buffers owned by a handle, the Pool.map over point
+// indices becomes a few kernel launches (one per LDS-footprint class), and the pickled
+// 5-tuples coming back become one device array copied to the host.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <new>
+#include <numeric>
+#include <string>
+#include <vector>
+
+#include "../../include/sid_pm.h"
+#include "pm_kernel.h"
+
+#define SID_EXPORT extern "C" __attribute__((visibility("default")))
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
+int fail(int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess)                                                                  \
+            return fail(e_ == hipErrorOutOfMemory ? SID_PM_ERR_NOMEM : SID_PM_ERR_HIP,         \
+                        "%s failed: %s", #expr, hipGetErrorString(e_));                        \
+    } while (0)
+
+struct Image {
+    const uint8_t *ptr = nullptr;       // device
+    int64_t rows = 0, cols = 0, stride = 0;
+};
+
+struct Bucket { int offset, count, lds; };
+
+template <typename T>
+struct DevBuf {
+    T *p = nullptr;
+    size_t cap = 0;
+    int reserve(size_t n)
+    {
+        if (n <= cap) return SID_PM_OK;
+        if (p) (void)hipFree(p);
+        p = nullptr; cap = 0;
+        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&p), std::max<size_t>(n, 1) * sizeof(T)));
+        cap = n;
+        return SID_PM_OK;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+
+}  // namespace
+
+struct sid_pm_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    // image pairs: two owned slots + one borrowed binding
+    DevBuf<uint8_t> own[2][2];
+    Image slot_img[2][2];
+    Image cur[2];
+    bool have_pair = false;
+    int cur_slot = -1;                  // -1: borrowed binding (or none)
+    // resident points
+    DevBuf<double> vec;                 // 5 * n
+    DevBuf<int32_t> order;
+    DevBuf<double> angles, rot;
+    DevBuf<double> out;
+    DevBuf<int32_t> out_ij;
+    std::vector<Bucket> buckets;
+    int64_t n = 0;
+    int img_size = 0, n_angles = 0;
+    uint32_t flags = 0;
+    bool have_points = false;
+    double info[6] = {0, 0, 0, 0, 0, 0};
+};
+
+namespace {
+
+struct Guard {
+    int prev = -1;
+    explicit Guard(int dev) { (void)hipGetDevice(&prev); if (prev != dev) (void)hipSetDevice(dev); else prev = -1; }
+    ~Guard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+
+void make_rot(const double *angles, int n_angles, double alpha0, int s, const double *rot_in,
+              std::vector<double> &rot)
+{
+    rot.resize(4 * (size_t)n_angles);
+    if (rot_in) { memcpy(rot.data(), rot_in, sizeof(double) * rot.size()); return; }
+    // pmlib.py:105-110 with libm in place of NumPy's cos/sin
+    const double tc = (double)((int)((double)s / 2.) + 1);
+    for (int k = 0; k < n_angles; ++k) {
+        const double a = (angles[k] - alpha0) * (M_PI / 180.0);
+        const double ca = cos(a), sa = sin(a);
+        rot[4 * k + 0] = ca; rot[4 * k + 1] = sa;
+        rot[4 * k + 2] = tc * ca + tc * sa;
+        rot[4 * k + 3] = tc * (-sa) + tc * ca;
+    }
+}
+
+// window geometry of one point, the same arithmetic as the kernel (pmlib.py:200-202)
+bool window_dims(double c2fg, double r2fg, double border, int s, int64_t rows2, int64_t cols2,
+                 int &wh, int &ww)
+{
+    const int hws = (int)((double)s / 2.0);
+    const double r0d = r2fg - hws - border, r1d = r2fg + hws + border + 1;
+    const double c0d = c2fg - hws - border, c1d = c2fg + hws + border + 1;
+    if (!(fabs(r0d) < 1e15 && fabs(r1d) < 1e15 && fabs(c0d) < 1e15 && fabs(c1d) < 1e15)) return false;
+    const int64_t r0 = (int64_t)r0d, r1e = (int64_t)r1d, c0 = (int64_t)c0d, c1e = (int64_t)c1d;
+    if (!(r0 >= 0 && c0 >= 0 && r1e <= rows2 && c1e <= cols2 && r1e - r0 >= s + 1 && c1e - c0 >= s + 1))
+        return false;
+    wh = (int)(r1e - r0); ww = (int)(c1e - c0);
+    return true;
+}
+
+int check_images(const Image &a, const Image &b)
+{
+    if (!a.ptr || !b.ptr) return fail(SID_PM_ERR_ARG, "null image pointer");
+    if (a.rows < 1 || a.cols < 1 || a.stride < a.cols || b.rows < 1 || b.cols < 1 || b.stride < b.cols)
+        return fail(SID_PM_ERR_ARG, "bad image shape/stride");
+    return SID_PM_OK;
+}
+
+int check_sweep(int img_size, const double *angles, int n_angles, uint32_t flags)
+{
+    if (!angles || n_angles < 1)
+        return fail(SID_PM_ERR_ARG, "angles must hold at least one angle (the reference's loop, pmlib.py:150, "
+                                    "leaves best_result undefined for an empty list)");
+    if (n_angles > sid::kMaxAngles) return fail(SID_PM_ERR_UNSUPPORTED, "more than %d angles", sid::kMaxAngles);
+    if (!sid::img_size_supported(img_size))
+        return fail(SID_PM_ERR_UNSUPPORTED, "img_size=%d: kernels are instantiated for 33..36", img_size);
+    if (flags & SID_PM_HES_SMTH) return fail(SID_PM_ERR_UNSUPPORTED, "hes_smth=True is not implemented on the device");
+    if (flags & ~(SID_PM_HES_NORM | SID_PM_HES_SMTH | SID_PM_MCC_NORM)) return fail(SID_PM_ERR_ARG, "unknown flag bits");
+    return SID_PM_OK;
+}
+
+int fill_args(sid_pm_ctx *ctx, sid::PMArgs &A)
+{
+    memset(&A, 0, sizeof A);
+    A.img1 = ctx->cur[0].ptr; A.rows1 = ctx->cur[0].rows; A.cols1 = ctx->cur[0].cols; A.stride1 = ctx->cur[0].stride;
+    A.img2 = ctx->cur[1].ptr; A.rows2 = ctx->cur[1].rows; A.cols2 = ctx->cur[1].cols; A.stride2 = ctx->cur[1].stride;
+    const int64_t n = ctx->n;
+    A.c1 = ctx->vec.p; A.r1 = ctx->vec.p + n; A.c2fg = ctx->vec.p + 2 * n; A.r2fg = ctx->vec.p + 3 * n;
+    A.border = ctx->vec.p + 4 * n;
+    A.img_size = ctx->img_size; A.n_angles = ctx->n_angles; A.flags = ctx->flags;
+    A.angles = ctx->angles.p; A.rot = ctx->rot.p;
+    A.out = ctx->out.p; A.out_ij = ctx->out_ij.p;
+    return SID_PM_OK;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------- API
+SID_EXPORT int sid_pm_abi_version(void) { return SID_PM_ABI_VERSION; }
+
+SID_EXPORT const char *sid_pm_strerror(int code)
+{
+    switch (code) {
+    case SID_PM_OK: return "ok";
+    case SID_PM_ERR_ARG: return "bad argument";
+    case SID_PM_ERR_HIP: return "HIP runtime error";
+    case SID_PM_ERR_NOMEM: return "out of memory";
+    case SID_PM_ERR_UNSUPPORTED: return "unsupported option or size";
+    case SID_PM_ERR_NODEVICE: return "no gfx950 device";
+    case SID_PM_ERR_STATE: return "call order violated";
+    default: return "unknown error";
+    }
+}
+
+SID_EXPORT const char *sid_pm_last_error(void) { return g_err.c_str(); }
+
+SID_EXPORT int sid_pm_device_count(int *count)
+{
+    if (!count) return fail(SID_PM_ERR_ARG, "null count");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) { *count = 0; return fail(SID_PM_ERR_NODEVICE, "hipGetDeviceCount: %s", hipGetErrorString(e)); }
+    *count = n;
+    return SID_PM_OK;
+}
+
+SID_EXPORT int sid_pm_create(int device, sid_pm_ctx **out)
+{
+    if (!out) return fail(SID_PM_ERR_ARG, "null ctx pointer");
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n < 1) return fail(SID_PM_ERR_NODEVICE, "no HIP device visible");
+    if (device < 0 || device >= n) return fail(SID_PM_ERR_ARG, "device %d out of range (0..%d)", device, n - 1);
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(SID_PM_ERR_NODEVICE, "device %d is %s; this library carries gfx950 code only", device, prop.gcnArchName);
+    sid_pm_ctx *ctx = new (std::nothrow) sid_pm_ctx();
+    if (!ctx) return fail(SID_PM_ERR_NOMEM, "host allocation failed");
+    ctx->device = device;
+    *out = ctx;
+    return SID_PM_OK;
+}
+
+SID_EXPORT void sid_pm_destroy(sid_pm_ctx *ctx)
+{
+    if (!ctx) return;
+    Guard g(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    for (auto &pair : ctx->own) for (auto &b : pair) b.release();
+    ctx->vec.release(); ctx->order.release(); ctx->angles.release(); ctx->rot.release();
+    ctx->out.release(); ctx->out_ij.release();
+    delete ctx;
+}
+
+SID_EXPORT int sid_pm_set_stream(sid_pm_ctx *ctx, void *hip_stream)
+{
+    if (!ctx) return fail(SID_PM_ERR_ARG, "null ctx");
+    ctx->stream = reinterpret_cast<hipStream_t>(hip_stream);
+    return SID_PM_OK;
+}
+
+SID_EXPORT int sid_pm_upload_pair(sid_pm_ctx *ctx, int slot,
+                                  const uint8_t *img1, int64_t rows1, int64_t cols1, int64_t stride1,
+                                  const uint8_t *img2, int64_t rows2, int64_t cols2, int64_t stride2)
+{
+    if (!ctx) return fail(SID_PM_ERR_ARG, "null ctx");
+    if (slot < 0 || slot > 1) return fail(SID_PM_ERR_ARG, "slot must be 0 or 1");
+    Image h[2] = {{img1, rows1, cols1, stride1}, {img2, rows2, cols2, stride2}};
+    if (int rc = check_images(h[0], h[1])) return rc;
+    Guard g(ctx->device);
+    for (int k = 0; k < 2; ++k) {
+        // device copy is packed to a 256-byte multiple pitch (coalesced, dword-aligned rows)
+        const int64_t pitch = (h[k].cols + 255) / 256 * 256;
+        if (int rc = ctx->own[slot][k].reserve((size_t)(pitch * h[k].rows))) return rc;
+        HIP_TRY(hipMemcpy2DAsync(ctx->own[slot][k].p, (size_t)pitch, h[k].ptr, (size_t)h[k].stride,
+                                 (size_t)h[k].cols, (size_t)h[k].rows, hipMemcpyHostToDevice, ctx->stream));
+        ctx->slot_img[slot][k] = Image{ctx->own[slot][k].p, h[k].rows, h[k].cols, pitch};
+    }
+    if (!ctx->have_pair || ctx->cur_slot == slot) {       // first pair, or refresh of the selected slot
+        ctx->cur[0] = ctx->slot_img[slot][0]; ctx->cur[1] = ctx->slot_img[slot][1];
+        ctx->have_pair = true; ctx->cur_slot = slot;
+    }
+    return SID_PM_OK;
+}
+
+SID_EXPORT int sid_pm_select_pair(sid_pm_ctx *ctx, int slot)
+{
+    if (!ctx) return fail(SID_PM_ERR_ARG, "null ctx");
+    if (slot < 0 || slot > 1 || !ctx->slot_img[slot][0].ptr) return fail(SID_PM_ERR_STATE, "slot %d holds no pair", slot);
+    ctx->cur[0] = ctx->slot_img[slot][0]; ctx->cur[1] = ctx->slot_img[slot][1];
+    ctx->have_pair = true; ctx->cur_slot = slot;
+    return SID_PM_OK;
+}
+
+SID_EXPORT int sid_pm_bind_pair(sid_pm_ctx *ctx,
+                                const uint8_t *d_img1, int64_t rows1, int64_t cols1, int64_t stride1,
+                                const uint8_t *d_img2, int64_t rows2, int64_t cols2, int64_t stride2)
+{
+    if (!ctx) return fail(SID_PM_ERR_ARG, "null ctx");
+    Image d[2] = {{d_img1, rows1, cols1, stride1}, {d_img2, rows2, cols2, stride2}};
+    if (int rc = check_images(d[0], d[1])) return rc;
+    ctx->cur[0] = d[0]; ctx->cur[1] = d[1];
+    ctx->have_pair = true; ctx->cur_slot = -1;
+    return SID_PM_OK;
+}
+
+SID_EXPORT int sid_pm_set_points(sid_pm_ctx *ctx, const double *c1, const double *r1, const double *c2fg,
+                                 const double *r2fg, const double *border, int64_t n, int img_size,
+                                 double alpha0, const double *angles, const double *rot, int n_angles,
+                                 uint32_t flags)
+{
+    if (!ctx) return fail(SID_PM_ERR_ARG, "null ctx");
+    if (n < 0 || n > 0x7fffffff / 8) return fail(SID_PM_ERR_ARG, "bad point count");
+    if (n > 0 && (!c1 || !r1 || !c2fg || !r2fg || !border)) return fail(SID_PM_ERR_ARG, "null point vector");
+    if (int rc = check_sweep(img_size, angles, n_angles, flags)) return rc;
+    if (!ctx->have_pair) return fail(SID_PM_ERR_STATE, "set_points needs an image pair (upload_pair/bind_pair first)");
+    Guard g(ctx->device);
+    const int s = img_size, K = n_angles;
+    const int64_t rows2 = ctx->cur[1].rows, cols2 = ctx->cur[1].cols;
+
+    // classify: LDS footprint -> residency class (blocks per CU), work for ordering
+    struct P { int idx; int lds; int cls; double work; };
+    std::vector<P> pts((size_t)n);
+    const int lds_min = sid::lds_layout(s + 1, s + 1, s, K).total;
+    double macs = 0, bytes = 0, valid = 0;
+    int lds_max = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        int wh = 0, ww = 0;
+        P p{(int)i, lds_min, 0, 0.0};
+        if (window_dims(c2fg[i], r2fg[i], border[i], s, rows2, cols2, wh, ww)) {
+            const sid::LdsLayout L = sid::lds_layout(wh, ww, s, K);
+            if (L.total > sid::max_lds_bytes())
+                return fail(SID_PM_ERR_UNSUPPORTED, "point %lld: search window %dx%d needs %d bytes of LDS (> %d)",
+                            (long long)i, wh, ww, L.total, sid::max_lds_bytes());
+            p.lds = L.total;
+            const double rh = wh - s + 1, rw = ww - s + 1;
+            p.work = rh * rw;
+            macs += (double)K * rh * rw * s * s;
+            // window + bounding box of the rotated template + 5 inputs + outputs
+            bytes += (double)wh * ww + 51.0 * 51.0 + 40.0 + 52.0;
+            valid += 1;
+        }
+        p.cls = std::min(8, sid::max_lds_bytes() / p.lds);
+        lds_max = std::max(lds_max, p.lds);
+        pts[(size_t)i] = p;
+    }
+    std::sort(pts.begin(), pts.end(), [](const P &a, const P &b) {
+        if (a.cls != b.cls) return a.cls < b.cls;                 // biggest footprints first
+        if (a.work != b.work) return a.work > b.work;             // then longest first
+        return a.idx < b.idx;
+    });
+    std::vector<int32_t> order((size_t)n);
+    ctx->buckets.clear();
+    for (int64_t i = 0; i < n; ++i) {
+        order[(size_t)i] = pts[(size_t)i].idx;
+        if (ctx->buckets.empty() || pts[(size_t)i].cls != pts[(size_t)(i - 1)].cls)
+            ctx->buckets.push_back(Bucket{(int)i, 0, 0});
+        Bucket &b = ctx->buckets.back();
+        b.count += 1;
+        b.lds = std::max(b.lds, pts[(size_t)i].lds);
+    }
+
+    std::vector<double> rotv;
+    make_rot(angles, K, alpha0, s, rot, rotv);
+
+    if (int rc = ctx->vec.reserve((size_t)(5 * n))) return rc;
+    if (int rc = ctx->order.reserve((size_t)n)) return rc;
+    if (int rc = ctx->angles.reserve((size_t)K)) return rc;
+    if (int rc = ctx->rot.reserve((size_t)(4 * K))) return rc;
+    if (int rc = ctx->out.reserve((size_t)(5 * n))) return rc;
+    if (int rc = ctx->out_ij.reserve((size_t)(3 * n))) return rc;
+    // synchronous copies: the host vectors are caller-owned and not retained
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    const double *src[5] = {c1, r1, c2fg, r2fg, border};
+    for (int k = 0; k < 5 && n > 0; ++k)
+        HIP_TRY(hipMemcpy(ctx->vec.p + k * n, src[k], sizeof(double) * (size_t)n, hipMemcpyHostToDevice));
+    if (n > 0) HIP_TRY(hipMemcpy(ctx->order.p, order.data(), sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(ctx->angles.p, angles, sizeof(double) * (size_t)K, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(ctx->rot.p, rotv.data(), sizeof(double) * rotv.size(), hipMemcpyHostToDevice));
+
+    ctx->n = n; ctx->img_size = s; ctx->n_angles = K; ctx->flags = flags;
+    ctx->have_points = true;
+    const double img_bytes = (double)ctx->cur[0].rows * ctx->cur[0].cols + (double)rows2 * cols2;
+    ctx->info[0] = (double)ctx->buckets.size();
+    ctx->info[1] = valid;
+    ctx->info[2] = macs;
+    ctx->info[3] = std::min(bytes, img_bytes + 92.0 * valid);
+    ctx->info[4] = (double)lds_max;
+    ctx->info[5] = 0;
+    return SID_PM_OK;
+}
+
+SID_EXPORT int sid_pm_run(sid_pm_ctx *ctx)
+{
+    if (!ctx) return fail(SID_PM_ERR_ARG, "null ctx");
+    if (!ctx->have_points || !ctx->have_pair) return fail(SID_PM_ERR_STATE, "run needs set_points and an image pair");
+    Guard g(ctx->device);
+    sid::PMArgs A;
+    fill_args(ctx, A);
+    for (const Bucket &b : ctx->buckets) {
+        A.order = ctx->order.p + b.offset;
+        A.n_launch = b.count;
+        const int e = sid::launch_pm(A, b.lds, ctx->stream);
+        if (e != 0) return fail(SID_PM_ERR_HIP, "kernel launch failed: %s", hipGetErrorString((hipError_t)e));
+    }
+    return SID_PM_OK;
+}
+
+SID_EXPORT int sid_pm_sync(sid_pm_ctx *ctx)
+{
+    if (!ctx) return fail(SID_PM_ERR_ARG, "null ctx");
+    Guard g(ctx->device);
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return SID_PM_OK;
+}
+
+SID_EXPORT int sid_pm_fetch(sid_pm_ctx *ctx, double *out, int32_t *out_ij)
+{
+    if (!ctx) return fail(SID_PM_ERR_ARG, "null ctx");
+    if (!ctx->have_points) return fail(SID_PM_ERR_STATE, "fetch before set_points");
+    if (ctx->n > 0 && !out) return fail(SID_PM_ERR_ARG, "null out");
+    Guard g(ctx->device);
+    if (ctx->n > 0) {
+        HIP_TRY(hipMemcpyAsync(out, ctx->out.p, sizeof(double) * 5 * (size_t)ctx->n, hipMemcpyDeviceToHost, ctx->stream));
+        if (out_ij)
+            HIP_TRY(hipMemcpyAsync(out_ij, ctx->out_ij.p, sizeof(int32_t) * 3 * (size_t)ctx->n, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return SID_PM_OK;
+}
+
+SID_EXPORT int sid_pm_device_results(sid_pm_ctx *ctx, double **d_out, int32_t **d_out_ij)
+{
+    if (!ctx) return fail(SID_PM_ERR_ARG, "null ctx");
+    if (!ctx->have_points) return fail(SID_PM_ERR_STATE, "device_results before set_points");
+    if (d_out) *d_out = ctx->out.p;
+    if (d_out_ij) *d_out_ij = ctx->out_ij.p;
+    return SID_PM_OK;
+}
+
+SID_EXPORT int sid_pm_work_info(sid_pm_ctx *ctx, double info[6])
+{
+    if (!ctx || !info) return fail(SID_PM_ERR_ARG, "null argument");
+    if (!ctx->have_points) return fail(SID_PM_ERR_STATE, "work_info before set_points");
+    memcpy(info, ctx->info, sizeof ctx->info);
+    return SID_PM_OK;
+}
+
+SID_EXPORT int sid_pm_batch(const uint8_t *img1, int64_t rows1, int64_t cols1, int64_t stride1,
+                            const uint8_t *img2, int64_t rows2, int64_t cols2, int64_t stride2,
+                            const double *c1, const double *r1, const double *c2fg, const double *r2fg,
+                            const double *border, int64_t n, int img_size, double alpha0,
+                            const double *angles, const double *rot, int n_angles, uint32_t flags,
+                            double *out, int32_t *out_ij)
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return fail(SID_PM_ERR_NODEVICE, "no current HIP device");
+    sid_pm_ctx *ctx = nullptr;
+    int rc = sid_pm_create(dev, &ctx);
+    if (rc) return rc;
+    rc = sid_pm_upload_pair(ctx, 0, img1, rows1, cols1, stride1, img2, rows2, cols2, stride2);
+    if (!rc) rc = sid_pm_set_points(ctx, c1, r1, c2fg, r2fg, border, n, img_size, alpha0, angles, rot, n_angles, flags);
+    if (!rc) rc = sid_pm_run(ctx);
+    if (!rc) rc = sid_pm_fetch(ctx, out, out_ij);
+    const std::string keep = g_err;
+    sid_pm_destroy(ctx);
+    if (rc) g_err = keep;
+    return rc;
+}
+
+SID_EXPORT int sid_pm_debug_point(sid_pm_ctx *ctx, double c1, double r1, double c2fg, double r2fg,
+                                  double border, int img_size, double alpha0, const double *angles,
+                                  const double *rot, int n_angles, uint32_t flags,
+                                  uint8_t *templates, float *ccm, float *hes, int64_t cap, int32_t rh_rw[2],
+                                  double out5[5], int32_t ij3[3])
+{
+    if (!ctx) return fail(SID_PM_ERR_ARG, "null ctx");
+    if (!ctx->have_pair) return fail(SID_PM_ERR_STATE, "debug_point needs an image pair");
+    if (int rc = check_sweep(img_size, angles, n_angles, flags)) return rc;
+    Guard g(ctx->device);
+    const int s = img_size, K = n_angles;
+    int wh = 0, ww = 0, lds = sid::lds_layout(s + 1, s + 1, s, K).total;
+    if (window_dims(c2fg, r2fg, border, s, ctx->cur[1].rows, ctx->cur[1].cols, wh, ww))
+        lds = sid::lds_layout(wh, ww, s, K).total;
+    if (lds > sid::max_lds_bytes()) return fail(SID_PM_ERR_UNSUPPORTED, "search window too large for LDS");
+    std::vector<double> rotv;
+    make_rot(angles, K, alpha0, s, rot, rotv);
+
+    DevBuf<double> dv, dang, drot, dout;
+    DevBuf<int32_t> dord, dij, dshape;
+    DevBuf<uint8_t> dt;
+    DevBuf<float> dccm, dhes;
+    int rc = SID_PM_OK;
+    auto cleanup = [&]() { dv.release(); dang.release(); drot.release(); dout.release(); dord.release();
+                           dij.release(); dshape.release(); dt.release(); dccm.release(); dhes.release(); };
+    const size_t tcount = (size_t)K * s * s;
+    if ((rc = dv.reserve(5)) || (rc = dang.reserve((size_t)K)) || (rc = drot.reserve(4 * (size_t)K)) ||
+        (rc = dout.reserve(5)) || (rc = dord.reserve(1)) || (rc = dij.reserve(3)) || (rc = dshape.reserve(2)) ||
+        (rc = dt.reserve(tcount)) || (rc = dccm.reserve((size_t)std::max<int64_t>(cap, 1))) ||
+        (rc = dhes.reserve((size_t)std::max<int64_t>(cap, 1)))) { cleanup(); return rc; }
+    const double v5[5] = {c1, r1, c2fg, r2fg, border};
+    const int32_t zero = 0, shape0[2] = {0, 0};
+    hipError_t e = hipSuccess;
+    auto step = [&](hipError_t x) { if (e == hipSuccess) e = x; };
+    step(hipStreamSynchronize(ctx->stream));
+    step(hipMemcpy(dv.p, v5, sizeof v5, hipMemcpyHostToDevice));
+    step(hipMemcpy(dang.p, angles, sizeof(double) * K, hipMemcpyHostToDevice));
+    step(hipMemcpy(drot.p, rotv.data(), sizeof(double) * rotv.size(), hipMemcpyHostToDevice));
+    step(hipMemcpy(dord.p, &zero, sizeof zero, hipMemcpyHostToDevice));
+    step(hipMemcpy(dshape.p, shape0, sizeof shape0, hipMemcpyHostToDevice));
+    step(hipMemset(dt.p, 0, tcount));
+    if (cap > 0) { step(hipMemset(dccm.p, 0, sizeof(float) * cap)); step(hipMemset(dhes.p, 0, sizeof(float) * cap)); }
+    if (e == hipSuccess) {
+        sid::PMArgs A;
+        memset(&A, 0, sizeof A);
+        A.img1 = ctx->cur[0].ptr; A.rows1 = ctx->cur[0].rows; A.cols1 = ctx->cur[0].cols; A.stride1 = ctx->cur[0].stride;
+        A.img2 = ctx->cur[1].ptr; A.rows2 = ctx->cur[1].rows; A.cols2 = ctx->cur[1].cols; A.stride2 = ctx->cur[1].stride;
+        A.c1 = dv.p; A.r1 = dv.p + 1; A.c2fg = dv.p + 2; A.r2fg = dv.p + 3; A.border = dv.p + 4;
+        A.order = dord.p; A.n_launch = 1; A.img_size = s; A.n_angles = K; A.flags = flags;
+        A.angles = dang.p; A.rot = drot.p; A.out = dout.p; A.out_ij = dij.p;
+        A.dbg_templates = dt.p; A.dbg_ccm = dccm.p; A.dbg_hes = dhes.p; A.dbg_shape = dshape.p; A.dbg_cap = cap;
+        step((hipError_t)sid::launch_pm(A, lds, ctx->stream));
+        step(hipStreamSynchronize(ctx->stream));
+        if (templates) step(hipMemcpy(templates, dt.p, tcount, hipMemcpyDeviceToHost));
+        if (ccm && cap > 0) step(hipMemcpy(ccm, dccm.p, sizeof(float) * cap, hipMemcpyDeviceToHost));
+        if (hes && cap > 0) step(hipMemcpy(hes, dhes.p, sizeof(float) * cap, hipMemcpyDeviceToHost));
+        if (rh_rw) step(hipMemcpy(rh_rw, dshape.p, sizeof(int32_t) * 2, hipMemcpyDeviceToHost));
+        if (out5) step(hipMemcpy(out5, dout.p, sizeof(double) * 5, hipMemcpyDeviceToHost));
+        if (ij3) step(hipMemcpy(ij3, dij.p, sizeof(int32_t) * 3, hipMemcpyDeviceToHost));
+    }
+    cleanup();
+    if (e != hipSuccess) return fail(SID_PM_ERR_HIP, "debug_point: %s", hipGetErrorString(e));
+    return SID_PM_OK;
+}
+
+SID_EXPORT int sid_pm_debug_rsqrt(sid_pm_ctx *ctx, const double *x, double *y, int64_t n)
+{
+    if (!ctx || !x || !y || n < 0) return fail(SID_PM_ERR_ARG, "bad argument");
+    Guard g(ctx->device);
+    DevBuf<double> dx, dy;
+    int rc;
+    if ((rc = dx.reserve((size_t)n)) || (rc = dy.reserve((size_t)n))) { dx.release(); dy.release(); return rc; }
+    hipError_t e = hipMemcpy(dx.p, x, sizeof(double) * (size_t)n, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = (hipError_t)sid::launch_rsqrt(dx.p, dy.p, n, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e == hipSuccess) e = hipMemcpy(y, dy.p, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost);
+    dx.release(); dy.release();
+    if (e != hipSuccess) return fail(SID_PM_ERR_HIP, "debug_rsqrt: %s", hipGetErrorString(e));
+    return SID_PM_OK;
+}

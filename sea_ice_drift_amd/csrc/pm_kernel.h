@@ -1,0 +1,65 @@
+// Shared between the HIP kernel (pm_kernel.hip) and the host C-ABI (pm_capi.hip).
+#pragma once
+#include <stdint.h>
+
+namespace sid {
+
+constexpr int kBlock = 256;          // threads per grid point: 4 wavefronts of 64
+constexpr int kStrip = 8;            // NCC outputs per thread-task along a row
+constexpr int kMaxAngles = 64;
+constexpr int kMiscBytes = 4096;     // fixed LDS header: histogram, reduction scratch, per-angle terms
+
+// Arguments of one launch (one block per grid point of this launch).
+struct PMArgs {
+    const uint8_t *img1; int64_t rows1, cols1, stride1;
+    const uint8_t *img2; int64_t rows2, cols2, stride2;
+    const double *c1, *r1, *c2fg, *r2fg, *border;   // [n_total], original point order
+    const int32_t *order;                           // [n_launch] -> original point index
+    int32_t n_launch;
+    int32_t img_size;                               // s
+    int32_t n_angles;                               // K
+    uint32_t flags;
+    const double *angles;                           // [K] degrees (reported as-is)
+    const double *rot;                              // [K][4] cos, sin, tcT0, tcT1
+    double *out;                                    // [n_total][5]
+    int32_t *out_ij;                                // [n_total][3]
+    // diagnostics (debug_point only; null in production launches)
+    uint8_t *dbg_templates; float *dbg_ccm; float *dbg_hes; int32_t *dbg_shape; int64_t dbg_cap;
+};
+
+// LDS carve-up for a window of wh x ww pixels, template side s, K angles.
+struct LdsLayout {
+    int wpitch;      // bytes per window row in LDS
+    int win_off, ccm_off, tmpl_off, total;
+};
+
+__host__ __device__ inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+// dwords per template row in LDS (zero padded, multiple of 4 so rows are 16-byte aligned)
+__host__ __device__ inline int tmpl_row_dwords(int s) { return round_up((s + 3) / 4, 4); }
+
+__host__ __device__ inline LdsLayout lds_layout(int wh, int ww, int s, int K)
+{
+    LdsLayout L;
+    const int rh = wh - s + 1, rw = ww - s + 1;
+    const int nch = (s + 3) / 4;
+    // a strip task reads (nch + 2) dwords rounded up to an even count from its first output
+    L.wpitch = round_up(rw, kStrip) - kStrip + round_up(nch + 2, 2) * 4;
+    if (L.wpitch < round_up(ww, 8)) L.wpitch = round_up(ww, 8);
+    L.win_off = kMiscBytes;
+    L.ccm_off = round_up(L.win_off + wh * L.wpitch, 16);
+    L.tmpl_off = round_up(L.ccm_off + rh * rw * 4, 16);
+    const int tmpl_bytes = K * s * tmpl_row_dwords(s) * 4;
+    const int hes_bytes = rh * rw * 4;              // aliases the templates once they are dead
+    L.total = round_up(L.tmpl_off + (tmpl_bytes > hes_bytes ? tmpl_bytes : hes_bytes), 16);
+    return L;
+}
+
+// host-side launcher implemented in pm_kernel.hip; returns a hipError_t as int
+int launch_pm(const PMArgs &args, int lds_bytes, void *stream);
+int launch_rsqrt(const double *x, double *y, int64_t n, void *stream);
+// true when a kernel instantiation exists for this template side
+bool img_size_supported(int s);
+int max_lds_bytes();
+
+}  // namespace sid

@@ -1,0 +1,77 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle on seeded inputs."""
+import numpy as np
+import pytest
+
+from sea_ice_drift_amd import _capi, synthetic as syn
+from oracle import pm_oracle as po
+
+pytestmark = pytest.mark.gpu
+
+ANGLES7 = list(range(-3, 4))
+ANGLES15 = list(range(-7, 8))
+
+
+def rot_for(angles, alpha0, s):
+    return np.array([po.rotation_terms(a - alpha0, s) for a in angles])
+
+
+def assert_parity(got, got_ij, exp, exp_ij):
+    """Integer outputs bit-exact; c2, r2, a exact; r exact (float32 spec); h within 1e-5."""
+    np.testing.assert_array_equal(got_ij, exp_ij)
+    nan_e = np.isnan(exp[:, 0])
+    np.testing.assert_array_equal(np.isnan(got[:, 0]), nan_e)
+    g, e = got[~nan_e], exp[~nan_e]
+    np.testing.assert_array_equal(g[:, :3], e[:, :3])
+    np.testing.assert_array_equal(g[:, 3], e[:, 3])
+    np.testing.assert_allclose(g[:, 4], e[:, 4], rtol=1e-5, atol=1e-5)
+
+
+def test_device_double_rsqrt_is_ieee(pm_ctx):
+    rng = np.random.default_rng(5)
+    x = np.concatenate([rng.integers(1, 2**40, 200000).astype(np.float64),
+                        rng.random(100000) * 1e12 + 1.0, [1.0, 2.0, 3.0, 4.0, 578.0, 1156.0]])
+    y = pm_ctx.debug_rsqrt(x)
+    np.testing.assert_array_equal(y, 1.0 / np.sqrt(x))
+
+
+@pytest.mark.parametrize('s,alpha0,angles', [(34, 0.0, ANGLES7), (35, -3.85, [-3, 0, 3]), (34, 0.0, ANGLES15)])
+def test_small_pair_matches_oracle(pm_ctx, c_oracle, s, alpha0, angles):
+    img1, img2 = syn.make_pair(600, 600, seed=7)
+    img1 = img1.copy()
+    img1[300:320, 300:330] = 0                       # invalid patch -> NaN path (pmlib.py:152-154)
+    g = syn.make_grid(600, 600, 12, margin=90)
+    rot = rot_for(angles, alpha0, s)
+    exp, exp_ij = c_oracle.pm_batch(img1, img2, g['c1'], g['r1'], g['c2fg'], g['r2fg'], g['border'], s, alpha0,
+                                    angles, rot=rot, nthreads=8)
+    assert np.isnan(exp[:, 0]).sum() >= 1
+    pm_ctx.upload_pair(img1, img2)
+    pm_ctx.set_points(g['c1'], g['r1'], g['c2fg'], g['r2fg'], g['border'], s, alpha0, angles, rot=rot)
+    pm_ctx.run()
+    got, got_ij = pm_ctx.fetch()
+    assert_parity(got, got_ij, exp, exp_ij)
+
+
+def test_debug_point_intermediates(pm_ctx):
+    img1, img2 = syn.make_pair(400, 400, seed=11)
+    pm_ctx.upload_pair(img1, img2)
+    s, alpha0, angles = 34, 0.0, ANGLES7
+    rot = rot_for(angles, alpha0, s)
+    d = pm_ctx.debug_point(200.0, 180.0, 203.0, 178.0, 23.0, s, alpha0, angles, rot=rot)
+    for k, a in enumerate(angles):
+        np.testing.assert_array_equal(d['templates'][k], po.get_template(img1, 200.0, 180.0, a - alpha0, s))
+    res, (bij, bk, best_result, _) = po.use_mcc(200.0, 180.0, 203.0, 178.0, 23.0, img1, img2, s, alpha0,
+                                               full=True, angles=angles)
+    assert tuple(d['ij']) == (bij[0], bij[1], bk)
+    np.testing.assert_array_equal(d['ccm'], best_result)
+    np.testing.assert_array_equal(d['hes'], po.raw_hessian(best_result))
+    np.testing.assert_allclose(d['out'], res, rtol=1e-5, atol=1e-5)
+
+
+def test_one_shot_batch_entry(c_oracle):
+    img1, img2 = syn.make_pair(300, 300, seed=3)
+    g = syn.make_grid(300, 300, 4, margin=80, border=20)
+    exp, exp_ij = c_oracle.pm_batch(img1, img2, g['c1'], g['r1'], g['c2fg'], g['r2fg'], g['border'], 34, 0.0,
+                                    ANGLES7, rot=rot_for(ANGLES7, 0.0, 34))
+    got, got_ij = _capi.pm_batch(img1, img2, g['c1'], g['r1'], g['c2fg'], g['r2fg'], g['border'], 34, 0.0,
+                                 ANGLES7, rot=rot_for(ANGLES7, 0.0, 34))
+    assert_parity(got, got_ij, exp, exp_ij)
