@@ -117,6 +117,12 @@ int sid_pm_set_points(sid_pm_ctx *ctx, const double *c1, const double *r1, const
                       double alpha0, const double *angles, const double *rot, int n_angles,
                       uint32_t flags);
 
+/* Optional: have the kernels write into caller-owned device arrays ([n][5] float64 and
+ * [n][3] int32, e.g. torch tensors that an RCCL gather will read) instead of the handle's
+ * own.  Call after set_points; the binding is dropped by the next set_points.  NULL, NULL
+ * restores the handle's buffers. */
+int sid_pm_bind_results(sid_pm_ctx *ctx, double *d_out, int32_t *d_out_ij);
+
 /* Enqueue the kernels for the resident points on the resident pair (asynchronous). */
 int sid_pm_run(sid_pm_ctx *ctx);
 /* Wait for the stream. */

@@ -174,6 +174,19 @@ static float pairwise_sum_f32(const float *a, int64_t n)
     }
 }
 
+/* np.add.reduce over a contiguous float32 array: the ufunc machinery feeds the inner loop
+ * in chunks of the default buffer size (8192 elements) and accumulates the chunk results
+ * sequentially (verified against numpy 2.2 on random lengths). */
+static float numpy_sum_f32(const float *a, int64_t n)
+{
+    float res = 0.f;
+    for (int64_t i = 0; i < n; i += 8192) {
+        const int64_t m = n - i < 8192 ? n - i : 8192;
+        res += pairwise_sum_f32(a + i, m);
+    }
+    return res;
+}
+
 static int cmp_f32(const void *a, const void *b)
 {
     const float x = *(const float *)a, y = *(const float *)b;
@@ -187,9 +200,9 @@ static void median_std_f32(const float *v, int64_t n, float *tmp, float *med, fl
     qsort(tmp, n, sizeof(float), cmp_f32);
     if (n & 1) *med = tmp[n / 2];
     else *med = (tmp[n / 2 - 1] + tmp[n / 2]) / 2.0f;     /* np.mean of the two middles, float32 */
-    const float mean = pairwise_sum_f32(v, n) / (float)n;
+    const float mean = numpy_sum_f32(v, n) / (float)n;
     for (int64_t k = 0; k < n; ++k) { const float x = v[k] - mean; tmp[k] = x * x; }
-    const float var = pairwise_sum_f32(tmp, n) / (float)n;
+    const float var = numpy_sum_f32(tmp, n) / (float)n;
     *sd = sqrtf(var);
 }
 
@@ -334,7 +347,7 @@ static void use_mcc_ws(sid_ws *w, const uint8_t *img1, int64_t rows1, int64_t co
     const int64_t c0 = (int64_t)(c2fg - hws - border), c1e = (int64_t)(c2fg + hws + border + 1);
     for (int k = 0; k < 5; ++k) out5[k] = NAN;
     if (ij3) { ij3[0] = ij3[1] = ij3[2] = -1; }
-    if (!(r0 >= 0 && c0 >= 0 && r1e <= rows2 && c1e <= cols2 && r1e - r0 >= s && c1e - c0 >= s)) return;
+    if (!(r0 >= 0 && c0 >= 0 && r1e <= rows2 && c1e <= cols2 && r1e - r0 >= s + 1 && c1e - c0 >= s + 1)) return;
     const int wh = (int)(r1e - r0), ww = (int)(c1e - c0);
     const int rh = wh - s + 1, rw = ww - s + 1;
     ws_reserve(w, (size_t)rh * rw, s);

@@ -248,11 +248,12 @@ def window_bounds(c2fg, r2fg, border, img_size):
 
 
 def use_mcc(c1, r1, c2fg, r2fg, border, img1, img2, img_size, alpha0, full=False, **kw):
-    """pmlib.py:176-212.  A window that is not wholly inside img2 (never produced by
-    the reference's validity mask, pmlib.py:417-426) yields NaN*5."""
+    """pmlib.py:176-212.  A window that is not wholly inside img2, or that leaves fewer
+    than 2 placements per axis (np.gradient needs 2), is never produced by the reference's
+    validity mask (pmlib.py:417-426); it yields NaN*5 here and in the HIP kernel."""
     r0, r1_, c0, c1_ = window_bounds(c2fg, r2fg, border, img_size)
     ok = (0 <= r0 and 0 <= c0 and r1_ <= img2.shape[0] and c1_ <= img2.shape[1]
-          and r1_ - r0 >= img_size and c1_ - c0 >= img_size)
+          and r1_ - r0 >= img_size + 1 and c1_ - c0 >= img_size + 1)
     if not ok:
         nan = np.nan
         return ((nan,) * 5, ((-1, -1), -1, None, None)) if full else (nan,) * 5

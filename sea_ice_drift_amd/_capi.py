@@ -21,7 +21,7 @@ ABI_VERSION = 1
 SYMBOLS = (
     'sid_pm_abi_version', 'sid_pm_strerror', 'sid_pm_last_error', 'sid_pm_device_count',
     'sid_pm_batch', 'sid_pm_create', 'sid_pm_destroy', 'sid_pm_set_stream', 'sid_pm_upload_pair',
-    'sid_pm_select_pair', 'sid_pm_bind_pair', 'sid_pm_set_points', 'sid_pm_run', 'sid_pm_sync',
+    'sid_pm_select_pair', 'sid_pm_bind_pair', 'sid_pm_set_points', 'sid_pm_bind_results', 'sid_pm_run', 'sid_pm_sync',
     'sid_pm_fetch', 'sid_pm_device_results', 'sid_pm_work_info', 'sid_pm_debug_point',
     'sid_pm_debug_rsqrt',
 )
@@ -68,6 +68,7 @@ def lib():
     L.sid_pm_bind_pair.argtypes = [C.c_void_p] + ptr + ptr
     L.sid_pm_set_points.argtypes = [C.c_void_p] + [_f64p] * 5 + [C.c_int64, C.c_int, C.c_double, _f64p, _f64p,
                                                                 C.c_int, C.c_uint32]
+    L.sid_pm_bind_results.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     L.sid_pm_run.argtypes = [C.c_void_p]
     L.sid_pm_sync.argtypes = [C.c_void_p]
     L.sid_pm_fetch.argtypes = [C.c_void_p, _f64p, _i32p]
@@ -202,6 +203,17 @@ class PMContext(object):
         _check(lib().sid_pm_set_points(self._h, *[_p(x, _f64p) for x in v], n, int(img_size), float(alpha0),
                                        _p(angles, _f64p), rotp, len(angles), int(flags)))
         self.n = n
+
+    def bind_results_tensors(self, t_out, t_ij=None):
+        """Write results into caller-owned device tensors: float64 [n,5] and int32 [n,3]."""
+        if tuple(t_out.shape) != (self.n, 5) or str(t_out.dtype) != 'torch.float64' or not t_out.is_contiguous():
+            raise TypeError('t_out must be a contiguous float64 [n,5] device tensor')
+        if t_ij is not None and (tuple(t_ij.shape) != (self.n, 3) or str(t_ij.dtype) != 'torch.int32'
+                                 or not t_ij.is_contiguous()):
+            raise TypeError('t_ij must be a contiguous int32 [n,3] device tensor')
+        self._keep_out = (t_out, t_ij)
+        _check(lib().sid_pm_bind_results(self._h, C.c_void_p(t_out.data_ptr()),
+                                         C.c_void_p(t_ij.data_ptr()) if t_ij is not None else None))
 
     def run(self):
         _check(lib().sid_pm_run(self._h))

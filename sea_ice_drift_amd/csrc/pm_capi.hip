@@ -85,6 +85,8 @@ struct sid_pm_ctx {
     DevBuf<double> angles, rot;
     DevBuf<double> out;
     DevBuf<int32_t> out_ij;
+    double *user_out = nullptr;         // caller-owned result arrays (bind_results)
+    int32_t *user_ij = nullptr;
     std::vector<Bucket> buckets;
     int64_t n = 0;
     int img_size = 0, n_angles = 0;
@@ -163,7 +165,8 @@ int fill_args(sid_pm_ctx *ctx, sid::PMArgs &A)
     A.border = ctx->vec.p + 4 * n;
     A.img_size = ctx->img_size; A.n_angles = ctx->n_angles; A.flags = ctx->flags;
     A.angles = ctx->angles.p; A.rot = ctx->rot.p;
-    A.out = ctx->out.p; A.out_ij = ctx->out_ij.p;
+    A.out = ctx->user_out ? ctx->user_out : ctx->out.p;
+    A.out_ij = ctx->user_out ? ctx->user_ij : ctx->out_ij.p;
     return SID_PM_OK;
 }
 
@@ -353,6 +356,7 @@ SID_EXPORT int sid_pm_set_points(sid_pm_ctx *ctx, const double *c1, const double
     HIP_TRY(hipMemcpy(ctx->angles.p, angles, sizeof(double) * (size_t)K, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(ctx->rot.p, rotv.data(), sizeof(double) * rotv.size(), hipMemcpyHostToDevice));
 
+    ctx->user_out = nullptr; ctx->user_ij = nullptr;
     ctx->n = n; ctx->img_size = s; ctx->n_angles = K; ctx->flags = flags;
     ctx->have_points = true;
     const double img_bytes = (double)ctx->cur[0].rows * ctx->cur[0].cols + (double)rows2 * cols2;
@@ -362,6 +366,15 @@ SID_EXPORT int sid_pm_set_points(sid_pm_ctx *ctx, const double *c1, const double
     ctx->info[3] = std::min(bytes, img_bytes + 92.0 * valid);
     ctx->info[4] = (double)lds_max;
     ctx->info[5] = 0;
+    return SID_PM_OK;
+}
+
+SID_EXPORT int sid_pm_bind_results(sid_pm_ctx *ctx, double *d_out, int32_t *d_out_ij)
+{
+    if (!ctx) return fail(SID_PM_ERR_ARG, "null ctx");
+    if (!ctx->have_points) return fail(SID_PM_ERR_STATE, "bind_results before set_points");
+    if (!d_out && d_out_ij) return fail(SID_PM_ERR_ARG, "d_out_ij without d_out");
+    ctx->user_out = d_out; ctx->user_ij = d_out_ij;
     return SID_PM_OK;
 }
 
@@ -396,9 +409,11 @@ SID_EXPORT int sid_pm_fetch(sid_pm_ctx *ctx, double *out, int32_t *out_ij)
     if (ctx->n > 0 && !out) return fail(SID_PM_ERR_ARG, "null out");
     Guard g(ctx->device);
     if (ctx->n > 0) {
-        HIP_TRY(hipMemcpyAsync(out, ctx->out.p, sizeof(double) * 5 * (size_t)ctx->n, hipMemcpyDeviceToHost, ctx->stream));
-        if (out_ij)
-            HIP_TRY(hipMemcpyAsync(out_ij, ctx->out_ij.p, sizeof(int32_t) * 3 * (size_t)ctx->n, hipMemcpyDeviceToHost, ctx->stream));
+        const double *src = ctx->user_out ? ctx->user_out : ctx->out.p;
+        const int32_t *src_ij = ctx->user_out ? ctx->user_ij : ctx->out_ij.p;
+        HIP_TRY(hipMemcpyAsync(out, src, sizeof(double) * 5 * (size_t)ctx->n, hipMemcpyDeviceToHost, ctx->stream));
+        if (out_ij && src_ij)
+            HIP_TRY(hipMemcpyAsync(out_ij, src_ij, sizeof(int32_t) * 3 * (size_t)ctx->n, hipMemcpyDeviceToHost, ctx->stream));
     }
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return SID_PM_OK;
@@ -408,8 +423,8 @@ SID_EXPORT int sid_pm_device_results(sid_pm_ctx *ctx, double **d_out, int32_t **
 {
     if (!ctx) return fail(SID_PM_ERR_ARG, "null ctx");
     if (!ctx->have_points) return fail(SID_PM_ERR_STATE, "device_results before set_points");
-    if (d_out) *d_out = ctx->out.p;
-    if (d_out_ij) *d_out_ij = ctx->out_ij.p;
+    if (d_out) *d_out = ctx->user_out ? ctx->user_out : ctx->out.p;
+    if (d_out_ij) *d_out_ij = ctx->user_out ? ctx->user_ij : ctx->out_ij.p;
     return SID_PM_OK;
 }
 

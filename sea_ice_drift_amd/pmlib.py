@@ -1,0 +1,219 @@
+"""Pattern matching on MI355X with the reference's call shape.
+
+Drop-in for ``sea_ice_drift.pmlib.pattern_matching`` (reference pmlib.py:326-497):
+
+    u, v, a, r, h, lon2, lat2 = pattern_matching(lon_pm1, lat_pm1, n1, c1, r1, n2, c2, r2,
+                                                 margin=0, img_size=35, threads=5, srs=..., **kwargs)
+
+The structure is  prelude (host, NumPy)  ->  dispatch (GPU)  ->  postlude (host, NumPy):
+
+* ``pm_prelude``   builds the five per-point vectors, the validity mask and the scene
+                   rotation exactly as pmlib.py:393-428 / :249-324 do;
+* the dispatch replaces the ``multiprocessing.Pool.map`` of pmlib.py:436-448 with the HIP
+  kernel behind the C ABI (``_capi``).  ``threads`` is accepted for signature compatibility
+  and ignored.  There is no CPU fallback: without the HIP library / a gfx950 device this
+  raises.  Options the kernel does not implement (``hes_smth=True``, ``rot_order != 0``, a
+  user ``template_matcher``, ``img_size`` outside 33..36) raise ``NotImplementedError``;
+* ``pm_postlude``  turns the (N,5) result block into the seven output grids as
+                   pmlib.py:451-497 does.
+"""
+from __future__ import absolute_import, print_function
+
+import time
+
+import numpy as np
+from scipy.spatial import cKDTree
+
+from sea_ice_drift_amd import _capi
+from sea_ice_drift_amd.lib import NSR, _fill_gpi, interpolation_near, interpolation_poly
+
+DEFAULT_SRS = '+proj=latlong +datum=WGS84 +ellps=WGS84 +no_defs'
+
+
+# ------------------------------------------------------------------ small pieces
+def rotation_terms(angle_deg, img_size):
+    """(cos a, sin a, tcT0, tcT1) for one trial angle, computed with NumPy exactly like the
+    reference's get_template (pmlib.py:105-110): tc = int(s/2.)+1, a = radians(angle),
+    transform = [[cos,-sin],[sin,cos]], tcT = [tc,tc].dot(transform).  Passed to the C ABI so
+    the device samples the same float64 coordinates the reference's scipy call would."""
+    tc = int(img_size / 2.) + 1
+    tc = np.array([tc, tc])
+    a = np.radians(angle_deg)
+    transform = np.array([[np.cos(a), -np.sin(a)], [np.sin(a), np.cos(a)]])
+    tct = tc.dot(transform)
+    return float(transform[0, 0]), float(transform[1, 0]), float(tct[0]), float(tct[1])
+
+
+def rotation_table(angles, alpha0, img_size):
+    """[K,4] table of rotation_terms(angle - alpha0) (pmlib.py:151)."""
+    return np.array([rotation_terms(a - alpha0, img_size) for a in angles], dtype=np.float64).reshape(-1, 4)
+
+
+def get_initial_rotation(n1, n2):
+    """Angle of n2's left edge seen in n1 pixel space, degrees (reference pmlib.py:79-87)."""
+    lons, lats = n2.get_corners()
+    x0, y0 = n1.transform_points([lons[0]], [lats[0]], 1)
+    x1, y1 = n1.transform_points([lons[1]], [lats[1]], 1)
+    return np.degrees(np.arctan2(x1 - x0, y1 - y0)[0])
+
+
+def nearest_keypoint_distance(x_kp, y_kp, rows_q, cols_q):
+    """Distance from integer pixels (rows_q, cols_q) to the nearest keypoint pixel.
+
+    Same numbers as sampling the reference's full-image Euclidean distance transform
+    (pmlib.py:61-77: seed[uint16(y), uint16(x)] = True; distance_transform_edt) at those
+    pixels, but evaluated only where needed with a KD-tree: at 10000x10000 the EDT costs
+    ~0.8 GB and seconds of CPU.  Both are sqrt of an exact integer
+    squared distance in float64.
+    """
+    seeds = np.stack([np.uint16(y_kp).astype(np.float64), np.uint16(x_kp).astype(np.float64)], axis=1)
+    tree = cKDTree(seeds)
+    q = np.stack([np.asarray(rows_q, dtype=np.float64), np.asarray(cols_q, dtype=np.float64)], axis=1)
+    d, _ = tree.query(q, k=1)
+    return d
+
+
+def prepare_first_guess(c2pm1, r2pm1, n1, c1, r1, n2, c2, r2, img_size,
+                        min_fg_pts=5, min_border=20, max_border=50, old_border=True, **kwargs):
+    """First-guess position and search border per grid point (reference pmlib.py:249-324)."""
+    n2_shape = n2.shape()
+    lon1, lat1 = n1.transform_points(c1, r1)
+    c1n2, r1n2 = n2.transform_points(lon1, lat1, 1)
+
+    c2p, r2p = np.round(interpolation_poly(c1n2, r1n2, c2, r2, c2pm1, r2pm1, **kwargs))
+    c2fg, r2fg = np.round(interpolation_near(c1n2, r1n2, c2, r2, c2pm1, r2pm1, **kwargs))
+
+    if old_border:
+        border = np.zeros(c2pm1.size) + max_border
+        inside = ((c2pm1 >= 0) * (c2pm1 < n2_shape[1]) * (r2pm1 >= 0) * (r2pm1 < n2_shape[0]))
+        # the reference indexes the EDT image with int16-cast rounded coordinates (:304-305)
+        rq = np.round(r2pm1[inside]).astype(np.int16)
+        cq = np.round(c2pm1[inside]).astype(np.int16)
+        # negative int16 values index from the end, as NumPy fancy indexing would
+        rq = np.where(rq < 0, rq + n2_shape[0], rq)
+        cq = np.where(cq < 0, cq + n2_shape[1], cq)
+        border[inside] = nearest_keypoint_distance(c2, r2, rq, cq)
+    else:
+        c2t, r2t = interpolation_poly(c1n2, r1n2, c2, r2, c1n2, r1n2, **kwargs)
+        c2d, r2d = interpolation_near(c1n2, r1n2, c2 - c2t, r2 - r2t, c2pm1, r2pm1, **kwargs)
+        border = np.hypot(c2d, r2d)
+
+    border[border < min_border] = min_border
+    border[border > max_border] = max_border
+    border[np.isnan(c2fg)] = max_border
+    border = np.floor(border)
+
+    nofg = np.isnan(c2fg)
+    c2fg[nofg] = c2p[nofg]
+    nofg = np.isnan(r2fg)
+    r2fg[nofg] = r2p[nofg]
+    return c2fg, r2fg, border
+
+
+# ------------------------------------------------------------------ prelude / postlude
+def pm_prelude(lon_pm1, lat_pm1, n1, c1, r1, n2, c2, r2, margin=0, img_size=35, **kwargs):
+    """Host work before the per-point sweep (reference pmlib.py:394-428)."""
+    dst_shape = lon_pm1.shape
+    c2pm1, r2pm1 = n2.transform_points(lon_pm1.flatten(), lat_pm1.flatten(), 1)
+    c2pm1i, r2pm1i = np.round([c2pm1, r2pm1])                       # half-to-even, as np.round
+    lon1i, lat1i = n2.transform_points(c2pm1i, r2pm1i)
+    c1pm1i, r1pm1i = n1.transform_points(lon1i, lat1i, 1)
+
+    c2fg, r2fg, brd2 = prepare_first_guess(c2pm1i, r2pm1i, n1, c1, r1, n2, c2, r2, img_size, **kwargs)
+
+    hws = round(img_size / 2) + 1                                   # Python-3 round (pmlib.py:417)
+    hyp = np.hypot(hws, hws)
+    rows2, cols2 = n2.shape()[0], n2.shape()[1]
+    rows1, cols1 = n1.shape()[0], n1.shape()[1]
+    gpi = ((c2fg - brd2 - hws - margin > 0) * (r2fg - brd2 - hws - margin > 0) *
+           (c2fg + brd2 + hws + margin < cols2) * (r2fg + brd2 + hws + margin < rows2) *
+           (c1pm1i - hyp - margin > 0) * (r1pm1i - hyp - margin > 0) *
+           (c1pm1i + hyp + margin < cols1) * (r1pm1i + hyp + margin < rows1))
+    alpha0 = get_initial_rotation(n1, n2)
+    return dict(dst_shape=dst_shape, c2pm1=c2pm1, r2pm1=r2pm1, c2pm1i=c2pm1i, r2pm1i=r2pm1i,
+                c1pm1i=c1pm1i, r1pm1i=r1pm1i, c2fg=c2fg, r2fg=r2fg, brd2=brd2, gpi=gpi, alpha0=alpha0)
+
+
+def pm_postlude(pre, results, n2, srs=DEFAULT_SRS):
+    """(N,5) results -> u, v, a, r, h, lon2, lat2 grids (reference pmlib.py:451-497)."""
+    dst_shape, gpi = pre['dst_shape'], pre['gpi']
+    if len(results) == 0:
+        return tuple(np.zeros(dst_shape) + np.nan for _ in range(7))
+    results = np.asarray(results, dtype=np.float64)
+    # integer start coordinates were matched; add the sub-pixel part back (:469-470)
+    dci, dri = pre['c2pm1'] - pre['c2pm1i'], pre['r2pm1'] - pre['r2pm1i']
+    c2pm2, r2pm2 = results[:, 0] + dci[gpi], results[:, 1] + dri[gpi]
+
+    xpm1, ypm1 = n2.transform_points(pre['c2pm1'], pre['r2pm1'], 0, NSR(srs))
+    xpm2, ypm2 = n2.transform_points(c2pm2, r2pm2, 0, NSR(srs))
+    lon_pm2, lat_pm2 = n2.transform_points(c2pm2, r2pm2, 0)
+
+    u = _fill_gpi(dst_shape, gpi, xpm2) - xpm1.reshape(dst_shape)
+    v = _fill_gpi(dst_shape, gpi, ypm2) - ypm1.reshape(dst_shape)
+    a = _fill_gpi(dst_shape, gpi, results[:, 2])
+    r = _fill_gpi(dst_shape, gpi, results[:, 3])
+    h = _fill_gpi(dst_shape, gpi, results[:, 4])
+    return u, v, a, r, h, _fill_gpi(dst_shape, gpi, lon_pm2), _fill_gpi(dst_shape, gpi, lat_pm2)
+
+
+# ------------------------------------------------------------------ dispatch
+def _sweep_options(kwargs):
+    """Pick the kernel's options out of the reference's catch-all kwargs (pmlib.py:358-375)."""
+    if kwargs.get('template_matcher') is not None:
+        raise NotImplementedError('template_matcher= is a CPU plug point of the reference (pmlib.py:120); '
+                                  'the device kernel implements TM_CCOEFF_NORMED only')
+    if kwargs.get('rot_order', 0) != 0:
+        raise NotImplementedError('rot_order=%r: the device samples templates nearest-neighbour (order 0) only'
+                                  % (kwargs['rot_order'],))
+    angles = list(kwargs.get('angles', [-3, 0, 3]))
+    flags = _capi.flags_from_kwargs(hes_norm=kwargs.get('hes_norm', True), hes_smth=kwargs.get('hes_smth', False),
+                                    mcc_norm=kwargs.get('mcc_norm', False))
+    if flags & _capi.HES_SMTH:
+        raise NotImplementedError('hes_smth=True is not implemented on the device')
+    return angles, flags
+
+
+def pm_dispatch(img1, img2, c1, r1, c2fg, r2fg, border, img_size, alpha0, device=0, context=None, **kwargs):
+    """The batch seam (reference pmlib.py:436-448): N points -> (N,5) float64 on the GPU."""
+    angles, flags = _sweep_options(kwargs)
+    rot = rotation_table(angles, alpha0, img_size)
+    own = context is None
+    ctx = _capi.PMContext(device) if own else context
+    try:
+        ctx.upload_pair(img1, img2)
+        try:
+            ctx.set_points(c1, r1, c2fg, r2fg, border, img_size, alpha0, angles, rot=rot, flags=flags)
+        except _capi.SidPmError as e:
+            if e.code == -4:
+                raise NotImplementedError(str(e))
+            raise
+        ctx.run()
+        return ctx.fetch(want_ij=False)
+    finally:
+        if own:
+            ctx.close()
+
+
+def use_mcc(c1, r1, c2fg, r2fg, border, img1, img2, img_size, alpha0, **kwargs):
+    """One point, same signature and return as the reference's use_mcc (pmlib.py:176-212)."""
+    out = pm_dispatch(img1, img2, [c1], [r1], [c2fg], [r2fg], [border], img_size, alpha0, **kwargs)
+    c2, r2, a, r, h = out[0]
+    return c2, r2, a, np.float32(r), np.float32(h)
+
+
+def pattern_matching(lon_pm1, lat_pm1, n1, c1, r1, n2, c2, r2,
+                     margin=0, img_size=35, threads=5, srs=DEFAULT_SRS, **kwargs):
+    """Run pattern matching on two images; same arguments and returns as the reference
+    (pmlib.py:326-392): u, v, a, r, h, lon2_dst, lat2_dst, each shaped like lon_pm1."""
+    t0 = time.time()
+    img1, img2 = n1[1], n2[1]
+    pre = pm_prelude(lon_pm1, lat_pm1, n1, c1, r1, n2, c2, r2, margin=margin, img_size=img_size, **kwargs)
+    gpi = pre['gpi']
+    if gpi.any():
+        results = pm_dispatch(img1, img2, pre['c1pm1i'][gpi], pre['r1pm1i'][gpi], pre['c2fg'][gpi],
+                              pre['r2fg'][gpi], pre['brd2'][gpi], img_size, pre['alpha0'], **kwargs)
+    else:
+        _sweep_options(kwargs)
+        results = np.zeros((0, 5))
+    print('\n', 'Pattern matching - OK! (%3.0f sec)' % (time.time() - t0))
+    return pm_postlude(pre, results, n2, srs=srs)

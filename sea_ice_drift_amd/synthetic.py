@@ -76,15 +76,17 @@ def true_displacement(c, r, amplitude=FIELD_AMPLITUDE, period=FIELD_PERIOD):
 
 
 def make_grid(rows, cols, n_side, border='mixed', seed=SEED_GRID, margin=100, fg_error=3):
-    """Kernel inputs for an n_side x n_side grid on a shared georeference (alpha0 = 0).
+    """Kernel inputs for an n_side x n_side (or (n_rows, n_cols)) grid on a shared
+    georeference (alpha0 = 0).
 
     Returns dict(c1, r1, c2fg, r2fg, border) of float64 vectors holding integers, exactly
     the five vectors the reference hands to its Pool (pmlib.py:438,443).
     border: 'mixed' -> clip(floor(Rayleigh(16)), 20, 50); or an int for a fixed border.
     """
+    n_rows, n_cols = (n_side, n_side) if np.isscalar(n_side) else n_side
     rng = np.random.Generator(np.random.PCG64(seed))
-    cs = np.rint(np.linspace(margin, cols - 1 - margin, n_side))
-    rs = np.rint(np.linspace(margin, rows - 1 - margin, n_side))
+    cs = np.rint(np.linspace(margin, cols - 1 - margin, n_cols))
+    rs = np.rint(np.linspace(margin, rows - 1 - margin, n_rows))
     c1, r1 = np.meshgrid(cs, rs)
     c1, r1 = c1.ravel(), r1.ravel()
     dc, dr = true_displacement(c1, r1)

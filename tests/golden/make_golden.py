@@ -1,0 +1,200 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ from the REFERENCE's own Python.
+
+Runs only in the build container (needs /root/reference; see oracle/ref_harness.py for the
+stub-import recipe).  The fixtures hold numbers only - inputs (or the seeds that regenerate
+them, with a sha256) and the outputs the reference's functions returned:
+
+  g1_templates.npz   pmlib.get_template              (pmlib.py:89-115)
+  g2_hessian.npz     pmlib.get_hessian               (pmlib.py:36-59)
+  g3_use_mcc.npz     pmlib.use_mcc / rotate_and_match (pmlib.py:117-212) with
+                     template_matcher=<restated TM_CCOEFF_NORMED> injected through the
+                     reference's own plug point (cv2 is absent: parity unpinned at that call)
+  g4_pattern_matching.npz  pmlib.pattern_matching    (pmlib.py:326-497) end to end on an
+                     affine stand-in for Nansat, incl. the kernel-input vectors it built
+  g5_fullsize.npz    sha256 of the 10000x10000 benchmark pair + C-oracle results on a 1 %
+                     subsample of the 200x200 grid (regression pin, not reference output)
+
+    python tests/golden/make_golden.py [g1 g2 g3 g4 g5]
+"""
+import os
+import sys
+import time
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+
+from oracle import c_oracle, pm_oracle as po, ref_harness          # noqa: E402
+from sea_ice_drift_amd import synthetic as syn                     # noqa: E402
+from sea_ice_drift_amd.domain import ArrayNansat                   # noqa: E402
+
+G1_ANGLES = [-9, -6, -3, 0, 3, 6, 9, 1.234, -3.85, 45, 90, -7.5]
+G1_CENTRES = [(200, 150), (200.3, 150.7), (123.5, 321.5), (50.49999, 60.5)]
+G3_ANGLE_SETS = [[-3, 0, 3], list(range(-3, 4)), list(range(-7, 8))]
+
+
+def g1_image():
+    return np.random.default_rng(101).integers(1, 256, (400, 400), dtype=np.uint8)
+
+
+def g3_pair():
+    img1, img2 = syn.make_pair(512, 512, seed=303, amplitude=6.0, period=700.0)
+    img1 = img1.copy()
+    img1[250:262, 100:140] = 0                      # invalid pixels -> NaN path
+    return img1, img2
+
+
+def g3_points():
+    rng = np.random.default_rng(304)
+    n = 72
+    c1 = rng.uniform(90, 420, n)
+    r1 = rng.uniform(90, 420, n)
+    c1[::3] = np.rint(c1[::3])                      # a mix of integer and fractional centres
+    r1[::3] = np.rint(r1[::3])
+    dc, dr = syn.true_displacement(c1, r1, amplitude=6.0, period=700.0)
+    c2fg = np.rint(c1 + dc) + rng.integers(-3, 4, n)
+    r2fg = np.rint(r1 + dr) + rng.integers(-3, 4, n)
+    border = rng.integers(20, 51, n).astype(np.float64)
+    border[:6] = [20, 50, 21, 49, 35, 36]
+    return c1, r1, c2fg, r2fg, border
+
+
+def make_g1(pmlib):
+    img = g1_image()
+    out = []
+    for s in (34, 35):
+        for a in G1_ANGLES:
+            for (c, r) in G1_CENTRES:
+                out.append(pmlib.get_template(img, c, r, a, s).ravel())
+    edge = pmlib.get_template(img, 5, 5, 10, 34)    # sticks out of the image -> zeros
+    np.savez_compressed(os.path.join(HERE, 'g1_templates.npz'),
+                        img_sha=syn.sha256(img), t34=np.array(out[:48], dtype=np.uint8),
+                        t35=np.array(out[48:], dtype=np.uint8), edge=edge)
+
+
+def g2_inputs():
+    rng = np.random.default_rng(202)
+    mats = {}
+    for n in (42, 72, 101, 102):
+        # smooth-ish correlation-like surfaces: low-pass noise in [-1, 1]
+        m = rng.standard_normal((n, n)).astype(np.float32)
+        k = np.ones(5, dtype=np.float32) / 5
+        m = np.apply_along_axis(lambda v: np.convolve(v, k, 'same'), 0, m)
+        m = np.apply_along_axis(lambda v: np.convolve(v, k, 'same'), 1, m).astype(np.float32)
+        mats[n] = (m / np.abs(m).max()).astype(np.float32)
+    return mats
+
+
+def make_g2(pmlib):
+    d = {}
+    for n, m in g2_inputs().items():
+        d['in%d' % n] = m
+        d['norm%d' % n] = pmlib.get_hessian(m)
+        d['raw%d' % n] = pmlib.get_hessian(m, hes_norm=False)
+        d['smth%d' % n] = pmlib.get_hessian(m, hes_norm=True, hes_smth=True)
+    np.savez_compressed(os.path.join(HERE, 'g2_hessian.npz'), **d)
+
+
+def make_g3(pmlib):
+    img1, img2 = g3_pair()
+    c1, r1, c2fg, r2fg, border = g3_points()
+    d = dict(pair_sha=syn.sha256(img1, img2), c1=c1, r1=r1, c2fg=c2fg, r2fg=r2fg, border=border)
+    for s, alpha0 in ((34, 0.0), (35, -3.85)):
+        for k, angles in enumerate(G3_ANGLE_SETS):
+            for mcc_norm in (False, True):
+                if mcc_norm and k != 1:
+                    continue
+                res = np.array([pmlib.use_mcc(c1[i], r1[i], c2fg[i], r2fg[i], border[i], img1, img2, s, alpha0,
+                                              angles=angles, mcc_norm=mcc_norm, template_matcher=po.match_template)
+                                for i in range(len(c1))], dtype=np.float64)
+                d['out_s%d_k%d_m%d' % (s, k, int(mcc_norm))] = res
+    # full intermediates of a few points through the reference's rotate_and_match
+    full = []
+    for i in (0, 1, 7):
+        s, alpha0, angles = 34, 0.0, G3_ANGLE_SETS[1]
+        hws = int(s / 2.)
+        b = border[i]
+        win = img2[int(r2fg[i] - hws - b):int(r2fg[i] + hws + b + 1), int(c2fg[i] - hws - b):int(c2fg[i] + hws + b + 1)]
+        dc, dr, ba, br, bh, bres, btmpl = pmlib.rotate_and_match(img1, c1[i], r1[i], s, win, alpha0, angles=angles,
+                                                                  template_matcher=po.match_template)
+        d['full%d_result' % i] = bres
+        d['full%d_template' % i] = btmpl
+        d['full%d_scalars' % i] = np.array([dc, dr, ba, br, bh], dtype=np.float64)
+        full.append(i)
+    d['full_points'] = np.array(full)
+    np.savez_compressed(os.path.join(HERE, 'g3_use_mcc.npz'), **d)
+
+
+def g4_inputs():
+    img1, img2 = syn.make_pair(1200, 1200, seed=5)
+    n1 = ArrayNansat.rotated(img1, angle_deg=0.0, scale=0.001, origin=(10.0, 70.0))
+    n2 = ArrayNansat.rotated(img2, angle_deg=2.0, scale=0.001, origin=(10.003, 70.002))
+    rng = np.random.default_rng(3)
+    c1 = rng.uniform(100, 1100, 300)
+    r1 = rng.uniform(100, 1100, 300)
+    lon, lat = n1.transform_points(c1, r1)
+    c2, r2 = n2.transform_points(lon, lat, 1)
+    dc, dr = syn.true_displacement(c1, r1)
+    c2 = c2 + dc + rng.normal(0, 0.5, 300)
+    r2 = r2 + dr + rng.normal(0, 0.5, 300)
+    lon_g, lat_g = np.meshgrid(np.linspace(10.05, 11.1, 25), np.linspace(70.05, 71.1, 25))
+    return n1, n2, c1, r1, c2, r2, lon_g, lat_g
+
+
+def make_g4(pmlib):
+    n1, n2, c1, r1, c2, r2, lon_g, lat_g = g4_inputs()
+    rec = {}
+    orig = pmlib.prepare_first_guess
+
+    def wrap(*a, **k):
+        out = orig(*a, **k)
+        rec['fg'] = [x.copy() for x in out]
+        return out
+    pmlib.prepare_first_guess = wrap
+    try:
+        kw = dict(img_size=34, angles=list(range(-3, 4)))
+        out = pmlib.pattern_matching(lon_g, lat_g, n1, c1, r1, n2, c2, r2, threads=1,
+                                     template_matcher=po.match_template, **kw)
+    finally:
+        pmlib.prepare_first_guess = orig
+    sa = pmlib.shared_args
+    np.savez_compressed(os.path.join(HERE, 'g4_pattern_matching.npz'),
+                        pair_sha=syn.sha256(n1[1], n2[1]), c1=c1, r1=r1, c2=c2, r2=r2, lon_g=lon_g, lat_g=lat_g,
+                        fg_c2=rec['fg'][0], fg_r2=rec['fg'][1], fg_border=rec['fg'][2],
+                        k_c1=sa[0], k_r1=sa[1], k_c2fg=sa[2], k_r2fg=sa[3], k_border=sa[4], alpha0=sa[8],
+                        u=out[0], v=out[1], a=out[2], r=out[3], h=out[4], lon2=out[5], lat2=out[6])
+
+
+def make_g5():
+    img1, img2 = syn.make_pair(10000, 10000)
+    g = syn.make_grid(10000, 10000, 200)
+    sel = np.arange(37, 40000, 100)
+    angles = list(range(-7, 8))
+    rot = np.array([po.rotation_terms(a, 34) for a in angles])
+    out, ij = c_oracle.pm_batch(img1, img2, g['c1'][sel], g['r1'][sel], g['c2fg'][sel], g['r2fg'][sel],
+                                g['border'][sel], 34, 0.0, angles, rot=rot, nthreads=os.cpu_count())
+    np.savez_compressed(os.path.join(HERE, 'g5_fullsize.npz'), pair_sha=syn.sha256(img1, img2),
+                        grid_sha=syn.sha256(*[g[k] for k in ('c1', 'r1', 'c2fg', 'r2fg', 'border')]),
+                        sel=sel, out=out, ij=ij)
+
+
+def main():
+    which = sys.argv[1:] or ['g1', 'g2', 'g3', 'g4', 'g5']
+    pmlib, _ = ref_harness.load()
+    c_oracle.build()
+    for name, fn in (('g1', make_g1), ('g2', make_g2), ('g3', make_g3), ('g4', make_g4)):
+        if name in which:
+            t = time.time()
+            fn(pmlib)
+            print(name, 'done in %.1f s' % (time.time() - t))
+    if 'g5' in which:
+        t = time.time()
+        make_g5()
+        print('g5 done in %.1f s' % (time.time() - t))
+
+
+if __name__ == '__main__':
+    main()

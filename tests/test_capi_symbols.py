@@ -1,0 +1,43 @@
+"""CPU test: the C-ABI library loads and exports every symbol include/sid_pm.h declares.
+No compute call is made (there is no GPU here)."""
+import ctypes
+import os
+import re
+
+from sea_ice_drift_amd import _capi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_functions():
+    src = open(os.path.join(ROOT, 'include', 'sid_pm.h')).read()
+    src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
+    return sorted(set(re.findall(r'\b(sid_pm_[a-z_0-9]+)\s*\(', src)))
+
+
+def test_header_and_binding_agree():
+    assert header_functions() == sorted(_capi.SYMBOLS)
+
+
+def test_library_exports_every_declared_symbol():
+    assert os.path.exists(_capi.LIB_PATH), 'build with __graft_entry__.build() first'
+    lib = ctypes.CDLL(_capi.LIB_PATH)
+    for name in header_functions():
+        assert hasattr(lib, name), name
+    assert lib.sid_pm_abi_version() == _capi.ABI_VERSION
+    lib.sid_pm_strerror.restype = ctypes.c_char_p
+    assert lib.sid_pm_strerror(-4) == b'unsupported option or size'
+
+
+def test_library_carries_gfx950_code_object():
+    blob = open(_capi.LIB_PATH, 'rb').read()
+    assert b'gfx950' in blob
+    assert b'pm_kernel' in blob
+
+
+def test_argument_errors_without_a_device():
+    """Argument validation that happens before any device work."""
+    lib = _capi.lib()
+    assert lib.sid_pm_create(0, None) == -1
+    assert lib.sid_pm_run(None) == -1
+    assert b'null ctx' in lib.sid_pm_last_error()

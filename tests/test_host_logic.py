@@ -1,0 +1,127 @@
+"""CPU tests of the host side of pattern_matching (prelude / postlude / option handling)
+against fixture G4 = the reference's own pattern_matching run end to end."""
+import os
+
+import numpy as np
+import pytest
+from scipy import ndimage as nd
+
+from sea_ice_drift_amd import lib as mylib, pmlib as my, synthetic as syn
+from sea_ice_drift_amd.domain import ArrayNansat
+from sea_ice_drift_amd.seaicedrift import SeaIceDrift
+from tests.golden import make_golden as mg
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+KW = dict(img_size=34, angles=list(range(-3, 4)))
+
+
+@pytest.fixture(scope='module')
+def g4():
+    g = np.load(os.path.join(GOLD, 'g4_pattern_matching.npz'))
+    n1, n2, c1, r1, c2, r2, lon_g, lat_g = mg.g4_inputs()
+    assert syn.sha256(n1[1], n2[1]) == str(g['pair_sha'])
+    for a, b in ((c1, g['c1']), (r1, g['r1']), (c2, g['c2']), (r2, g['r2']), (lon_g, g['lon_g'])):
+        np.testing.assert_array_equal(a, b)
+    return g, (n1, n2, c1, r1, c2, r2, lon_g, lat_g)
+
+
+def test_prelude_builds_the_reference_kernel_inputs(g4):
+    g, (n1, n2, c1, r1, c2, r2, lon_g, lat_g) = g4
+    pre = my.pm_prelude(lon_g, lat_g, n1, c1, r1, n2, c2, r2, **KW)
+    np.testing.assert_array_equal(pre['c2fg'], g['fg_c2'])
+    np.testing.assert_array_equal(pre['r2fg'], g['fg_r2'])
+    np.testing.assert_array_equal(pre['brd2'], g['fg_border'])
+    gpi = pre['gpi']
+    for mine, ref in (('c1pm1i', 'k_c1'), ('r1pm1i', 'k_r1'), ('c2fg', 'k_c2fg'), ('r2fg', 'k_r2fg'),
+                      ('brd2', 'k_border')):
+        np.testing.assert_array_equal(pre[mine][gpi], g[ref])
+    assert pre['alpha0'] == float(g['alpha0'])
+    assert abs(pre['alpha0'] + 2.0) < 1e-9
+    assert 20 <= pre['brd2'][gpi].min() and pre['brd2'][gpi].max() <= 50
+
+
+def test_postlude_reproduces_the_reference_grids(g4):
+    g, (n1, n2, c1, r1, c2, r2, lon_g, lat_g) = g4
+    pre = my.pm_prelude(lon_g, lat_g, n1, c1, r1, n2, c2, r2, **KW)
+    gpi = pre['gpi'].reshape(lon_g.shape)
+    # rebuild the (N,5) block the reference's workers returned from its output grids
+    dci = (pre['c2pm1'] - pre['c2pm1i'])[pre['gpi']]
+    dri = (pre['r2pm1'] - pre['r2pm1i'])[pre['gpi']]
+    c2pm2, r2pm2 = n2.transform_points(g['lon2'][gpi], g['lat2'][gpi], 1)
+    res = np.stack([c2pm2 - dci, r2pm2 - dri, g['a'][gpi], g['r'][gpi], g['h'][gpi]], axis=1)
+    out = my.pm_postlude(pre, res, n2)
+    for name, arr in zip(('u', 'v', 'a', 'r', 'h', 'lon2', 'lat2'), out):
+        np.testing.assert_allclose(arr, g[name], rtol=0, atol=1e-9, equal_nan=True, err_msg=name)
+    for name, arr in zip(('a', 'r', 'h'), out[2:5]):
+        np.testing.assert_array_equal(arr, g[name])
+
+
+def test_empty_result_gives_nan_grids(g4):
+    g, (n1, n2, c1, r1, c2, r2, lon_g, lat_g) = g4
+    pre = my.pm_prelude(lon_g, lat_g, n1, c1, r1, n2, c2, r2, **KW)
+    out = my.pm_postlude(pre, np.zeros((0, 5)), n2)
+    assert len(out) == 7 and all(o.shape == lon_g.shape and np.isnan(o).all() for o in out)
+
+
+def test_border_from_kdtree_equals_full_image_edt():
+    rng = np.random.default_rng(4)
+    shape = (300, 260)
+    x = rng.uniform(0, shape[1] - 1, 40)
+    y = rng.uniform(0, shape[0] - 1, 40)
+    seed = np.zeros(shape, dtype=bool)
+    seed[np.uint16(y), np.uint16(x)] = True
+    dist = nd.distance_transform_edt(~seed)                       # what pmlib.py:61-77 builds
+    rq = rng.integers(0, shape[0], 500)
+    cq = rng.integers(0, shape[1], 500)
+    np.testing.assert_array_equal(my.nearest_keypoint_distance(x, y, rq, cq), dist[rq, cq])
+
+
+def test_interpolators_and_fill():
+    rng = np.random.default_rng(6)
+    x1, y1 = rng.uniform(0, 100, 50), rng.uniform(0, 100, 50)
+    x2, y2 = 3 + 1.01 * x1 - 0.02 * y1, -2 + 0.03 * x1 + 0.99 * y1
+    gx, gy = np.meshgrid(np.linspace(10, 90, 5), np.linspace(10, 90, 4))
+    px, py = mylib.interpolation_poly(x1, y1, x2, y2, gx.ravel(), gy.ravel())
+    np.testing.assert_allclose(px, 3 + 1.01 * gx.ravel() - 0.02 * gy.ravel(), atol=1e-9)
+    np.testing.assert_allclose(py, -2 + 0.03 * gx.ravel() + 0.99 * gy.ravel(), atol=1e-9)
+    nx, ny = mylib.interpolation_near(x1, y1, x2, y2, np.array([50.0, 500.0]), np.array([50.0, 500.0]))
+    assert np.isfinite(nx[0]) and np.isnan(nx[1])                 # NaN outside the convex hull
+    filled = mylib._fill_gpi((2, 3), np.array([1, 0, 0, 1, 0, 1], dtype=bool), np.array([1.0, 2.0, 3.0]))
+    np.testing.assert_array_equal(filled, [[1, np.nan, np.nan], [2, np.nan, 3]])
+
+
+def test_rotation_table_matches_reference_formula():
+    t = my.rotation_table([-3, 0, 3], -3.85, 35)
+    assert t.shape == (3, 4)
+    a = np.radians(-3 + 3.85)
+    assert t[0, 0] == np.cos(a) and t[0, 1] == np.sin(a)
+    tc = 18
+    np.testing.assert_array_equal(t[0, 2:], np.array([tc, tc]).dot(np.array([[np.cos(a), -np.sin(a)],
+                                                                            [np.sin(a), np.cos(a)]])))
+
+
+def test_unsupported_options_raise_instead_of_falling_back():
+    img = np.ones((200, 200), dtype=np.uint8)
+    args = ([100.0], [100.0], [100.0], [100.0], [20.0], 34, 0.0)
+    with pytest.raises(NotImplementedError):
+        my.pm_dispatch(img, img, *args, hes_smth=True)
+    with pytest.raises(NotImplementedError):
+        my.pm_dispatch(img, img, *args, rot_order=1)
+    with pytest.raises(NotImplementedError):
+        my.pm_dispatch(img, img, *args, template_matcher=lambda *a: None)
+
+
+def test_api_surface():
+    img = np.ones((64, 64), dtype=np.uint8)
+    sid = SeaIceDrift(ArrayNansat(img), ArrayNansat(img))
+    assert callable(sid.get_drift_PM) and callable(sid.get_drift_FT)
+    with pytest.raises(NotImplementedError):
+        SeaIceDrift('a.tif', 'b.tif')
+    with pytest.raises(NotImplementedError):
+        sid.get_drift_FT()
+    n = ArrayNansat.rotated(img, angle_deg=5.0, scale=0.01, origin=(3.0, 4.0))
+    lon, lat = n.transform_points([10.0, 20.0], [5.0, 7.0])
+    c, r = n.transform_points(lon, lat, 1)
+    np.testing.assert_allclose(c, [10.0, 20.0], atol=1e-9)
+    np.testing.assert_allclose(r, [5.0, 7.0], atol=1e-9)
+    assert abs(my.get_initial_rotation(ArrayNansat(img), n) + 5.0) < 1e-9

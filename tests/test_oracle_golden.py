@@ -1,0 +1,145 @@
+"""CPU tests: the oracle (NumPy and C forms) against the fixtures generated from the
+reference's own Python (tests/golden/make_golden.py), and against each other."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import pm_oracle as po
+from sea_ice_drift_amd import synthetic as syn
+from tests.golden import make_golden as mg
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+
+
+def load(name):
+    return np.load(os.path.join(GOLD, name))
+
+
+def rot_for(angles, alpha0, s):
+    return np.array([po.rotation_terms(a - alpha0, s) for a in angles])
+
+
+# ---------------------------------------------------------------- G1 get_template
+def test_g1_templates_numpy_and_c(c_oracle):
+    g = load('g1_templates.npz')
+    img = mg.g1_image()
+    assert syn.sha256(img) == str(g['img_sha'])
+    k = 0
+    for s, key in ((34, 't34'), (35, 't35')):
+        k = 0
+        for a in mg.G1_ANGLES:
+            for (c, r) in mg.G1_CENTRES:
+                exp = g[key][k].reshape(s, s)
+                np.testing.assert_array_equal(po.get_template(img, c, r, a, s), exp)
+                np.testing.assert_array_equal(c_oracle.get_template(img, c, r, po.rotation_terms(a, s), s), exp)
+                k += 1
+    np.testing.assert_array_equal(po.get_template(img, 5, 5, 10, 34), g['edge'])
+    np.testing.assert_array_equal(c_oracle.get_template(img, 5, 5, po.rotation_terms(10, 34), 34), g['edge'])
+    assert g['edge'].min() == 0
+
+
+# ---------------------------------------------------------------- G2 get_hessian
+@pytest.mark.parametrize('n', [42, 72, 101, 102])
+def test_g2_hessian(c_oracle, n):
+    g = load('g2_hessian.npz')
+    m = g['in%d' % n]
+    np.testing.assert_array_equal(po.raw_hessian(m), g['raw%d' % n])
+    np.testing.assert_array_equal(po.get_hessian(m), g['norm%d' % n])
+    np.testing.assert_array_equal(c_oracle.hessian(m, 0), g['raw%d' % n])
+    np.testing.assert_array_equal(c_oracle.hessian(m, 1), g['norm%d' % n])
+    # hes_smth: the C form restates scipy's gaussian_filter; float32 round-off level agreement
+    np.testing.assert_allclose(c_oracle.hessian(m, 3), g['smth%d' % n], rtol=2e-4, atol=2e-4)
+
+
+# ---------------------------------------------------------------- matcher
+def test_match_template_definition_and_c_form(c_oracle):
+    rng = np.random.default_rng(9)
+    for (wh, ww, s) in ((75, 75, 34), (60, 71, 35), (40, 37, 34)):
+        img = rng.integers(1, 256, (wh, ww), dtype=np.uint8)
+        t = rng.integers(1, 256, (s, s), dtype=np.uint8)
+        r = po.match_template(img, t)
+        assert r.dtype == np.float32 and r.shape == (wh - s + 1, ww - s + 1)
+        np.testing.assert_allclose(r, po.ncc_bruteforce_f64(img, t), atol=2e-7)
+        np.testing.assert_array_equal(c_oracle.match_template(img, t), r)
+
+
+def test_match_template_special_cases(c_oracle):
+    rng = np.random.default_rng(10)
+    img = rng.integers(1, 256, (50, 50), dtype=np.uint8)
+    flat_t = np.full((34, 34), 77, dtype=np.uint8)
+    for f in (po.match_template, c_oracle.match_template):
+        np.testing.assert_array_equal(f(img, flat_t), np.ones((17, 17), dtype=np.float32))   # constant template
+        flat_img = np.full((50, 50), 9, dtype=np.uint8)
+        t = rng.integers(1, 256, (34, 34), dtype=np.uint8)
+        np.testing.assert_array_equal(f(flat_img, t), np.zeros((17, 17), dtype=np.float32))  # no window variance
+        exact = img.copy()
+        exact[5:39, 7:41] = t
+        r = f(exact, t)
+        assert r[5, 7] == np.float32(1.0) and np.argmax(r) == 5 * 17 + 7                     # perfect match
+
+
+# ---------------------------------------------------------------- G3 use_mcc
+@pytest.mark.parametrize('s,alpha0', [(34, 0.0), (35, -3.85)])
+def test_g3_use_mcc(c_oracle, s, alpha0):
+    g = load('g3_use_mcc.npz')
+    img1, img2 = mg.g3_pair()
+    assert syn.sha256(img1, img2) == str(g['pair_sha'])
+    v = [g[k] for k in ('c1', 'r1', 'c2fg', 'r2fg', 'border')]
+    n_nan = 0
+    for k, angles in enumerate(mg.G3_ANGLE_SETS):
+        for mcc in ((0, 1) if k == 1 else (0,)):
+            exp = g['out_s%d_k%d_m%d' % (s, k, mcc)]
+            flags = 1 | (4 if mcc else 0)
+            got_c, ij = c_oracle.pm_batch(img1, img2, *v, s, alpha0, angles, rot=rot_for(angles, alpha0, s),
+                                          flags=flags, nthreads=4)
+            np.testing.assert_array_equal(got_c, exp)              # bit-exact incl. NaN rows and h
+            assert ((ij[:, 2] == -1) == np.isnan(exp[:, 0])).all()
+            n_nan += int(np.isnan(exp[:, 0]).sum())
+            if k == 0:                                             # NumPy form on the cheapest set
+                got_n, _ = po.pm_batch(img1, img2, *v, s, alpha0, angles, flags=flags)
+                np.testing.assert_array_equal(got_n, exp)
+    assert n_nan > 0                                               # the zero-pixel NaN path is exercised
+
+
+def test_g3_full_intermediates(c_oracle):
+    g = load('g3_use_mcc.npz')
+    img1, img2 = mg.g3_pair()
+    angles, s, alpha0 = mg.G3_ANGLE_SETS[1], 34, 0.0
+    for i in g['full_points']:
+        res, (bij, bk, bres, btmpl) = po.use_mcc(g['c1'][i], g['r1'][i], g['c2fg'][i], g['r2fg'][i], g['border'][i],
+                                                 img1, img2, s, alpha0, full=True, angles=angles)
+        np.testing.assert_array_equal(bres, g['full%d_result' % i])
+        np.testing.assert_array_equal(btmpl, g['full%d_template' % i])
+        dc, dr, ba, br, bh = g['full%d_scalars' % i]
+        assert (res[0] - g['c2fg'][i], res[1] - g['r2fg'][i], res[2], res[3], res[4]) == (dc, dr, ba, br, bh)
+        np.testing.assert_array_equal(c_oracle.match_template(
+            img2[int(g['r2fg'][i] - 17 - g['border'][i]):int(g['r2fg'][i] + 17 + g['border'][i] + 1),
+                 int(g['c2fg'][i] - 17 - g['border'][i]):int(g['c2fg'][i] + 17 + g['border'][i] + 1)], btmpl), bres)
+
+
+def test_reference_quirks_are_kept():
+    """tc = int(s/2.)+1 biases the displacement by -1.5 px (s=34) / -1 px (s=35)."""
+    rng = np.random.default_rng(1)
+    img1 = rng.integers(1, 256, (300, 300), dtype=np.uint8)
+    img2 = np.roll(np.roll(img1, 4, axis=0), -6, axis=1)          # shift +4 rows, -6 cols
+    for s, (edr, edc) in ((35, (3.0, -7.0)), (34, (2.5, -7.5))):
+        c2, r2, a, r, h = po.use_mcc(150.0, 150.0, 150.0, 150.0, 20.0, img1, img2, s, 0.0, angles=[0])
+        assert (r2 - 150.0, c2 - 150.0) == (edr, edc)
+        assert r == np.float32(1.0)
+
+
+def test_out_of_image_window_is_nan(c_oracle):
+    img1, img2 = syn.make_pair(200, 200, seed=2)
+    out, ij = c_oracle.pm_batch(img1, img2, [100.0, 100.0], [100.0, 100.0], [30.0, 100.0], [100.0, 100.0],
+                                [20.0, 20.0], 34, 0.0, [0.0])
+    assert np.isnan(out[0]).all() and (ij[0] == -1).all() and np.isfinite(out[1]).all()
+    exp, _ = po.pm_batch(img1, img2, [100.0, 100.0], [100.0, 100.0], [30.0, 100.0], [100.0, 100.0], [20.0, 20.0],
+                         34, 0.0, [0.0])
+    np.testing.assert_array_equal(out, exp)
+
+
+def test_g5_fullsize_subsample_present():
+    g = load('g5_fullsize.npz')
+    assert g['out'].shape == (400, 5) and g['ij'].shape == (400, 3)
+    assert np.isfinite(g['out']).all()
