@@ -32,8 +32,21 @@ if ROOT not in sys.path:
 
 # MI355X peaks used for the roofline fractions (/opt/skills/guides/MI355X_MICROARCH.md)
 HBM_PEAK_GBS = 8000.0
-# v_dot4_u32_u8: 4 MAC/lane, 32 lanes/clk/SIMD, 4 SIMD/CU, 256 CU, 2.4 GHz
-VALU_DOT4_PEAK_TMACS = 4 * 32 * 4 * 256 * 2.4e9 / 1e12
+# v_dot4_u32_u8 issues at half rate on gfx950 (tools/ubench/valu_rates.hip: 31 T lane-instr/s measured):
+# 4 MAC/lane x 16 lanes/clk/SIMD x 4 SIMD/CU x 256 CU x 2.4 GHz
+VALU_DOT4_PEAK_TMACS = 4 * 16 * 4 * 256 * 2.4e9 / 1e12
+
+
+def host_cores():
+    """CPU threads this process may really use: affinity mask capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()[:2]
+        if quota != 'max':
+            n = min(n, max(1, int(np.ceil(int(quota) / int(period)))))
+    except (OSError, ValueError):
+        pass
+    return n
 
 
 def parse_args():
@@ -180,14 +193,14 @@ def main():
                         'vector integer-dot rate, not HBM; see "valu" and DESIGN.md',
                 'valu': {'achieved': valu_achieved, 'peak': VALU_DOT4_PEAK_TMACS, 'unit': 'TMAC/s',
                          'frac': valu_achieved / VALU_DOT4_PEAK_TMACS,
-                         'peak_basis': 'v_dot4_u32_u8: 4 MAC x 32 lanes/clk x 4 SIMD x 256 CU x 2.4 GHz'},
+                         'peak_basis': 'v_dot4_u32_u8 (half rate): 4 MAC x 16 lanes/clk x 4 SIMD x 256 CU x 2.4 GHz'},
             },
             'setup_s': {'generate_and_upload_pair': t_gen},
         }
         # ---- parity spot check against the oracle (checker only; not timed) ----
         from oracle import c_oracle
         c_oracle.build()
-        nthreads = len(os.sched_getaffinity(0))
+        nthreads = host_cores()
         if args.check > 0:
             sel = np.random.default_rng(0).choice(n_total, size=min(args.check, n_total), replace=False)
             exp, exp_ij = c_oracle.pm_batch(img1, img2, g['c1'][sel], g['r1'][sel], g['c2fg'][sel], g['r2fg'][sel],
