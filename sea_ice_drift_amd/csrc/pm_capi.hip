@@ -8,6 +8,7 @@
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -70,8 +71,11 @@ struct DevBuf {
 
 }  // namespace
 
+enum KernelKind { KERNEL_MFMA = 0, KERNEL_DOT4 = 1 };
+
 struct sid_pm_ctx {
     int device = 0;
+    int kernel = KERNEL_MFMA;           // SID_PM_KERNEL=dot4 selects the VALU kernel (A/B runs, tests)
     hipStream_t stream = nullptr;
     // image pairs: two owned slots + one borrowed binding
     DevBuf<uint8_t> own[2][2];
@@ -142,14 +146,25 @@ int check_images(const Image &a, const Image &b)
     return SID_PM_OK;
 }
 
-int check_sweep(int img_size, const double *angles, int n_angles, uint32_t flags)
+bool size_supported(int kernel, int s)
+{
+    return kernel == KERNEL_DOT4 ? sid::img_size_supported(s) : sid::mfma_img_size_supported(s);
+}
+
+int lds_need(int kernel, int wh, int ww, int s, int K)
+{
+    return kernel == KERNEL_DOT4 ? sid::lds_layout(wh, ww, s, K).total : sid::mfma_lds_layout(wh, ww, s).total;
+}
+
+int check_sweep(int kernel, int img_size, const double *angles, int n_angles, uint32_t flags)
 {
     if (!angles || n_angles < 1)
         return fail(SID_PM_ERR_ARG, "angles must hold at least one angle (the reference's loop, pmlib.py:150, "
                                     "leaves best_result undefined for an empty list)");
     if (n_angles > sid::kMaxAngles) return fail(SID_PM_ERR_UNSUPPORTED, "more than %d angles", sid::kMaxAngles);
-    if (!sid::img_size_supported(img_size))
-        return fail(SID_PM_ERR_UNSUPPORTED, "img_size=%d: kernels are instantiated for 33..36", img_size);
+    if (!size_supported(kernel, img_size))
+        return fail(SID_PM_ERR_UNSUPPORTED, "img_size=%d: the %s kernel supports %s", img_size,
+                    kernel == KERNEL_DOT4 ? "dot4" : "MFMA", kernel == KERNEL_DOT4 ? "33..36" : "2..49");
     if (flags & SID_PM_HES_SMTH) return fail(SID_PM_ERR_UNSUPPORTED, "hes_smth=True is not implemented on the device");
     if (flags & ~(SID_PM_HES_NORM | SID_PM_HES_SMTH | SID_PM_MCC_NORM)) return fail(SID_PM_ERR_ARG, "unknown flag bits");
     return SID_PM_OK;
@@ -215,6 +230,8 @@ SID_EXPORT int sid_pm_create(int device, sid_pm_ctx **out)
     sid_pm_ctx *ctx = new (std::nothrow) sid_pm_ctx();
     if (!ctx) return fail(SID_PM_ERR_NOMEM, "host allocation failed");
     ctx->device = device;
+    const char *kk = getenv("SID_PM_KERNEL");
+    if (kk && strcmp(kk, "dot4") == 0) ctx->kernel = KERNEL_DOT4;
     *out = ctx;
     return SID_PM_OK;
 }
@@ -290,7 +307,7 @@ SID_EXPORT int sid_pm_set_points(sid_pm_ctx *ctx, const double *c1, const double
     if (!ctx) return fail(SID_PM_ERR_ARG, "null ctx");
     if (n < 0 || n > 0x7fffffff / 8) return fail(SID_PM_ERR_ARG, "bad point count");
     if (n > 0 && (!c1 || !r1 || !c2fg || !r2fg || !border)) return fail(SID_PM_ERR_ARG, "null point vector");
-    if (int rc = check_sweep(img_size, angles, n_angles, flags)) return rc;
+    if (int rc = check_sweep(ctx->kernel, img_size, angles, n_angles, flags)) return rc;
     if (!ctx->have_pair) return fail(SID_PM_ERR_STATE, "set_points needs an image pair (upload_pair/bind_pair first)");
     Guard g(ctx->device);
     const int s = img_size, K = n_angles;
@@ -299,18 +316,18 @@ SID_EXPORT int sid_pm_set_points(sid_pm_ctx *ctx, const double *c1, const double
     // classify: LDS footprint -> residency class (blocks per CU), work for ordering
     struct P { int idx; int lds; int cls; double work; };
     std::vector<P> pts((size_t)n);
-    const int lds_min = sid::lds_layout(s + 1, s + 1, s, K).total;
+    const int lds_min = lds_need(ctx->kernel, s + 1, s + 1, s, K);
     double macs = 0, bytes = 0, valid = 0;
     int lds_max = 0;
     for (int64_t i = 0; i < n; ++i) {
         int wh = 0, ww = 0;
         P p{(int)i, lds_min, 0, 0.0};
         if (window_dims(c2fg[i], r2fg[i], border[i], s, rows2, cols2, wh, ww)) {
-            const sid::LdsLayout L = sid::lds_layout(wh, ww, s, K);
-            if (L.total > sid::max_lds_bytes())
+            const int need = lds_need(ctx->kernel, wh, ww, s, K);
+            if (need > sid::max_lds_bytes())
                 return fail(SID_PM_ERR_UNSUPPORTED, "point %lld: search window %dx%d needs %d bytes of LDS (> %d)",
-                            (long long)i, wh, ww, L.total, sid::max_lds_bytes());
-            p.lds = L.total;
+                            (long long)i, wh, ww, need, sid::max_lds_bytes());
+            p.lds = need;
             const double rh = wh - s + 1, rw = ww - s + 1;
             p.work = rh * rw;
             macs += (double)K * rh * rw * s * s;
@@ -388,7 +405,8 @@ SID_EXPORT int sid_pm_run(sid_pm_ctx *ctx)
     for (const Bucket &b : ctx->buckets) {
         A.order = ctx->order.p + b.offset;
         A.n_launch = b.count;
-        const int e = sid::launch_pm(A, b.lds, ctx->stream);
+        const int e = ctx->kernel == KERNEL_DOT4 ? sid::launch_pm(A, b.lds, ctx->stream)
+                                                 : sid::launch_pm_mfma(A, b.lds, ctx->stream);
         if (e != 0) return fail(SID_PM_ERR_HIP, "kernel launch failed: %s", hipGetErrorString((hipError_t)e));
     }
     return SID_PM_OK;
@@ -466,12 +484,12 @@ SID_EXPORT int sid_pm_debug_point(sid_pm_ctx *ctx, double c1, double r1, double 
 {
     if (!ctx) return fail(SID_PM_ERR_ARG, "null ctx");
     if (!ctx->have_pair) return fail(SID_PM_ERR_STATE, "debug_point needs an image pair");
-    if (int rc = check_sweep(img_size, angles, n_angles, flags)) return rc;
+    if (int rc = check_sweep(ctx->kernel, img_size, angles, n_angles, flags)) return rc;
     Guard g(ctx->device);
     const int s = img_size, K = n_angles;
-    int wh = 0, ww = 0, lds = sid::lds_layout(s + 1, s + 1, s, K).total;
+    int wh = 0, ww = 0, lds = lds_need(ctx->kernel, s + 1, s + 1, s, K);
     if (window_dims(c2fg, r2fg, border, s, ctx->cur[1].rows, ctx->cur[1].cols, wh, ww))
-        lds = sid::lds_layout(wh, ww, s, K).total;
+        lds = lds_need(ctx->kernel, wh, ww, s, K);
     if (lds > sid::max_lds_bytes()) return fail(SID_PM_ERR_UNSUPPORTED, "search window too large for LDS");
     std::vector<double> rotv;
     make_rot(angles, K, alpha0, s, rot, rotv);
@@ -509,7 +527,8 @@ SID_EXPORT int sid_pm_debug_point(sid_pm_ctx *ctx, double c1, double r1, double 
         A.order = dord.p; A.n_launch = 1; A.img_size = s; A.n_angles = K; A.flags = flags;
         A.angles = dang.p; A.rot = drot.p; A.out = dout.p; A.out_ij = dij.p;
         A.dbg_templates = dt.p; A.dbg_ccm = dccm.p; A.dbg_hes = dhes.p; A.dbg_shape = dshape.p; A.dbg_cap = cap;
-        step((hipError_t)sid::launch_pm(A, lds, ctx->stream));
+        step((hipError_t)(ctx->kernel == KERNEL_DOT4 ? sid::launch_pm(A, lds, ctx->stream)
+                                                     : sid::launch_pm_mfma(A, lds, ctx->stream)));
         step(hipStreamSynchronize(ctx->stream));
         if (templates) step(hipMemcpy(templates, dt.p, tcount, hipMemcpyDeviceToHost));
         if (ccm && cap > 0) step(hipMemcpy(ccm, dccm.p, sizeof(float) * cap, hipMemcpyDeviceToHost));

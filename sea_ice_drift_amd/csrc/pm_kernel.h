@@ -55,6 +55,39 @@ __host__ __device__ inline LdsLayout lds_layout(int wh, int ww, int s, int K)
     return L;
 }
 
+// ---- MFMA kernel (pm_kernel_mfma.hip) ----
+constexpr int kMiscMfmaBytes = 2048;
+
+struct MfmaLdsLayout {
+    int wpitch;        // bytes per window row (int8, re-centred)
+    int win_off;       // window
+    int sii_off;       // sum w'^2 per placement (u32); later the Hessian (f32)
+    int u_off;         // union: column sums | sweep template fragments | winner operands + NCC matrix
+    int trow_bytes;    // one winner operand block: 4 k-groups x (s+32) rows x 16 B
+    int total;
+};
+
+__host__ __device__ inline MfmaLdsLayout mfma_lds_layout(int wh, int ww, int s)
+{
+    MfmaLdsLayout L;
+    const int rh = wh - s + 1, rw = ww - s + 1;
+    const int ntx = (rw + 15) / 16;
+    L.wpitch = 16 * ntx + 68;                       // a window fragment reads 5 dwords from (x0+15+48) & ~3
+    if (L.wpitch < round_up(ww, 4)) L.wpitch = round_up(ww, 4);
+    L.win_off = kMiscMfmaBytes;
+    L.sii_off = round_up(L.win_off + wh * L.wpitch, 16);
+    L.u_off = round_up(L.sii_off + rh * rw * 4, 16);
+    L.trow_bytes = 4 * (s + 32) * 16;
+    int u = rh * ww * 4;                            // column sums
+    if (u < (s + 1) * 1024) u = (s + 1) * 1024;     // 16 slots x 64 columns per template row (+ a zero row)
+    if (u < 2 * L.trow_bytes + rh * rw * 4) u = 2 * L.trow_bytes + rh * rw * 4;
+    L.total = round_up(L.u_off + u, 16);
+    return L;
+}
+
+int launch_pm_mfma(const PMArgs &args, int lds_bytes, void *stream);
+bool mfma_img_size_supported(int s);
+
 // host-side launcher implemented in pm_kernel.hip; returns a hipError_t as int
 int launch_pm(const PMArgs &args, int lds_bytes, void *stream);
 int launch_rsqrt(const double *x, double *y, int64_t n, void *stream);

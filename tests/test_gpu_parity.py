@@ -75,3 +75,45 @@ def test_one_shot_batch_entry(c_oracle):
     got, got_ij = _capi.pm_batch(img1, img2, g['c1'], g['r1'], g['c2fg'], g['r2fg'], g['border'], 34, 0.0,
                                  ANGLES7, rot=rot_for(ANGLES7, 0.0, 34))
     assert_parity(got, got_ij, exp, exp_ij)
+
+
+@pytest.mark.parametrize('s,nang', [(21, 5), (33, 7), (36, 15), (49, 3), (34, 17), (35, 31)])
+def test_other_template_sizes_and_angle_counts(pm_ctx, c_oracle, s, nang):
+    """Generic-size code path (s not 34/35) and more than 15 angles (several template groups)."""
+    img1, img2 = syn.make_pair(500, 500, seed=21)
+    g = syn.make_grid(500, 500, 7, margin=95, border=20 if s > 40 else 'mixed')
+    half = nang // 2
+    angles = [0.5 * k for k in range(-half, nang - half)]
+    rot = rot_for(angles, 1.25, s)
+    exp, exp_ij = c_oracle.pm_batch(img1, img2, g['c1'], g['r1'], g['c2fg'], g['r2fg'], g['border'], s, 1.25,
+                                    angles, rot=rot, nthreads=8)
+    pm_ctx.upload_pair(img1, img2)
+    pm_ctx.set_points(g['c1'], g['r1'], g['c2fg'], g['r2fg'], g['border'], s, 1.25, angles, rot=rot)
+    pm_ctx.run()
+    got, got_ij = pm_ctx.fetch()
+    assert_parity(got, got_ij, exp, exp_ij)
+
+
+def test_ties_and_degenerate_inputs(pm_ctx, c_oracle):
+    """Exact ties (periodic image: many placements with r == 1), a constant template (r == 1
+    everywhere -> first placement wins) and a flat window (r == 0 everywhere)."""
+    yy, xx = np.mgrid[0:400, 0:400]
+    periodic = (1 + ((yy % 8) * 8 + (xx % 8)) * 3).astype(np.uint8)      # period 8 in both directions
+    flat1 = periodic.copy()
+    flat1[100:200, 100:200] = 77                                        # constant template region
+    flat2 = periodic.copy()
+    flat2[250:400, 250:400] = 9                                         # flat search window region
+    pts = dict(c1=[300.0, 150.0, 60.0], r1=[60.0, 150.0, 300.0], c2fg=[301.0, 150.0, 320.0],
+               r2fg=[62.0, 150.0, 320.0], border=[20.0, 22.0, 21.0])
+    angles = [-3.0, 0.0, 3.0]
+    rot = rot_for(angles, 0.0, 34)
+    v = [pts[k] for k in ('c1', 'r1', 'c2fg', 'r2fg', 'border')]
+    exp, exp_ij = c_oracle.pm_batch(flat1, flat2, *v, 34, 0.0, angles, rot=rot)
+    pm_ctx.upload_pair(flat1, flat2)
+    pm_ctx.set_points(*v, 34, 0.0, angles, rot=rot)
+    pm_ctx.run()
+    got, got_ij = pm_ctx.fetch()
+    np.testing.assert_array_equal(got_ij, exp_ij)
+    np.testing.assert_array_equal(got[:, :4], exp[:, :4])
+    assert exp[0, 3] == 1.0 and exp[1, 3] == 1.0 and exp[2, 3] == 0.0
+    assert tuple(exp_ij[1]) == (0, 0, 0) and tuple(exp_ij[2]) == (0, 0, 0)
