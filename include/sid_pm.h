@@ -143,12 +143,13 @@ int sid_pm_work_info(sid_pm_ctx *ctx, double info[6]);
 
 /* Intermediate results of one point: rotated templates [n_angles][s][s] (uint8), the NCC
  * matrix of the winning angle and its raw Hessian magnitude [rh][rw] (float32, caller
- * provides capacity `cap` floats each), shape in rh_rw[2].  Any output pointer may be NULL. */
+ * provides capacity `cap` floats each), shape in rh_rw[2]; phase_cycles = shader-clock stamps at
+ * the kernel's phase boundaries (one workgroup on an idle device).  Any output pointer may be NULL. */
 int sid_pm_debug_point(sid_pm_ctx *ctx, double c1, double r1, double c2fg, double r2fg,
                        double border, int img_size, double alpha0, const double *angles,
                        const double *rot, int n_angles, uint32_t flags,
                        uint8_t *templates, float *ccm, float *hes, int64_t cap, int32_t rh_rw[2],
-                       double out5[5], int32_t ij3[3]);
+                       double out5[5], int32_t ij3[3], int64_t phase_cycles[16]);
 
 /* y[i] = 1.0 / sqrt(x[i]) evaluated on the device in IEEE double, the one transcendental
  * step of the NCC specification; lets a test pin device vs host rounding. */

@@ -76,7 +76,7 @@ def lib():
     L.sid_pm_work_info.argtypes = [C.c_void_p, _f64p]
     L.sid_pm_debug_point.argtypes = [C.c_void_p] + [C.c_double] * 5 + [C.c_int, C.c_double, _f64p, _f64p, C.c_int,
                                                                       C.c_uint32, _u8p, _f32p, _f32p, C.c_int64,
-                                                                      _i32p, _f64p, _i32p]
+                                                                      _i32p, _f64p, _i32p, C.POINTER(C.c_int64)]
     L.sid_pm_debug_rsqrt.argtypes = [C.c_void_p, _f64p, _f64p, C.c_int64]
     for name in SYMBOLS:
         getattr(L, name)                      # AttributeError here = header/library mismatch
@@ -252,13 +252,15 @@ class PMContext(object):
         shape = np.zeros(2, dtype=np.int32)
         out5 = np.zeros(5, dtype=np.float64)
         ij3 = np.zeros(3, dtype=np.int32)
+        cyc = np.zeros(16, dtype=np.int64)
         _check(lib().sid_pm_debug_point(self._h, float(c1), float(r1), float(c2fg), float(r2fg), float(border), s,
                                         float(alpha0), _p(angles, _f64p), rotp, K, int(flags), _p(tm, _u8p),
                                         _p(ccm, _f32p), _p(hes, _f32p), cap, _p(shape, _i32p), _p(out5, _f64p),
-                                        _p(ij3, _i32p)))
+                                        _p(ij3, _i32p), cyc.ctypes.data_as(C.POINTER(C.c_int64))))
         rh, rw = int(shape[0]), int(shape[1])
         n = rh * rw
-        return dict(templates=tm, ccm=ccm[:n].reshape(rh, rw), hes=hes[:n].reshape(rh, rw), out=out5, ij=ij3)
+        return dict(templates=tm, ccm=ccm[:n].reshape(rh, rw), hes=hes[:n].reshape(rh, rw), out=out5, ij=ij3,
+                    cycles=cyc)
 
     def debug_rsqrt(self, x):
         x = _f64(x)

@@ -402,7 +402,10 @@ SID_EXPORT int sid_pm_run(sid_pm_ctx *ctx)
     Guard g(ctx->device);
     sid::PMArgs A;
     fill_args(ctx, A);
-    for (const Bucket &b : ctx->buckets) {
+    static const int lds_pad = getenv("SID_PM_LDS_PAD") ? atoi(getenv("SID_PM_LDS_PAD")) : 0;   // occupancy experiments
+    for (const Bucket &b0 : ctx->buckets) {
+        Bucket b = b0;
+        b.lds = std::min(b.lds + lds_pad, sid::max_lds_bytes());
         A.order = ctx->order.p + b.offset;
         A.n_launch = b.count;
         const int e = ctx->kernel == KERNEL_DOT4 ? sid::launch_pm(A, b.lds, ctx->stream)
@@ -480,7 +483,7 @@ SID_EXPORT int sid_pm_debug_point(sid_pm_ctx *ctx, double c1, double r1, double 
                                   double border, int img_size, double alpha0, const double *angles,
                                   const double *rot, int n_angles, uint32_t flags,
                                   uint8_t *templates, float *ccm, float *hes, int64_t cap, int32_t rh_rw[2],
-                                  double out5[5], int32_t ij3[3])
+                                  double out5[5], int32_t ij3[3], int64_t phase_cycles[16])
 {
     if (!ctx) return fail(SID_PM_ERR_ARG, "null ctx");
     if (!ctx->have_pair) return fail(SID_PM_ERR_STATE, "debug_point needs an image pair");
@@ -498,14 +501,15 @@ SID_EXPORT int sid_pm_debug_point(sid_pm_ctx *ctx, double c1, double r1, double 
     DevBuf<int32_t> dord, dij, dshape;
     DevBuf<uint8_t> dt;
     DevBuf<float> dccm, dhes;
+    DevBuf<long long> dcyc;
     int rc = SID_PM_OK;
     auto cleanup = [&]() { dv.release(); dang.release(); drot.release(); dout.release(); dord.release();
-                           dij.release(); dshape.release(); dt.release(); dccm.release(); dhes.release(); };
+                           dij.release(); dshape.release(); dt.release(); dccm.release(); dhes.release(); dcyc.release(); };
     const size_t tcount = (size_t)K * s * s;
     if ((rc = dv.reserve(5)) || (rc = dang.reserve((size_t)K)) || (rc = drot.reserve(4 * (size_t)K)) ||
         (rc = dout.reserve(5)) || (rc = dord.reserve(1)) || (rc = dij.reserve(3)) || (rc = dshape.reserve(2)) ||
         (rc = dt.reserve(tcount)) || (rc = dccm.reserve((size_t)std::max<int64_t>(cap, 1))) ||
-        (rc = dhes.reserve((size_t)std::max<int64_t>(cap, 1)))) { cleanup(); return rc; }
+        (rc = dhes.reserve((size_t)std::max<int64_t>(cap, 1))) || (rc = dcyc.reserve(16))) { cleanup(); return rc; }
     const double v5[5] = {c1, r1, c2fg, r2fg, border};
     const int32_t zero = 0, shape0[2] = {0, 0};
     hipError_t e = hipSuccess;
@@ -517,6 +521,7 @@ SID_EXPORT int sid_pm_debug_point(sid_pm_ctx *ctx, double c1, double r1, double 
     step(hipMemcpy(dord.p, &zero, sizeof zero, hipMemcpyHostToDevice));
     step(hipMemcpy(dshape.p, shape0, sizeof shape0, hipMemcpyHostToDevice));
     step(hipMemset(dt.p, 0, tcount));
+    step(hipMemset(dcyc.p, 0, sizeof(long long) * 16));
     if (cap > 0) { step(hipMemset(dccm.p, 0, sizeof(float) * cap)); step(hipMemset(dhes.p, 0, sizeof(float) * cap)); }
     if (e == hipSuccess) {
         sid::PMArgs A;
@@ -527,6 +532,7 @@ SID_EXPORT int sid_pm_debug_point(sid_pm_ctx *ctx, double c1, double r1, double 
         A.order = dord.p; A.n_launch = 1; A.img_size = s; A.n_angles = K; A.flags = flags;
         A.angles = dang.p; A.rot = drot.p; A.out = dout.p; A.out_ij = dij.p;
         A.dbg_templates = dt.p; A.dbg_ccm = dccm.p; A.dbg_hes = dhes.p; A.dbg_shape = dshape.p; A.dbg_cap = cap;
+        A.dbg_cycles = dcyc.p;
         step((hipError_t)(ctx->kernel == KERNEL_DOT4 ? sid::launch_pm(A, lds, ctx->stream)
                                                      : sid::launch_pm_mfma(A, lds, ctx->stream)));
         step(hipStreamSynchronize(ctx->stream));
@@ -536,6 +542,7 @@ SID_EXPORT int sid_pm_debug_point(sid_pm_ctx *ctx, double c1, double r1, double 
         if (rh_rw) step(hipMemcpy(rh_rw, dshape.p, sizeof(int32_t) * 2, hipMemcpyDeviceToHost));
         if (out5) step(hipMemcpy(out5, dout.p, sizeof(double) * 5, hipMemcpyDeviceToHost));
         if (ij3) step(hipMemcpy(ij3, dij.p, sizeof(int32_t) * 3, hipMemcpyDeviceToHost));
+        if (phase_cycles) step(hipMemcpy(phase_cycles, dcyc.p, sizeof(long long) * 16, hipMemcpyDeviceToHost));
     }
     cleanup();
     if (e != hipSuccess) return fail(SID_PM_ERR_HIP, "debug_point: %s", hipGetErrorString(e));

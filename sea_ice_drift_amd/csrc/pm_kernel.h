@@ -25,6 +25,7 @@ struct PMArgs {
     int32_t *out_ij;                                // [n_total][3]
     // diagnostics (debug_point only; null in production launches)
     uint8_t *dbg_templates; float *dbg_ccm; float *dbg_hes; int32_t *dbg_shape; int64_t dbg_cap;
+    long long *dbg_cycles;                          // [16] shader-clock stamps at phase boundaries
 };
 
 // LDS carve-up for a window of wh x ww pixels, template side s, K angles.
@@ -57,12 +58,16 @@ __host__ __device__ inline LdsLayout lds_layout(int wh, int ww, int s, int K)
 
 // ---- MFMA kernel (pm_kernel_mfma.hip) ----
 constexpr int kMiscMfmaBytes = 2048;
+constexpr int kQueueCap = 192;       // arg-max candidates waiting for exact evaluation (16 B each)
 
 struct MfmaLdsLayout {
     int wpitch;        // bytes per window row (int8, re-centred)
     int win_off;       // window
     int sii_off;       // sum w'^2 per placement (u32); later the Hessian (f32)
-    int u_off;         // union: column sums | sweep template fragments | winner operands + NCC matrix
+    int u_off;         // union: column sums | sweep operands + patch + queue | winner operands + NCC matrix
+    int arow;          // bytes per template row in the sweep operand table (48 or 64 lanes x 16 B)
+    int patch_off, ppitch, pdim, pradius;   // image-1 patch the templates are sampled from
+    int queue_off;
     int trow_bytes;    // one winner operand block: 4 k-groups x (s+32) rows x 16 B
     int total;
 };
@@ -77,9 +82,20 @@ __host__ __device__ inline MfmaLdsLayout mfma_lds_layout(int wh, int ww, int s)
     L.win_off = kMiscMfmaBytes;
     L.sii_off = round_up(L.win_off + wh * L.wpitch, 16);
     L.u_off = round_up(L.sii_off + rh * rw * 4, 16);
+    L.arow = s <= 48 ? 768 : 1024;                  // columns >= 48 of a template row are zero unless s = 49
+    // rotated template samples stay within hypot(tc, tc) of the centre, tc = int(s/2)+1 (pmlib.py:105)
+    const int tc = s / 2 + 1;
+    int r = 0;
+    while (r * r < 2 * tc * tc) ++r;                // ceil(hypot(tc, tc))
+    L.pradius = r + 1;
+    L.pdim = 2 * L.pradius + 2;
+    L.ppitch = round_up(L.pdim, 4);
+    L.patch_off = L.u_off + round_up((s + 1) * L.arow, 16);       // + one all-zero row
+    L.queue_off = round_up(L.patch_off + L.pdim * L.ppitch, 16);
     L.trow_bytes = 4 * (s + 32) * 16;
-    int u = rh * ww * 4;                            // column sums
-    if (u < (s + 1) * 1024) u = (s + 1) * 1024;     // 16 slots x 64 columns per template row (+ a zero row)
+    int u = rh * ww * 4;                                          // column sums
+    const int sweep = L.queue_off + kQueueCap * 16 - L.u_off;
+    if (u < sweep) u = sweep;
     if (u < 2 * L.trow_bytes + rh * rw * 4) u = 2 * L.trow_bytes + rh * rw * 4;
     L.total = round_up(L.u_off + u, 16);
     return L;

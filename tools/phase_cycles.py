@@ -1,0 +1,27 @@
+#!/usr/bin/env python3
+"""Shader-clock cycles per kernel phase for single points (one workgroup on an idle GPU)."""
+import sys, os
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from sea_ice_drift_amd import _capi, synthetic as syn
+from sea_ice_drift_amd.pmlib import rotation_table
+
+img1, img2 = syn.make_pair(1000, 1000)
+g = syn.make_grid(1000, 1000, 10, border=20)
+angles = list(range(-7, 8))
+rot = rotation_table(angles, 0.0, 34)
+names = ['P0a window', 'P1 sums', 'P0b templates', 'P2 sweep', 'P3 argmax', 'P4 winner', 'P5 hessian']
+with _capi.PMContext(0) as ctx:
+    ctx.upload_pair(img1, img2)
+    for b in (20, 35, 50):
+        acc = []
+        for i in (11, 45, 77, 78):
+            d = ctx.debug_point(g['c1'][i], g['r1'][i], g['c2fg'][i], g['r2fg'][i], float(b), 34, 0.0, angles, rot=rot)
+            acc.append(np.diff(d['cycles'][:8]))
+            c = d['cycles']
+            fine = [c[8] - c[2], c[9] - c[8], c[3] - c[9], c[11] - c[10], c[12] - c[11], c[13] - c[5], c[6] - c[13], c[14] - c[6], c[7] - c[14]]
+        acc = np.median(np.array(acc), axis=0)
+        print('border %d: total %d cycles' % (b, acc.sum()))
+        for n, c in zip(names, acc):
+            print('   %-14s %8d  %5.1f %%' % (n, c, 100.0 * c / acc.sum()))
+        print('   fine: patch+zero %d, sampling %d, sums %d | item0 sweep %d, item0 epilogue %d | P4 staging %d, P4 mfma+norm %d | P5 hessian %d, P5 median/std %d' % tuple(fine))
