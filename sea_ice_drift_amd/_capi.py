@@ -9,7 +9,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libsid_pm.so')
+LIB_PATH = os.environ.get('SID_PM_LIB') or os.path.join(_HERE, 'libsid_pm.so')   # SID_PM_LIB: A/B builds
 
 HES_NORM = 1
 HES_SMTH = 2

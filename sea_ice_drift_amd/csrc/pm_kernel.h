@@ -57,7 +57,8 @@ __host__ __device__ inline LdsLayout lds_layout(int wh, int ww, int s, int K)
 }
 
 // ---- MFMA kernel (pm_kernel_mfma.hip) ----
-constexpr int kMiscMfmaBytes = 2048;
+constexpr int kMiscMfmaBytes = 2816;
+constexpr int kBandRowsPad = 3;     // zero rows below the window: the sweep steps past it without clamping
 constexpr int kQueueCap = 192;       // arg-max candidates waiting for exact evaluation (16 B each)
 
 struct MfmaLdsLayout {
@@ -80,7 +81,7 @@ __host__ __device__ inline MfmaLdsLayout mfma_lds_layout(int wh, int ww, int s)
     L.wpitch = 16 * ntx + 68;                       // a window fragment reads 5 dwords from (x0+15+48) & ~3
     if (L.wpitch < round_up(ww, 4)) L.wpitch = round_up(ww, 4);
     L.win_off = kMiscMfmaBytes;
-    L.sii_off = round_up(L.win_off + wh * L.wpitch, 16);
+    L.sii_off = round_up(L.win_off + (wh + kBandRowsPad) * L.wpitch, 16);
     L.u_off = round_up(L.sii_off + rh * rw * 4, 16);
     L.arow = s <= 48 ? 768 : 1024;                  // columns >= 48 of a template row are zero unless s = 49
     // rotated template samples stay within hypot(tc, tc) of the centre, tc = int(s/2)+1 (pmlib.py:105)
@@ -90,7 +91,7 @@ __host__ __device__ inline MfmaLdsLayout mfma_lds_layout(int wh, int ww, int s)
     L.pradius = r + 1;
     L.pdim = 2 * L.pradius + 2;
     L.ppitch = round_up(L.pdim, 4);
-    L.patch_off = L.u_off + round_up((s + 1) * L.arow, 16);       // + one all-zero row
+    L.patch_off = L.u_off + round_up((s + 1) * L.arow + 16, 16);  // + one all-zero row + 16 scratch bytes
     L.queue_off = round_up(L.patch_off + L.pdim * L.ppitch, 16);
     L.trow_bytes = 4 * (s + 32) * 16;
     int u = rh * ww * 4;                                          // column sums

@@ -38,6 +38,7 @@ typedef int v4i __attribute__((ext_vector_type(4)));
 constexpr int kBlockM = 256;          // threads per grid point in this kernel: 4 wavefronts
 constexpr int kWavesM = kBlockM / 64;
 constexpr int kBand = 4;             // output rows per sweep work item
+constexpr int kOccM = 3;             // wavefronts per SIMD the register allocation must allow
 constexpr int kSlots = 16;           // MFMA M: 15 angles + ones
 constexpr int kAnglesPerGroup = 15;
 constexpr float kMargin = 1e-5f;     // pre-filter margin (see header)
@@ -53,12 +54,34 @@ struct MiscM {                       // LDS offset 0, kMiscMfmaBytes reserved
     u32 qcount;                      // candidate queue fill
     int pad_;
     int isT[kSlots], isTT[kSlots];   // integer template sums of the current group
+    double rot[kSlots][4];           // cos, sin, tcT0, tcT1 of the current group's angles
     double rTd[kMaxAngles];          // 1/sqrt(dT) per angle
     double sTd[kMaxAngles];          // sum t' per angle
     float rTf[kMaxAngles];
     int constT[kMaxAngles];
 };
-static_assert(sizeof(MiscM) <= kMiscMfmaBytes, "misc header too large");
+
+// Per-point geometry, written once by thread 0 and read by every phase (the phases are separate
+// non-inlined functions so that each gets its own register allocation; their shared state is here).
+struct Geo {
+    int wh, ww, rh, rw, npos, wpitch, arow, s, K;
+    int win_off, sii_off, u_off, patch_off, ppitch, pdim, pradius, queue_off, trow_bytes;
+    int pr0, pc0;                    // patch origin on image 1
+    int pad_;
+    long long r0, c0;                // window origin on image 2
+    double c1, r1, nd;
+};
+constexpr int kGeoOff = 2432;
+static_assert(sizeof(MiscM) <= kGeoOff, "misc header too large");
+static_assert(kGeoOff + sizeof(Geo) <= kMiscMfmaBytes, "geometry block does not fit the LDS header");
+
+#define SID_PHASE_LOCALS                                                                        \
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];                         \
+    [[maybe_unused]] MiscM *m = reinterpret_cast<MiscM *>(smem);                                 \
+    [[maybe_unused]] const Geo &G = *reinterpret_cast<const Geo *>(smem + kGeoOff);              \
+    [[maybe_unused]] const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;                \
+    [[maybe_unused]] const int n_l = lane & 15, q_l = lane >> 4
+
 
 // ---- wavefront reductions on the VALU (DPP row shifts + row broadcasts, gfx9 encoding): the
 // __shfl_* forms go through the LDS crossbar (~100 cycles per step) and were the slowest part of
@@ -112,8 +135,6 @@ __device__ __forceinline__ double wave_sum_dpp_d(double v) {
 }
 
 // ---- small block utilities (same semantics as in pm_kernel.hip) ----
-__device__ __forceinline__ double wave_sum_d(double v) { for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o); return v; }
-__device__ __forceinline__ int wave_sum_i(int v) { for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o); return v; }
 
 __device__ __forceinline__ double block_sum(double v, MiscM *m) {
     v = wave_sum_dpp_d(v);
@@ -204,147 +225,6 @@ __device__ __forceinline__ float std_from_sums(double sx, double sxx, int n) {
     return sqrtf((float)var);
 }
 
-__device__ __forceinline__ float grad1(const float *f, int stride, int k, int n) {
-    if (k == 0) return f[stride] - f[0];
-    if (k == n - 1) return f[(n - 1) * stride] - f[(n - 2) * stride];
-    return (f[(k + 1) * stride] - f[(k - 1) * stride]) * 0.5f;
-}
-__device__ __forceinline__ float grad2(const float *f, int stride, int k, int n) {
-    if (k == 0) return grad1(f, stride, 1, n) - grad1(f, stride, 0, n);
-    if (k == n - 1) return grad1(f, stride, n - 1, n) - grad1(f, stride, n - 2, n);
-    return (grad1(f, stride, k + 1, n) - grad1(f, stride, k - 1, n)) * 0.5f;
-}
-
-// One rotated-template sample (reference pmlib.py:105-113; scipy order-0 arithmetic), read from the
-// LDS copy of the image-1 neighbourhood.  Returns the uint8 pixel (0 outside the image).
-struct Patch { const uint8_t *p; int r0, c0; int pitch; };
-
-__device__ __forceinline__ uint8_t sample_template(const PMArgs &A, const Patch &P, const double *rot4,
-                                                   double c1, double r1, int i, int j)
-{
-    const double cosa = rot4[0], sina = rot4[1];
-    const double off0 = r1 - rot4[2], off1 = c1 - rot4[3];
-    double rr = 0.0 + (double)i * cosa;
-    rr = rr + (double)j * sina;
-    rr = rr + off0;
-    double cc = 0.0 + (double)i * (-sina);
-    cc = cc + (double)j * cosa;
-    cc = cc + off1;
-    uint8_t v = 0;
-    if (rr >= 0.0 && rr <= (double)(A.rows1 - 1) && cc >= 0.0 && cc <= (double)(A.cols1 - 1)) {
-        const int ri = (int)floor(rr + 0.5), ci = (int)floor(cc + 0.5);
-        v = P.p[(ri - P.r0) * P.pitch + (ci - P.c0)];
-    }
-    return v;
-}
-
-// Window fragment for one MFMA: lane (n = l&15, g = l>>4) gets bytes W'[row][x0+n+16g .. +15].
-// `p` points at the lane's dword-aligned start, `sh` = byte misalignment (0..3).
-__device__ __forceinline__ v4i load_bfrag(const uint8_t *p, u32 sh)
-{
-    const u32 *q = reinterpret_cast<const u32 *>(p);
-    const u32 r0 = q[0], r1 = q[1], r2 = q[2], r3 = q[3], r4 = q[4];
-    v4i b;
-    b[0] = (int)__builtin_amdgcn_alignbyte(r1, r0, sh);
-    b[1] = (int)__builtin_amdgcn_alignbyte(r2, r1, sh);
-    b[2] = (int)__builtin_amdgcn_alignbyte(r3, r2, sh);
-    b[3] = (int)__builtin_amdgcn_alignbyte(r4, r3, sh);
-    return b;
-}
-
-// One sweep work item: 8 output rows x 16 placements x 16 template slots.
-// Window row rho = y0 + step feeds output row y0 + t through template row i = step - t, whose
-// fragment sits in ring slot (i & 7).  S > 0: template side known at compile time - the whole
-// schedule is static (no branch, exactly 8*S MFMAs).  S == 0: runtime side; the ring holds zero
-// fragments for i outside [0, s) so the 8 MFMAs of a step are unconditional.
-template <int S>
-__device__ __forceinline__ void sweep_item(v4i (&acc)[kBand], const uint8_t *abase, int arow, bool zero_a,
-                                           const uint8_t *bbase, int wpitch, int y0, int wh, int s, u32 sh)
-{
-    // lanes of k-group 3 (columns 48..63) hold an all-zero template fragment unless s = 49
-    auto load_a = [&](int i) {
-        v4i a = *reinterpret_cast<const v4i *>(abase + i * arow);
-        if (zero_a) a = v4i{0, 0, 0, 0};
-        return a;
-    };
-#pragma unroll
-    for (int t = 0; t < kBand; ++t) acc[t] = v4i{0, 0, 0, 0};
-    v4i ring[kBand];
-#pragma unroll
-    for (int t = 0; t < kBand; ++t) ring[t] = v4i{0, 0, 0, 0};
-    if (S > 0) {
-        constexpr int NS = kBand + (S > 0 ? S : 1) - 1;
-        // Software pipeline of depth 2, interleaved with the MFMAs of the current step (a single
-        // wavefront issues in order: anything not placed between two MFMAs adds to the step time):
-        //   step k:  8 MFMAs(k)  ||  finish operands of k+1 (alignbyte x4, zeroing x4)  ||  issue LDS reads of k+2
-        struct Raw { u32 r[5]; };
-        auto issue_b = [&](int step) {
-            int row = y0 + step;
-            row = row < wh - 1 ? row : wh - 1;                    // last band: rows past the window are unused
-            const u32 *q = reinterpret_cast<const u32 *>(bbase + row * wpitch);
-            Raw w;
-            w.r[0] = q[0]; w.r[1] = q[1]; w.r[2] = q[2]; w.r[3] = q[3]; w.r[4] = q[4];
-            return w;
-        };
-        auto finish_b = [&](const Raw &w) {
-            v4i b;
-            b[0] = (int)__builtin_amdgcn_alignbyte(w.r[1], w.r[0], sh);
-            b[1] = (int)__builtin_amdgcn_alignbyte(w.r[2], w.r[1], sh);
-            b[2] = (int)__builtin_amdgcn_alignbyte(w.r[3], w.r[2], sh);
-            b[3] = (int)__builtin_amdgcn_alignbyte(w.r[4], w.r[3], sh);
-            return b;
-        };
-        auto finish_a = [&](v4i a) { if (zero_a) a = v4i{0, 0, 0, 0}; return a; };
-        // prologue: operands of step 0 ready, raw reads of step 1 in flight
-        ring[0] = finish_a(*reinterpret_cast<const v4i *>(abase));
-        v4i b_cur = finish_b(issue_b(0));
-        v4i a_raw = *reinterpret_cast<const v4i *>(abase + (1 < S ? 1 : 0) * arow);
-        Raw b_raw = issue_b(1 < NS ? 1 : 0);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int step = 0; step < NS; ++step) {
-            // operands of step+1 (their reads were issued during step-1)
-            v4i a_fin = finish_a(a_raw);
-            v4i b_nxt = finish_b(b_raw);
-            // reads of step+2
-            if (step + 2 < NS) {
-                if (step + 2 < S) a_raw = *reinterpret_cast<const v4i *>(abase + (step + 2) * arow);
-                b_raw = issue_b(step + 2);
-            }
-#pragma unroll
-            for (int t = 0; t < kBand; ++t) {
-                const int i = step - t;
-                if (i >= 0 && i < S)
-                    acc[t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(ring[i & (kBand - 1)], b_cur, acc[t], 0, 0, 0);
-            }
-            // interleave: one MFMA, then up to three of the other instructions
-#pragma unroll
-            for (int g = 0; g < kBand; ++g) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
-                __builtin_amdgcn_sched_group_barrier(0x106, 3, 0);   // VALU | SALU | DS read
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            if (step + 1 < S) ring[(step + 1) & (kBand - 1)] = a_fin;
-            b_cur = b_nxt;
-        }
-    } else {
-        const int nsteps = kBand + s - 1;
-        for (int cbase = 0; cbase < nsteps; cbase += kBand) {
-#pragma unroll
-            for (int u = 0; u < kBand; ++u) {
-                const int step = cbase + u;
-                const int ia = step < s ? step : s;               // row s of the fragment table is all zero
-                ring[u] = load_a(ia);
-                int row = y0 + step;
-                row = row < wh - 1 ? row : wh - 1;
-                const v4i b = load_bfrag(bbase + row * wpitch, sh);
-#pragma unroll
-                for (int t = 0; t < kBand; ++t)
-                    acc[t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(ring[(u - t) & (kBand - 1)], b, acc[t], 0, 0, 0);
-            }
-        }
-    }
-}
 
 // The spec's normalisation in IEEE double -> float32 (shared by candidates and the winner's matrix).
 __device__ __forceinline__ float exact_ncc(double numer, double dI, double rTd, bool constT, bool lowvar)
@@ -358,152 +238,696 @@ __device__ __forceinline__ float exact_ncc(double numer, double dI, double rTd, 
     return aq < 1.0 ? (float)q : (aq < 1.125 ? (q > 0.0 ? 1.0f : -1.0f) : 0.0f);
 }
 
+__device__ __forceinline__ float exact_from_sums(int p, int swp, u32 siiv, double nd, double sT, double rTd, bool cT)
+{
+    const double swd = (double)swp, siid = (double)siiv;
+    const double dI = nd * siid - swd * swd;                           // exact
+    const double s2 = siid + 256.0 * swd + 16384.0 * nd;               // S_II in the uint8 domain
+    const bool lowvar = (2.0 * dI <= nd) && (dI * 8388608.0 <= 10.0 * nd * s2);
+    const double numer = nd * (double)p - swd * sT;                    // exact
+    return exact_ncc(numer, dI, rTd, cT, lowvar);
+}
+
 struct Score { float lmax, bestv; int bestkey; };
+
+__device__ __forceinline__ void take_better(Score &sc, float rv, int key)
+{
+    if (rv > sc.bestv || (rv == sc.bestv && key < sc.bestkey)) { sc.bestv = rv; sc.bestkey = key; }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Phase 0a: search window of image 2 -> LDS, re-centred to int8 (w ^ 0x80), zero beyond the window.
+// Loads are issued four dwords deep before any is consumed (HBM/L2 latency overlaps).
+// ---------------------------------------------------------------------------------------------
+__device__ __noinline__ void ph_window(const uint8_t *img2, long long rows2, long long cols2, long long stride2)
+{
+    SID_PHASE_LOCALS;
+    uint8_t *win = smem + G.win_off;
+    const int wpitch = G.wpitch, ww = G.ww, wh = G.wh;
+    const long long r0 = G.r0, c0 = G.c0;
+    const int dw_per_row = wpitch / 4, ndw = (wh + kBand - 1) * dw_per_row;    // + kBand-1 zero rows below
+    const uintptr_t last_dw = (reinterpret_cast<uintptr_t>(img2 + (rows2 - 1) * stride2 + cols2) - 1) & ~(uintptr_t)3;
+    for (int base = 0; base < ndw; base += 4 * kBlockM) {
+        u32 lo[4], hi[4], shv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int idx = base + u * kBlockM + tid;
+            const int idc = idx < ndw ? idx : 0;
+            int row = idc / dw_per_row;
+            const int dq = idc - row * dw_per_row;
+            row = row < wh ? row : wh - 1;                             // clamp so that the loads are always legal
+            const int dqc = 4 * dq < ww ? dq : 0;
+            const uint8_t *gp = img2 + (r0 + row) * stride2 + c0 + 4 * dqc;
+            const uintptr_t ga = reinterpret_cast<uintptr_t>(gp) & ~(uintptr_t)3;
+            const uintptr_t gb = ga + 4 <= last_dw ? ga + 4 : last_dw;
+            shv[u] = (u32)(reinterpret_cast<uintptr_t>(gp) & 3);
+            lo[u] = *reinterpret_cast<const u32 *>(ga);
+            hi[u] = *reinterpret_cast<const u32 *>(gb);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int idx = base + u * kBlockM + tid;
+            if (idx < ndw) {
+                const int row = idx / dw_per_row, dq = idx - row * dw_per_row;
+                u32 v = __builtin_amdgcn_alignbyte(hi[u], lo[u], shv[u]) ^ 0x80808080u;
+                const int nvalid = row < wh ? ww - 4 * dq : 0;
+                if (nvalid < 4) v = nvalid > 0 ? (v & ((1u << (8 * nvalid)) - 1u)) : 0u;
+                reinterpret_cast<u32 *>(win + row * wpitch)[dq] = v;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Phase 1: S_II' = box sums of w'^2 (running sums down the columns, then along the rows).
+// ---------------------------------------------------------------------------------------------
+__device__ __noinline__ void ph_sums()
+{
+    SID_PHASE_LOCALS;
+    const uint8_t *win = smem + G.win_off;
+    u32 *sii = reinterpret_cast<u32 *>(smem + G.sii_off);
+    u32 *colsum = reinterpret_cast<u32 *>(smem + G.u_off);
+    const int s = G.s, ww = G.ww, rh = G.rh, rw = G.rw, wpitch = G.wpitch;
+    for (int x = tid; x < ww; x += kBlockM) {
+        const int8_t *col = reinterpret_cast<const int8_t *>(win) + x;
+        int c = 0;
+#pragma unroll 8
+        for (int i = 0; i < s; ++i) { const int v = col[i * wpitch]; c += v * v; }
+        colsum[x] = (u32)c;
+#pragma unroll 8
+        for (int y = 1; y < rh; ++y) {
+            const int vo = col[(y - 1) * wpitch], vn = col[(y + s - 1) * wpitch];
+            c += vn * vn - vo * vo;
+            colsum[y * ww + x] = (u32)c;
+        }
+    }
+    __syncthreads();
+    for (int y = tid; y < rh; y += kBlockM) {
+        const u32 *cr = colsum + y * ww;
+        u32 acc = 0;
+#pragma unroll 8
+        for (int j = 0; j < s; ++j) acc += cr[j];
+        sii[y * rw] = acc;
+#pragma unroll 8
+        for (int x = 1; x < rw; ++x) {
+            acc += cr[x + s - 1] - cr[x - 1];
+            sii[y * rw + x] = acc;
+        }
+    }
+    __syncthreads();
+}
+
+// ---------------------------------------------------------------------------------------------
+// Phase 0b: neighbourhood of the template centre on image 1 -> LDS patch (8 byte loads in flight).
+// ---------------------------------------------------------------------------------------------
+__device__ __noinline__ void ph_patch(const uint8_t *img1, long long rows1, long long cols1, long long stride1)
+{
+    SID_PHASE_LOCALS;
+    uint8_t *patch = smem + G.patch_off;
+    const int pdim = G.pdim, ppitch = G.ppitch, np = pdim * pdim;
+    const long long pr0 = G.pr0, pc0 = G.pc0;
+    for (int base = 0; base < np; base += 8 * kBlockM) {
+        uint8_t pv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int idx = base + u * kBlockM + tid;
+            const int idc = idx < np ? idx : 0;
+            const int pr = idc / pdim, pc = idc - pr * pdim;
+            long long gr = pr0 + pr, gc = pc0 + pc;
+            gr = gr < 0 ? 0 : (gr > rows1 - 1 ? rows1 - 1 : gr);       // clamped rows/cols are never sampled
+            gc = gc < 0 ? 0 : (gc > cols1 - 1 ? cols1 - 1 : gc);
+            pv[u] = img1[gr * stride1 + gc];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int idx = base + u * kBlockM + tid;
+            if (idx < np) { const int pr = idx / pdim, pc = idx - pr * pdim; patch[pr * ppitch + pc] = pv[u]; }
+        }
+    }
+}
+
+// Rotated-template sampling (reference pmlib.py:105-113; scipy order-0 arithmetic) from the LDS patch.
+// Thread -> one template column j and every ngrp-th row.  Fast pass in float32 on patch-relative
+// coordinates (one fma per coordinate and sample; branch-free so that several angles interleave);
+// whenever the rounding or the image-bounds decision could depend on the last bits (|doubt| < kGuard,
+// float error < 2.5e-5) the sample is flagged and redone afterwards with scipy's double arithmetic.
+struct SampleGeom {
+    const uint8_t *patch; int ppitch, pr0, pc0, s, ngrp, ig, j; bool act;
+    float lo_r, hi_r, lo_c, hi_c;
+    double c1, r1, rmax1, cmax1;
+};
+constexpr float kGuard = 1e-4f;
+constexpr int kRowsPerThread = 5;       // rows of one template column a thread samples per chunk
+
+__device__ __forceinline__ SampleGeom sample_geom(const Geo &G, int s, long long rows1, long long cols1, const uint8_t *patch)
+{
+    SampleGeom g;
+    g.patch = patch; g.ppitch = G.ppitch; g.pr0 = G.pr0; g.pc0 = G.pc0; g.s = s;
+    g.ngrp = kBlockM / s;
+    g.ig = (int)threadIdx.x / s; g.j = (int)threadIdx.x - g.ig * s;
+    g.act = g.ig < g.ngrp;
+    g.lo_r = (float)(-G.pr0); g.hi_r = (float)(rows1 - 1 - G.pr0);
+    g.lo_c = (float)(-G.pc0); g.hi_c = (float)(cols1 - 1 - G.pc0);
+    g.c1 = G.c1; g.r1 = G.r1; g.rmax1 = (double)(rows1 - 1); g.cmax1 = (double)(cols1 - 1);
+    return g;
+}
+
+// exact coordinates of sample (i, j) -> pixel value (0 outside image 1)
+__device__ __forceinline__ int sample_exact(const SampleGeom &g, const double *rot4, int i, int j)
+{
+    const double cosa = rot4[0], sina = rot4[1];
+    const double off0 = g.r1 - rot4[2], off1 = g.c1 - rot4[3];
+    double rr = 0.0 + (double)i * cosa;                                // NI_GeometricTransform order (matrix = transform.T)
+    rr = rr + (double)j * sina;
+    rr = rr + off0;
+    double cc = 0.0 + (double)i * (-sina);
+    cc = cc + (double)j * cosa;
+    cc = cc + off1;
+    int v = 0;
+    if (rr >= 0.0 && rr <= g.rmax1 && cc >= 0.0 && cc <= g.cmax1) {
+        const int ri = (int)floor(rr + 0.5) - g.pr0, ci = (int)floor(cc + 0.5) - g.pc0;
+        v = g.patch[ri * g.ppitch + ci];
+    }
+    return v;
+}
+
+// Fast pass for rows ig + (k0..k0+4)*ngrp of column j of one angle.  Returns the doubt bits; sure
+// samples are stored and summed, doubtful ones are left to the caller.
+template <typename Store>
+__device__ __forceinline__ u32 sample_fast5(const SampleGeom &g, const double *rot4, bool angle_ok, int k0,
+                                            int &st, int &stt, int &sawzero, Store store)
+{
+    const double cosa = rot4[0], sina = rot4[1];
+    const float cf = (float)cosa, sf = (float)sina;
+    const float orf = (float)((g.r1 - rot4[2]) - (double)g.pr0), ocf = (float)((g.c1 - rot4[3]) - (double)g.pc0);
+    const float fj = (float)g.j, fig = (float)g.ig;
+    const float base_r = fmaf(fig, cf, fmaf(fj, sf, orf)), step_r = (float)g.ngrp * cf;
+    const float base_c = fmaf(fig, -sf, fmaf(fj, cf, ocf)), step_c = -(float)g.ngrp * sf;
+    u32 doubt = 0;
+#pragma unroll
+    for (int u = 0; u < kRowsPerThread; ++u) {
+        const int k = k0 + u;
+        const int i = g.ig + k * g.ngrp;
+        const bool valid = angle_ok && g.act && i < g.s;
+        const float fk = (float)k;
+        const float rrf = fmaf(fk, step_r, base_r);
+        const float ccf = fmaf(fk, step_c, base_c);
+        const float tr = rrf + 0.5f, tc_ = ccf + 0.5f;
+        const float flr = floorf(tr), flc = floorf(tc_);
+        const float frr = tr - flr, frc = tc_ - flc;
+        const bool in_f = rrf >= g.lo_r + kGuard && rrf <= g.hi_r - kGuard && ccf >= g.lo_c + kGuard && ccf <= g.hi_c - kGuard;
+        const bool out_f = rrf < g.lo_r - kGuard || rrf > g.hi_r + kGuard || ccf < g.lo_c - kGuard || ccf > g.hi_c + kGuard;
+        const bool sure = (in_f || out_f) && frr > kGuard && frr < 1.0f - kGuard && frc > kGuard && frc < 1.0f - kGuard;
+        const int ri = in_f ? (int)flr : 0, ci = in_f ? (int)flc : 0; // in-image samples always lie inside the patch
+        int v = g.patch[ri * g.ppitch + ci];
+        v = in_f ? v : 0;
+        const bool take = valid && sure;
+        doubt |= ((valid && !sure) ? 1u : 0u) << u;
+        // branch-free: a rejected sample is written to a scratch byte, so that all the chains of a
+        // chunk (and of the angles in flight) sit in one basic block and overlap
+        sawzero |= (take && v == 0) ? 1 : 0;
+        store(i, g.j, v, take);
+        const int sv = take ? v - 128 : 0;
+        st += sv; stt += sv * sv;
+    }
+    return doubt;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Phase 0c: operands of one group of <= 15 angles.  afrag[i][lane = g*16 + slot][16 bytes], byte jj
+// <-> column c = 16 g + jj; slot 15 is the all-ones template; row s is all zero.
+// ---------------------------------------------------------------------------------------------
+template <int S>
+__device__ __noinline__ void ph_templates(const double *rot, int a0, int Kg, long long rows1, long long cols1,
+                                          uint8_t *dbg_templates, long long *dbg_cycles)
+{
+    SID_PHASE_LOCALS;
+    uint8_t *afrag = smem + G.u_off;
+    const uint8_t *patch = smem + G.patch_off;
+    const int s = S > 0 ? S : G.s, arow = G.arow;                      // compile-time s: divisions by s become multiplies
+    const double nd = G.nd;
+    if (tid < 4 * Kg) (&m->rot[0][0])[tid] = rot[4 * a0 + tid];        // one global round trip for the whole group
+    for (int idx = tid; idx < (s + 1) * arow / 4; idx += kBlockM) reinterpret_cast<u32 *>(afrag)[idx] = 0;
+    if (tid < kSlots) { m->isT[tid] = 0; m->isTT[tid] = 0; }
+    __syncthreads();                                                   // also: patch complete
+    if (dbg_cycles && tid == 0) dbg_cycles[8] = (long long)clock64();
+    const SampleGeom g = sample_geom(G, s, rows1, cols1, patch);
+#ifdef SID_ABLATE_SAMPLING
+    for (int idx = tid; idx < s * arow; idx += kBlockM) afrag[idx] = (uint8_t)(idx * 37 + 11);
+    if (tid < Kg) { m->isT[tid] = 1000 + tid; m->isTT[tid] = 9000000 + tid; }
+    Kg = Kg > 0 ? Kg : 0;
+#define SID_SKIP_SAMPLING_LOOP 1
+#endif
+    const int dump = (s + 1) * arow;                                   // 16 scratch bytes behind the operand table
+    int sawzero = 0;
+    u32 anydoubt = 0;
+#ifndef SID_SKIP_SAMPLING_LOOP
+    for (int k0 = 0; k0 * g.ngrp < s; k0 += kRowsPerThread) {
+        for (int a = 0; a < Kg; a += 3) {                              // three angles in flight: their chains interleave
+            int st[3] = {0, 0, 0}, stt[3] = {0, 0, 0};
+            u32 db[3];
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const int aa = a + q < Kg ? a + q : Kg - 1;
+                db[q] = sample_fast5(g, m->rot[aa], a + q < Kg, k0, st[q], stt[q], sawzero, [&](int i, int j, int v, bool take) {
+                    const int off = i * arow + ((j >> 4) * 16 + aa) * 16 + (j & 15);
+                    afrag[take ? off : dump] = (uint8_t)(v ^ 0x80); });
+            }
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                if (a + q < Kg) {                                      // wavefront-uniform
+                    const int ws = wave_sum_dpp(st[q]), wss = wave_sum_dpp(stt[q]);
+                    if (lane == 0) { atomicAdd(&m->isT[a + q], ws); atomicAdd(&m->isTT[a + q], wss); }
+                }
+                anydoubt |= db[q];
+                if (db[q]) {                                           // rare: redo the doubtful samples exactly
+                    for (int u = 0; u < kRowsPerThread; ++u) {
+                        if ((db[q] >> u) & 1u) {
+                            const int i = g.ig + (k0 + u) * g.ngrp, aa = a + q;
+                            const int v = sample_exact(g, m->rot[aa], i, g.j);
+                            sawzero |= (v == 0) ? 1 : 0;
+                            afrag[i * arow + ((g.j >> 4) * 16 + aa) * 16 + (g.j & 15)] = (uint8_t)(v ^ 0x80);
+                            atomicAdd(&m->isT[aa], v - 128); atomicAdd(&m->isTT[aa], (v - 128) * (v - 128));
+                        }
+                    }
+                }
+            }
+        }
+    }
+#else
+    (void)anydoubt; (void)dump;
+#endif
+    if (dbg_cycles && tid == 0) dbg_cycles[15] = (long long)clock64();
+    for (int idx = tid; idx < s * s; idx += kBlockM) {                  // slot 15: all-ones template
+        const int i = idx / s, j = idx - i * s;
+        afrag[i * arow + ((j >> 4) * 16 + 15) * 16 + (j & 15)] = 1;
+    }
+    if (sawzero) m->zero_flag = 1;
+    __syncthreads();
+    if (dbg_cycles && tid == 0) dbg_cycles[9] = (long long)clock64();
+    if (dbg_templates) {
+        for (int idx = tid; idx < Kg * s * s; idx += kBlockM) {
+            const int a = idx / (s * s), rem = idx - a * s * s;
+            const int i = rem / s, j = rem - i * s;
+            dbg_templates[(a0 + a) * s * s + rem] = afrag[i * arow + ((j >> 4) * 16 + a) * 16 + (j & 15)] ^ 0x80;
+        }
+    }
+    if (tid < Kg) {                                                    // per-angle terms (signed domain)
+        const double st = (double)m->isT[tid], stt = (double)m->isTT[tid];
+        const double dT = nd * stt - st * st;                          // exact
+        const double rT = 1.0 / sqrt(dT);
+        m->sTd[a0 + tid] = st;
+        m->constT[a0 + tid] = dT == 0.0 ? 1 : 0;
+        m->rTd[a0 + tid] = rT;
+        m->rTf[a0 + tid] = dT == 0.0 ? NAN : (float)rT;               // NaN estimate => always a candidate
+    }
+    __syncthreads();
+}
+
+// ---------------------------------------------------------------------------------------------
+// One sweep work item: kBand output rows x 16 placements x 16 template slots.
+// Window row rho = y0 + step feeds output row y0 + t through template row i = step - t, whose
+// fragment sits in ring slot (i & (kBand-1)).  S > 0: template side known at compile time - the whole
+// schedule is static (no branch, exactly kBand*S MFMAs).  S == 0: runtime side; the ring holds zero
+// fragments for i outside [0, s) so the MFMAs of a step are unconditional.
+// Lane (n = l&15, g = l>>4): B fragment = bytes W'[row][x0+n+16g .. +15], built from 5 dwords read at
+// the lane's dword-aligned address + v_alignbyte_b32; A fragment = 16 bytes of the operand table
+// (lanes of k-group 3 read the all-zero row when s <= 48: their per-lane row stride is 0).
+// ---------------------------------------------------------------------------------------------
+struct Raw5 { u32 r[5]; };
+__device__ __forceinline__ Raw5 read_raw(const uint8_t *p)
+{
+    const u32 *q = reinterpret_cast<const u32 *>(p);
+    Raw5 w;
+    w.r[0] = q[0]; w.r[1] = q[1]; w.r[2] = q[2]; w.r[3] = q[3]; w.r[4] = q[4];
+    return w;
+}
+__device__ __forceinline__ v4i align_raw(const Raw5 &w, u32 sh)
+{
+    v4i b;
+    b[0] = (int)__builtin_amdgcn_alignbyte(w.r[1], w.r[0], sh);
+    b[1] = (int)__builtin_amdgcn_alignbyte(w.r[2], w.r[1], sh);
+    b[2] = (int)__builtin_amdgcn_alignbyte(w.r[3], w.r[2], sh);
+    b[3] = (int)__builtin_amdgcn_alignbyte(w.r[4], w.r[3], sh);
+    return b;
+}
+
+template <int S>
+__device__ __forceinline__ void sweep_item(v4i (&acc)[kBand], const uint8_t *ap, int arow_l, const uint8_t *bp,
+                                           int wpitch, int s, u32 sh)
+{
+#pragma unroll
+    for (int t = 0; t < kBand; ++t) acc[t] = v4i{0, 0, 0, 0};
+    v4i ring[kBand];
+#pragma unroll
+    for (int t = 0; t < kBand; ++t) ring[t] = v4i{0, 0, 0, 0};
+    if (S > 0) {
+        constexpr int NS = kBand + (S > 0 ? S : 1) - 1;
+        // Software pipeline of depth 2, interleaved with the MFMAs of the current step (a single
+        // wavefront issues in order: anything not placed between two MFMAs adds to the step time):
+        //   step k:  MFMAs(k)  ||  finish the window fragment of k+1 (alignbyte x4)  ||  issue LDS reads of k+2
+        ring[0] = *reinterpret_cast<const v4i *>(ap);
+        v4i b_cur = align_raw(read_raw(bp), sh);
+        v4i a_nxt = *reinterpret_cast<const v4i *>(ap + arow_l);
+        Raw5 b_raw = read_raw(bp + wpitch);
+        ap += 2 * arow_l; bp += 2 * wpitch;
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int step = 0; step < NS; ++step) {
+            const v4i a_fin = a_nxt;
+            const v4i b_nxt = align_raw(b_raw, sh);                  // reads were issued during step-1
+            if (step + 2 < NS) {                                     // reads of step+2
+                if (step + 2 < S) a_nxt = *reinterpret_cast<const v4i *>(ap);
+                b_raw = read_raw(bp);
+                ap += arow_l; bp += wpitch;
+            }
+#pragma unroll
+            for (int t = 0; t < kBand; ++t) {
+                const int i = step - t;
+                if (i >= 0 && i < S)
+                    acc[t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(ring[i & (kBand - 1)], b_cur, acc[t], 0, 0, 0);
+            }
+#pragma unroll
+            for (int g = 0; g < kBand; ++g) {                        // one MFMA, then up to four of the others
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x106, 4, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (step + 1 < S) ring[(step + 1) & (kBand - 1)] = a_fin;
+            b_cur = b_nxt;
+        }
+    } else {
+        const int nsteps = kBand + s - 1;
+        for (int cbase = 0; cbase < nsteps; cbase += kBand) {
+#pragma unroll
+            for (int u = 0; u < kBand; ++u) {
+                const int step = cbase + u;
+                const int ia = step < s ? step : s;                   // row s of the operand table is all zero
+                ring[u] = *reinterpret_cast<const v4i *>(ap + ia * arow_l);
+                const v4i b = align_raw(read_raw(bp + step * wpitch), sh);
+#pragma unroll
+                for (int t = 0; t < kBand; ++t)
+                    acc[t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(ring[(u - t) & (kBand - 1)], b, acc[t], 0, 0, 0);
+            }
+        }
+    }
+}
 
 // Cold path: the candidate queue is full (only with massive exact ties).  Out of line so that its
 // double-precision sqrt/divide sequence does not inflate the register allocation of the sweep.
-__device__ __noinline__ Score overflow_eval(Score sc, int p, int swp, u32 siiv, int key, int s, double sT, double rTd, int cT)
+__device__ __noinline__ Score overflow_eval(Score sc, int p, int swp, u32 siiv, int key, double nd, double sT, double rTd, int cT)
 {
-    const double nd = (double)(s * s);
-    const double swd = (double)swp, siid = (double)siiv;
-    const double dI = nd * siid - swd * swd;
-    const double s2 = siid + 256.0 * swd + 16384.0 * nd;
-    const bool lowvar = (2.0 * dI <= nd) && (dI * 8388608.0 <= 10.0 * nd * s2);
-    const double numer = nd * (double)p - swd * sT;
-    const float rv = exact_ncc(numer, dI, rTd, cT != 0, lowvar);
-    if (rv > sc.bestv || (rv == sc.bestv && key < sc.bestkey)) { sc.bestv = rv; sc.bestkey = key; }
+    take_better(sc, exact_from_sums(p, swp, siiv, nd, sT, rTd, cT != 0), key);
     return sc;
 }
 
-// P2 of the kernel for one group of <= 15 angles: every wavefront takes sweep work items (8 output
-// rows x 16 placements), runs the MFMA schedule and scores the 8 x 16 x 15 results.
+// ---------------------------------------------------------------------------------------------
+// Phase 2: angle-major sweep of one group.  Every wavefront takes work items wv, wv+W, ... and scores
+// the kBand x 16 x 15 results of each item:
+//   pass A (always, branch-free): float32 estimate of this lane's kBand x 4 values and their maximum;
+//   pass B (only if the item can hold an arg-max candidate: its maximum is within kMargin of the
+//   running maximum, or an estimate is NaN = degenerate window/template): estimates within kMargin
+//   of the running maximum are queued for exact evaluation.  |estimate - value| <= 4e-7, so the
+//   true arg-max is always queued.
+// ---------------------------------------------------------------------------------------------
 template <int S>
-__device__ __forceinline__ Score sweep_group(Score sc, int afrag_off, int win_off, int sii_off, int queue_off,
-                                          int arow, int wpitch, int wh, int rh, int rw, int s, int Kg, int a0,
-                                          long long *dbg_cycles)
+__device__ __noinline__ Score ph_sweep(Score sc, int a0, int Kg, long long *dbg_cycles)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    MiscM *m = reinterpret_cast<MiscM *>(smem);
-    const uint8_t *afrag = smem + afrag_off;
-    const uint8_t *win = smem + win_off;
-    const u32 *sii = reinterpret_cast<const u32 *>(smem + sii_off);
-    uint4 *queue = reinterpret_cast<uint4 *>(smem + queue_off);
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int n_l = lane & 15, q_l = lane >> 4;
+    SID_PHASE_LOCALS;
+    const uint8_t *afrag = smem + G.u_off;
+    const uint8_t *win = smem + G.win_off;
+    const u32 *sii = reinterpret_cast<const u32 *>(smem + G.sii_off);
+    uint4 *queue = reinterpret_cast<uint4 *>(smem + G.queue_off);
+    const int s = S > 0 ? S : G.s, rh = G.rh, rw = G.rw, wpitch = G.wpitch, arow = G.arow;
+    const double nd = G.nd;
     const bool zero_a = (s <= 48) && q_l == 3;
-    const int alane = zero_a ? lane - 16 : lane;
-    const double nd = (double)(s * s);
-    float lmax = sc.lmax, bestv = sc.bestv;
-    int bestkey = sc.bestkey;
+    // lanes of k-group 3 sit on the zero row with stride 0
+    const uint8_t *abase = zero_a ? afrag + s * arow : afrag + lane * 16;
+    const int arow_l = zero_a ? 0 : arow;
+
+    double sT4[4];
+    float rT4[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int a = 4 * q_l + r;
+        sT4[r] = a < Kg ? m->sTd[a0 + a] : 0.0;
+        rT4[r] = a < Kg ? m->rTf[a0 + a] : 0.0f;
+    }
+    const u32 livebits = (4 * q_l + 0 < Kg ? 1u : 0u) | (4 * q_l + 1 < Kg ? 2u : 0u) |
+                         (4 * q_l + 2 < Kg ? 4u : 0u) | (4 * q_l + 3 < Kg ? 8u : 0u);
 #define STAMP2(k) do { if (dbg_cycles && tid == 0) dbg_cycles[k] = (long long)clock64(); } while (0)
-        // this lane's four template slots (rows 4 q + r of the MFMA result)
-        double sT4[4];
-        float rT4[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int a = 4 * q_l + r;
-            sT4[r] = a < Kg ? m->sTd[a0 + a] : 0.0;
-            rT4[r] = a < Kg ? m->rTf[a0 + a] : 0.0f;                // unused slots: estimate 0 * x, masked below
+
+    const int nbands = (rh + kBand - 1) / kBand, ntx = (rw + 15) / 16;
+    for (int item = wv; item < nbands * ntx; item += kWavesM) {
+        const int band = item / ntx, xt = item - band * ntx;
+        const int y0 = band * kBand, x0 = xt * 16;
+        const u32 sbyte = (u32)(x0 + n_l + 16 * q_l);
+        const u32 sh = sbyte & 3u;
+        if (item == wv) STAMP2(10);
+        v4i acc[kBand];
+        sweep_item<S>(acc, abase, arow_l, win + y0 * wpitch + (sbyte & ~3u), wpitch, s, sh);
+        if (item == wv) STAMP2(11);
+
+        {
+            const float gm = key2f(m->gmax_key);
+            sc.lmax = gm > sc.lmax ? gm : sc.lmax;
         }
-
-        // ---- P2: angle-major sweep; wave wv takes work items wv, wv+4, ... ----
-        const int nbands = (rh + kBand - 1) / kBand, ntx = (rw + 15) / 16;
-        for (int item = wv; item < nbands * ntx; item += kWavesM) {
-            const int band = item / ntx, xt = item - band * ntx;
-            const int y0 = band * kBand, x0 = xt * 16;
-            const u32 sbyte = (u32)(x0 + n_l + 16 * q_l);
-            const u32 sh = sbyte & 3u;
-            const uint8_t *bbase = win + (sbyte & ~3u);
-
-            if (item == wv) STAMP2(10);
-            v4i acc[kBand];
-            sweep_item<S>(acc, afrag + alane * 16, arow, zero_a, bbase, wpitch, y0, wh, s, sh);
-            if (item == wv) STAMP2(11);
-
-            // ---- epilogue.  Pass A (always, branch-free): float32 estimate of all 8 x 4 NCC values of
-            //      this lane and their maximum.  Pass B (only if the item can hold an arg-max candidate:
-            //      its maximum is within kMargin of the running maximum, or an estimate is NaN = degenerate
-            //      window/template): estimates within kMargin of the running maximum are queued for exact
-            //      evaluation.  |estimate - value| <= 4e-7, so the true arg-max is always queued. ----
-            {
-                const float gm = key2f(m->gmax_key);
-                lmax = gm > lmax ? gm : lmax;
-            }
-            const int x = x0 + n_l;
-            const bool xok = x < rw;
-            // operands of all 8 rows first (one LDS round trip), then straight-line arithmetic
-            int swp[kBand];
-            u32 siiv[kBand];
+        const int x = x0 + n_l;
+        const bool xok = x < rw;
+        // operands of all rows first (one LDS round trip), then straight-line arithmetic
+        int swp[kBand];
+        u32 siiv[kBand];
 #pragma unroll
-            for (int t = 0; t < kBand; ++t) {
-                swp[t] = __builtin_amdgcn_ds_bpermute((n_l + 48) << 2, acc[t][3]);   // slot 15 = sum of w'
-                const int y = y0 + t;
-                const int pos = (xok & (y < rh)) ? y * rw + x : 0;
-                siiv[t] = sii[pos];
-            }
-            const u32 livebits = (4 * q_l + 0 < Kg ? 1u : 0u) | (4 * q_l + 1 < Kg ? 2u : 0u) |
-                                 (4 * q_l + 2 < Kg ? 4u : 0u) | (4 * q_l + 3 < Kg ? 8u : 0u);
-            auto estimate_row = [&](int t, float (&e)[4]) {
-                const double swd = (double)swp[t], siid = (double)siiv[t];
-                const double dI = nd * siid - swd * swd;                  // exact
-                float rIf = __builtin_amdgcn_rsqf((float)dI);
-                rIf = (2.0 * dI <= nd) ? NAN : rIf;                       // (nearly) flat window: the exact path decides
-                const u32 lv = (xok & (y0 + t < rh)) ? livebits : 0u;
+        for (int t = 0; t < kBand; ++t) {
+            swp[t] = __builtin_amdgcn_ds_bpermute((n_l + 48) << 2, acc[t][3]);   // slot 15 = sum of w'
+            const int y = y0 + t;
+            siiv[t] = sii[(xok & (y < rh)) ? y * rw + x : 0];
+        }
+        auto estimate_row = [&](int t, float (&e)[4]) {
+            const double swd = (double)swp[t], siid = (double)siiv[t];
+            const double dI = nd * siid - swd * swd;                  // exact
+            float rIf = __builtin_amdgcn_rsqf((float)dI);
+            rIf = (2.0 * dI <= nd) ? NAN : rIf;                       // (nearly) flat window: the exact path decides
+            const u32 lv = (xok & (y0 + t < rh)) ? livebits : 0u;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const double numer = nd * (double)acc[t][r] - swd * sT4[r];   // exact
-                    const float v = ((float)numer * rIf) * rT4[r];
-                    e[r] = ((lv >> r) & 1u) ? v : -INFINITY;
-                }
-            };
-            float itemmax = -INFINITY;
-            u32 nanbits = 0;
+            for (int r = 0; r < 4; ++r) {
+                const double numer = nd * (double)acc[t][r] - swd * sT4[r];   // exact
+                const float v = ((float)numer * rIf) * rT4[r];
+                e[r] = ((lv >> r) & 1u) ? v : -INFINITY;
+            }
+        };
+        float itemmax = -INFINITY;
+        u32 nanbits = 0;
+#pragma unroll
+        for (int t = 0; t < kBand; ++t) {
+            float e[4];
+            estimate_row(t, e);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { itemmax = fmaxf(itemmax, e[r]); nanbits |= (e[r] != e[r]) ? 1u : 0u; }
+        }
+        const float wavemax = wave_max_dpp(itemmax);
+        const bool need_b = (wavemax >= sc.lmax - kMargin) || (__ballot(nanbits != 0) != 0ull);   // wavefront-uniform
+        sc.lmax = fmaxf(sc.lmax, wavemax);
+        if (need_b) {
+            const float thr = sc.lmax - kMargin;
 #pragma unroll
             for (int t = 0; t < kBand; ++t) {
                 float e[4];
                 estimate_row(t, e);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) { itemmax = fmaxf(itemmax, e[r]); nanbits |= (e[r] != e[r]) ? 1u : 0u; }
-            }
-            const bool anynan = nanbits != 0;
-            const float wavemax = wave_max_dpp(itemmax);
-            const bool need_b = (wavemax >= lmax - kMargin) || (__ballot(anynan) != 0ull);   // wavefront-uniform
-            lmax = fmaxf(lmax, wavemax);
-            if (need_b) {
-                const float thr = lmax - kMargin;
-#pragma unroll
-                for (int t = 0; t < kBand; ++t) {
-                    float e[4];
-                    estimate_row(t, e);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        if (e[r] != -INFINITY && !(e[r] < thr)) {         // live, and true for NaN
-                            const int a = 4 * q_l + r, y = y0 + t;
-                            const int key = ((a0 + a) * rh + y) * rw + x;
-                            const u32 slot = atomicAdd(&m->qcount, 1u);
-                            if (slot < (u32)kQueueCap) {
-                                queue[slot] = make_uint4((u32)acc[t][r], (u32)swp[t], siiv[t], (u32)key);
-                            } else {                                      // queue full (massive ties): cold path
-                                const Score o = overflow_eval(Score{lmax, bestv, bestkey}, acc[t][r], swp[t], siiv[t], key, s,
-                                                              sT4[r], m->rTd[a0 + a], m->constT[a0 + a]);
-                                bestv = o.bestv; bestkey = o.bestkey;
-                            }
-                        }
+                for (int r = 0; r < 4; ++r) {
+                    if (e[r] != -INFINITY && !(e[r] < thr)) {         // live, and true for NaN
+                        const int a = 4 * q_l + r;
+                        const int key = ((a0 + a) * rh + y0 + t) * rw + x;
+                        const u32 slot = atomicAdd(&m->qcount, 1u);
+                        if (slot < (u32)kQueueCap) queue[slot] = make_uint4((u32)acc[t][r], (u32)swp[t], siiv[t], (u32)key);
+                        else sc = overflow_eval(sc, acc[t][r], swp[t], siiv[t], key, nd, sT4[r], m->rTd[a0 + a], m->constT[a0 + a]);
                     }
                 }
             }
-            if (lane == 0) atomicMax(&m->gmax_key, f2key(lmax));
-            if (item == wv) STAMP2(12);
         }
-    return Score{lmax, bestv, bestkey};
+        if (lane == 0) atomicMax(&m->gmax_key, f2key(sc.lmax));
+        if (item == wv) STAMP2(12);
+    }
 #undef STAMP2
+    __syncthreads();
+    // exact (double) evaluation of the queued candidates of this group
+    {
+        const int nq = (int)(m->qcount < (u32)kQueueCap ? m->qcount : (u32)kQueueCap);
+        for (int idx = tid; idx < nq; idx += kBlockM) {
+            const uint4 rec = queue[idx];
+            const int key = (int)rec.w;
+            const int a = key / G.npos;
+            take_better(sc, exact_from_sums((int)rec.x, (int)rec.y, rec.z, nd, m->sTd[a], m->rTd[a], m->constT[a] != 0), key);
+        }
+    }
+    __syncthreads();                                                   // operands / queue are rewritten by the next group
+    if (tid == 0) m->qcount = 0;
+    return sc;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Phase 4: NCC matrix of the winning angle, row-major MFMA (M = 16 output rows).
+// trow[g][16 + i][16 B] holds the winner's template, trow1 the all-ones one; zero rows around.
+// ---------------------------------------------------------------------------------------------
+template <int S>
+__device__ __noinline__ void ph_winner(const double *rot4, long long rows1, long long cols1, int ka, long long *dbg_cycles)
+{
+    SID_PHASE_LOCALS;
+    const uint8_t *win = smem + G.win_off;
+    const u32 *sii = reinterpret_cast<const u32 *>(smem + G.sii_off);
+    const uint8_t *patch = smem + G.patch_off;
+    uint8_t *trow = smem + G.u_off;
+    uint8_t *trow1 = trow + G.trow_bytes;
+    float *ccm = reinterpret_cast<float *>(smem + G.u_off + 2 * G.trow_bytes);
+    const int s = S > 0 ? S : G.s, rh = G.rh, rw = G.rw, wpitch = G.wpitch;
+    const double nd = G.nd;
+    const int trows = s + 32;
+    for (int idx = tid; idx < 2 * G.trow_bytes / 4; idx += kBlockM) reinterpret_cast<u32 *>(trow)[idx] = 0;
+    __syncthreads();
+    {
+        if (tid < 4) m->rot[0][tid] = rot4[tid];
+        __syncthreads();
+        const SampleGeom g = sample_geom(G, s, rows1, cols1, patch);
+        const int pdump = 0;                                           // row 0 of k-group 0 is never read
+        auto put = [&](int i, int j, int v, bool take = true) {
+            const int off = take ? ((j >> 4) * trows + 16 + i) * 16 + (j & 15) : pdump;
+            trow[off] = (uint8_t)(v ^ 0x80);
+            trow1[off] = take ? 1 : 0;
+        };
+        for (int k0 = 0; k0 * g.ngrp < s; k0 += kRowsPerThread) {
+            int st = 0, stt = 0, sz = 0;
+            const u32 db = sample_fast5(g, m->rot[0], true, k0, st, stt, sz, put);
+            for (int u = 0; u < kRowsPerThread; ++u)
+                if ((db >> u) & 1u) { const int i = g.ig + (k0 + u) * g.ngrp; put(i, g.j, sample_exact(g, m->rot[0], i, g.j)); }
+        }
+    }
+    __syncthreads();
+    if (dbg_cycles && tid == 0) dbg_cycles[13] = (long long)clock64();
+    const double sT = m->sTd[ka], rT = m->rTd[ka];
+    const bool cT = m->constT[ka] != 0;
+    const int nty = (rh + 15) / 16, ntx = (rw + 15) / 16;
+    for (int item = wv; item < nty * ntx; item += kWavesM) {
+        const int yt = item / ntx, xt = item - yt * ntx;
+        const int y0 = yt * 16, x0 = xt * 16;
+        const int rows_here = (rh - y0) < 16 ? (rh - y0) : 16;
+        const int nsteps = rows_here + s - 1;
+        const u32 sbyte = (u32)(x0 + n_l + 16 * q_l);
+        const u32 sh = sbyte & 3u;
+        const uint8_t *bp = win + y0 * wpitch + (sbyte & ~3u);
+        // lane (m = n_l, g = q_l): template row i = step - m  ->  trow[g][16 + step - m]
+        const uint8_t *ta = trow + (q_l * trows + 16 - n_l) * 16;
+        const uint8_t *ta1 = trow1 + (q_l * trows + 16 - n_l) * 16;
+        v4i accT = {0, 0, 0, 0}, accS = {0, 0, 0, 0};
+        // depth-2 software pipeline: the LDS reads of step+2 are in flight while step's MFMAs issue
+        struct Ops { Raw5 w; v4i at, a1; };
+        auto issue = [&](int step) {
+            const int st = step < nsteps ? step : nsteps - 1;          // clamped: harmless re-read past the end
+            Ops o;
+            o.w = read_raw(bp + st * wpitch);
+            o.at = *reinterpret_cast<const v4i *>(ta + st * 16);
+            o.a1 = *reinterpret_cast<const v4i *>(ta1 + st * 16);
+            return o;
+        };
+        Ops o0 = issue(0), o1 = issue(1);
+        for (int step = 0; step < nsteps; step += 2) {
+            const Ops o2 = issue(step + 2), o3 = issue(step + 3);
+            {
+                const v4i bb = align_raw(o0.w, sh);
+                accT = __builtin_amdgcn_mfma_i32_16x16x64_i8(o0.at, bb, accT, 0, 0, 0);
+                accS = __builtin_amdgcn_mfma_i32_16x16x64_i8(o0.a1, bb, accS, 0, 0, 0);
+            }
+            if (step + 1 < nsteps) {
+                const v4i bb = align_raw(o1.w, sh);
+                accT = __builtin_amdgcn_mfma_i32_16x16x64_i8(o1.at, bb, accT, 0, 0, 0);
+                accS = __builtin_amdgcn_mfma_i32_16x16x64_i8(o1.a1, bb, accS, 0, 0, 0);
+            }
+            o0 = o2; o1 = o3;
+        }
+        const int x = x0 + n_l;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int y = y0 + 4 * q_l + r;
+            if (y < rh && x < rw)
+                ccm[y * rw + x] = exact_from_sums(accT[r], accS[r], sii[y * rw + x], nd, sT, rT, cT);
+        }
+    }
+    __syncthreads();
+}
+
+// ---------------------------------------------------------------------------------------------
+// Phase 5: Hessian at the peak (pmlib.py:36-59, :167) and the optional MCC normalisation.
+// hes aliases sii.  Returns h, r in m->red_f[0..1].
+// ---------------------------------------------------------------------------------------------
+__device__ __noinline__ void ph_hessian(unsigned flags, int iy, int ix, float best_r, float *dbg_ccm, float *dbg_hes,
+                                        long long dbg_cap, long long *dbg_cycles)
+{
+    SID_PHASE_LOCALS;
+    float *hes = reinterpret_cast<float *>(smem + G.sii_off);
+    const float *ccm = reinterpret_cast<const float *>(smem + G.u_off + 2 * G.trow_bytes);
+    u32 *hist4 = reinterpret_cast<u32 *>(smem + G.u_off);             // winner operands are dead: 4 KB of histograms
+    const int rh = G.rh, rw = G.rw, npos = G.npos;
+    double sx = 0.0, sxx = 0.0;
+    {
+        // np.gradient twice (unit spacing, one-sided edges) without branches:
+        //   g(j) = (f[min(j+1,n-1)] - f[max(j-1,0)]) * (0 < j < n-1 ? 0.5 : 1),  d2(k) = same formula on g
+        auto d2 = [&](const float *f, int stride, int k, int n) {
+            const int kp = k + 1 < n ? k + 1 : n - 1, km = k > 0 ? k - 1 : 0;
+            const int kpp = kp + 1 < n ? kp + 1 : n - 1, kpm = kp > 0 ? kp - 1 : 0;
+            const int kmp = km + 1 < n ? km + 1 : n - 1, kmm = km > 0 ? km - 1 : 0;
+            const float fa = f[kpp * stride], fb = f[kpm * stride], fc = f[kmp * stride], fd = f[kmm * stride];
+            const float gp = (fa - fb) * ((kp > 0 && kp < n - 1) ? 0.5f : 1.0f);
+            const float gm = (fc - fd) * ((km > 0 && km < n - 1) ? 0.5f : 1.0f);
+            return (gp - gm) * ((k > 0 && k < n - 1) ? 0.5f : 1.0f);
+        };
+#pragma unroll 2
+        for (int idx = tid; idx < npos; idx += kBlockM) {
+            const int y = idx / rw, x = idx - y * rw;
+            const float d2x = d2(ccm + y * rw, 1, x, rw);
+            const float d2y = d2(ccm + x, rw, y, rh);
+            const double hh = (double)d2x * (double)d2x + (double)d2y * (double)d2y;
+            const float hv = (float)sqrt(hh);                          // hypotf: double sqrt, narrowed
+            hes[idx] = hv;
+            sx += (double)hv; sxx += (double)hv * (double)hv;
+        }
+    }
+    __syncthreads();
+    if (dbg_ccm || dbg_hes) {
+        for (int idx = tid; idx < npos && idx < dbg_cap; idx += kBlockM) {
+            if (dbg_ccm) dbg_ccm[idx] = ccm[idx];
+            if (dbg_hes) dbg_hes[idx] = hes[idx];
+        }
+    }
+    if (dbg_cycles && tid == 0) dbg_cycles[14] = (long long)clock64();
+    float h = hes[iy * rw + ix];
+    if (flags & 1u) {
+        sx = block_sum(sx, m);
+        sxx = block_sum(sxx, m);
+        const float sd = std_from_sums(sx, sxx, npos);
+        const float med = block_median(hes, npos, m, hist4);
+        h = (h - med) / sd;
+    }
+    float rr = best_r;
+    if (flags & 4u) {
+        double cx = 0.0, cxx = 0.0;
+        for (int idx = tid; idx < npos; idx += kBlockM) { const double v = (double)ccm[idx]; cx += v; cxx += v * v; }
+        cx = block_sum(cx, m);
+        cxx = block_sum(cxx, m);
+        const float sd = std_from_sums(cx, cxx, npos);
+        const float med = block_median(ccm, npos, m, hist4);
+        rr = (best_r - med) / sd;
+    }
+    __syncthreads();
+    if (tid == 0) { m->red_f[0] = h; m->red_f[1] = rr; }
+    __syncthreads();
 }
 
 template <int S>
-__global__ __launch_bounds__(kBlockM, 3) void pm_kernel_mfma(const PMArgs A)
+__global__ __launch_bounds__(kBlockM, kOccM) void pm_kernel_mfma(const PMArgs A)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     MiscM *m = reinterpret_cast<MiscM *>(smem);
+    Geo *G = reinterpret_cast<Geo *>(smem + kGeoOff);
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int pt = A.order[blockIdx.x];
     const int s = S > 0 ? S : A.img_size, K = A.n_angles;
@@ -529,241 +953,56 @@ __global__ __launch_bounds__(kBlockM, 3) void pm_kernel_mfma(const PMArgs A)
         return;
     }
     const int wh = (int)(r1e - r0), ww = (int)(c1e - c0);
-    const int rh = wh - s + 1, rw = ww - s + 1;
-    const int npos = rh * rw;
-    const MfmaLdsLayout L = mfma_lds_layout(wh, ww, s);
-    uint8_t *win = smem + L.win_off;
-    u32 *sii = reinterpret_cast<u32 *>(smem + L.sii_off);
-    float *hes = reinterpret_cast<float *>(smem + L.sii_off);             // aliases sii (dead by then)
-    u32 *colsum = reinterpret_cast<u32 *>(smem + L.u_off);                // U region, stage 1 of S_II
-    uint8_t *afrag = smem + L.u_off;                                      // U region, sweep operands
-    uint8_t *patch = smem + L.patch_off;
-    uint4 *queue = reinterpret_cast<uint4 *>(smem + L.queue_off);
-    uint8_t *trow = smem + L.u_off;                                       // U region, winner operands
-    uint8_t *trow1 = trow + L.trow_bytes;
-    float *ccm = reinterpret_cast<float *>(smem + L.u_off + 2 * L.trow_bytes);
-    const int wpitch = L.wpitch, arow = L.arow;
-    const double nd = (double)(s * s);
-    const double c1 = A.c1[pt], r1 = A.r1[pt];
-    const int n_l = lane & 15, q_l = lane >> 4;
-
-    if (tid == 0) { m->zero_flag = 0; m->gmax_key = 0x007fffffu /* f2key(-inf) */; m->qcount = 0; }
-
-    // ---- P0a: search window -> LDS, re-centred to int8 (w ^ 0x80), zero beyond the window.
-    //      Loads are issued four dwords deep before any is consumed (HBM/L2 latency overlaps). ----
-    {
-        const int dw_per_row = wpitch / 4, ndw = wh * dw_per_row;
-        const uintptr_t last_dw = (reinterpret_cast<uintptr_t>(A.img2 + (A.rows2 - 1) * A.stride2 + A.cols2) - 1) & ~(uintptr_t)3;
-        for (int base = 0; base < ndw; base += 4 * kBlockM) {
-            u32 lo[4], hi[4], shv[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int idx = base + u * kBlockM + tid;
-                const int idc = idx < ndw ? idx : 0;
-                const int row = idc / dw_per_row, dq = idc - row * dw_per_row;
-                const int dqc = 4 * dq < ww ? dq : 0;               // clamp so that the loads are always legal
-                const uint8_t *gp = A.img2 + (r0 + row) * A.stride2 + c0 + 4 * dqc;
-                const uintptr_t ga = reinterpret_cast<uintptr_t>(gp) & ~(uintptr_t)3;
-                const uintptr_t gb = ga + 4 <= last_dw ? ga + 4 : last_dw;
-                shv[u] = (u32)(reinterpret_cast<uintptr_t>(gp) & 3);
-                lo[u] = *reinterpret_cast<const u32 *>(ga);
-                hi[u] = *reinterpret_cast<const u32 *>(gb);
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int idx = base + u * kBlockM + tid;
-                if (idx < ndw) {
-                    const int row = idx / dw_per_row, dq = idx - row * dw_per_row;
-                    u32 v = __builtin_amdgcn_alignbyte(hi[u], lo[u], shv[u]) ^ 0x80808080u;
-                    const int nvalid = ww - 4 * dq;
-                    if (nvalid < 4) v = nvalid > 0 ? (v & ((1u << (8 * nvalid)) - 1u)) : 0u;
-                    reinterpret_cast<u32 *>(win + row * wpitch)[dq] = v;
-                }
-            }
-        }
+    const int rh = wh - s + 1, rw = ww - s + 1, npos = rh * rw;
+    if (tid == 0) {
+        const MfmaLdsLayout L = mfma_lds_layout(wh, ww, s);
+        const double c1 = A.c1[pt], r1 = A.r1[pt];
+        G->wh = wh; G->ww = ww; G->rh = rh; G->rw = rw; G->npos = npos; G->wpitch = L.wpitch; G->arow = L.arow;
+        G->s = s; G->K = K;
+        G->win_off = L.win_off; G->sii_off = L.sii_off; G->u_off = L.u_off; G->patch_off = L.patch_off;
+        G->ppitch = L.ppitch; G->pdim = L.pdim; G->pradius = L.pradius; G->queue_off = L.queue_off;
+        G->trow_bytes = L.trow_bytes;
+        G->pr0 = (int)floor(r1) - L.pradius; G->pc0 = (int)floor(c1) - L.pradius;
+        G->r0 = r0; G->c0 = c0; G->c1 = c1; G->r1 = r1; G->nd = (double)(s * s);
+        m->zero_flag = 0; m->gmax_key = 0x007fffffu /* f2key(-inf) */; m->qcount = 0;
     }
+    __syncthreads();
+
+    ph_window(A.img2, A.rows2, A.cols2, A.stride2);
     __syncthreads();
     SID_STAMP(1);
-
-    // ---- P1: S_II' = box sums of w'^2.  Stage 1: running sums down each window column ----
-    for (int x = tid; x < ww; x += kBlockM) {
-        const int8_t *col = reinterpret_cast<const int8_t *>(win) + x;
-        int c = 0;
-#pragma unroll 8
-        for (int i = 0; i < s; ++i) { const int v = col[i * wpitch]; c += v * v; }
-        colsum[x] = (u32)c;
-#pragma unroll 8
-        for (int y = 1; y < rh; ++y) {
-            const int vo = col[(y - 1) * wpitch], vn = col[(y + s - 1) * wpitch];
-            c += vn * vn - vo * vo;
-            colsum[y * ww + x] = (u32)c;
-        }
-    }
-    __syncthreads();
-    // Stage 2: running sums along each output row
-    for (int y = tid; y < rh; y += kBlockM) {
-        const u32 *cr = colsum + y * ww;
-        u32 acc = 0;
-#pragma unroll 8
-        for (int j = 0; j < s; ++j) acc += cr[j];
-        sii[y * rw] = acc;
-#pragma unroll 8
-        for (int x = 1; x < rw; ++x) {
-            acc += cr[x + s - 1] - cr[x - 1];
-            sii[y * rw + x] = acc;
-        }
-    }
-    __syncthreads();
+#ifndef SID_ABLATE_SUMS
+    ph_sums();
+#endif
     SID_STAMP(2);
+    ph_patch(A.img1, A.rows1, A.cols1, A.stride1);
 
-    // ---- P0b: neighbourhood of the template centre on image 1 -> LDS patch ----
-    Patch P;
-    P.p = patch; P.pitch = L.ppitch;
-    P.r0 = (int)floor(r1) - L.pradius;
-    P.c0 = (int)floor(c1) - L.pradius;
-    {
-        const int np = L.pdim * L.pdim;
-        for (int base = 0; base < np; base += 8 * kBlockM) {
-            uint8_t pv[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {                           // 8 independent byte loads in flight
-                const int idx = base + u * kBlockM + tid;
-                const int idc = idx < np ? idx : 0;
-                const int pr = idc / L.pdim, pc = idc - pr * L.pdim;
-                int64_t gr = (int64_t)P.r0 + pr, gc = (int64_t)P.c0 + pc;
-                gr = gr < 0 ? 0 : (gr > A.rows1 - 1 ? A.rows1 - 1 : gr);     // clamped rows/cols are never sampled
-                gc = gc < 0 ? 0 : (gc > A.cols1 - 1 ? A.cols1 - 1 : gc);
-                pv[u] = A.img1[gr * A.stride1 + gc];
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int idx = base + u * kBlockM + tid;
-                if (idx < np) { const int pr = idx / L.pdim, pc = idx - pr * L.pdim; patch[pr * L.ppitch + pc] = pv[u]; }
-            }
-        }
-    }
-
-    // ---- per group of <= 15 angles: template operands, sweep, exact evaluation of candidates ----
-    float bestv = -INFINITY;         // exact best of this thread
-    int bestkey = 0x7fffffff;
-    float lmax = -INFINITY;          // running max of the float32 estimates (wavefront-uniform)
-    const bool zero_a = (s <= 48) && q_l == 3;
-    const int alane = zero_a ? lane - 16 : lane;                   // any legal address for the zeroed lanes
-    const double rmax1 = (double)(A.rows1 - 1), cmax1 = (double)(A.cols1 - 1);
-
+    Score sc{-INFINITY, -INFINITY, 0x7fffffff};
     for (int a0 = 0; a0 < K; a0 += kAnglesPerGroup) {
         const int Kg = (K - a0) < kAnglesPerGroup ? (K - a0) : kAnglesPerGroup;
-        // afrag[i][lane = g*16 + slot][16 bytes], byte jj <-> column c = 16 g + jj; row s is all zero
-        for (int idx = tid; idx < (s + 1) * arow / 4; idx += kBlockM) reinterpret_cast<u32 *>(afrag)[idx] = 0;
-        if (tid < kSlots) { m->isT[tid] = 0; m->isTT[tid] = 0; }
-        __syncthreads();                                           // also: patch complete
-        SID_STAMP(8);
-        {
-            int sawzero = 0;
-            const int nss = s * s;
-            for (int a = 0; a < Kg; ++a) {
-                const double *rot4 = A.rot + 4 * (a0 + a);
-                const double cosa = rot4[0], sina = rot4[1], msin = -sina;
-                const double off0 = r1 - rot4[2], off1 = c1 - rot4[3];
-                int st = 0, stt = 0;
-                for (int base = 0; base < nss; base += 4 * kBlockM) {
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {                  // independent chains: latencies overlap
-                        const int idx = base + u * kBlockM + tid;
-                        const bool valid = idx < nss;
-                        const int idc = valid ? idx : 0;
-                        const int i = idc / s, j = idc - i * s;
-                        // scipy NI_GeometricTransform order of operations (matrix = transform.T)
-                        double rr = 0.0 + (double)i * cosa;
-                        rr = rr + (double)j * sina;
-                        rr = rr + off0;
-                        double cc = 0.0 + (double)i * msin;
-                        cc = cc + (double)j * cosa;
-                        cc = cc + off1;
-                        const bool in = rr >= 0.0 && rr <= rmax1 && cc >= 0.0 && cc <= cmax1;
-                        int ri = (int)floor(rr + 0.5) - P.r0, ci = (int)floor(cc + 0.5) - P.c0;
-                        ri = in ? ri : 0; ci = in ? ci : 0;       // in-image samples always lie inside the patch
-                        int v = patch[ri * P.pitch + ci];
-                        v = in ? v : 0;
-                        if (valid) {
-                            if (v == 0) sawzero = 1;
-                            afrag[i * arow + ((j >> 4) * 16 + a) * 16 + (j & 15)] = (uint8_t)(v ^ 0x80);
-                            const int sv = v - 128;
-                            st += sv; stt += sv * sv;
-                        }
-                    }
-                }
-                st = wave_sum_dpp(st); stt = wave_sum_dpp(stt);
-                if (lane == 0) { atomicAdd(&m->isT[a], st); atomicAdd(&m->isTT[a], stt); }
-            }
-            for (int idx = tid; idx < nss; idx += kBlockM) {        // slot 15: all-ones template
-                const int i = idx / s, j = idx - i * s;
-                afrag[i * arow + ((j >> 4) * 16 + 15) * 16 + (j & 15)] = 1;
-            }
-            if (sawzero) m->zero_flag = 1;
-        }
-        __syncthreads();
-        SID_STAMP(9);
-        if (A.dbg_templates) {
-            for (int idx = tid; idx < Kg * s * s; idx += kBlockM) {
-                const int a = idx / (s * s), rem = idx - a * s * s;
-                const int i = rem / s, j = rem - i * s;
-                A.dbg_templates[(a0 + a) * s * s + rem] = afrag[i * arow + ((j >> 4) * 16 + a) * 16 + (j & 15)] ^ 0x80;
-            }
-        }
-        if (m->zero_flag) {                                        // pmlib.py:152-154
+        ph_templates<S>(A.rot, a0, Kg, A.rows1, A.cols1, A.dbg_templates, A.dbg_cycles);
+        if (m->zero_flag) {                                            // pmlib.py:152-154
             if (tid < 5) out[tid] = NAN;
             if (oij && tid < 3) oij[tid] = -1;
             if (A.dbg_shape && tid == 0) { A.dbg_shape[0] = rh; A.dbg_shape[1] = rw; }
             return;
         }
-        if (tid < Kg) {                                            // per-angle terms (signed domain)
-            const double st = (double)m->isT[tid], stt = (double)m->isTT[tid];
-            const double dT = nd * stt - st * st;                  // exact
-            const double rT = 1.0 / sqrt(dT);
-            m->sTd[a0 + tid] = st;
-            m->constT[a0 + tid] = dT == 0.0 ? 1 : 0;
-            m->rTd[a0 + tid] = rT;
-            m->rTf[a0 + tid] = dT == 0.0 ? NAN : (float)rT;       // NaN estimate => always a candidate
-        }
-        __syncthreads();
         SID_STAMP(3);
-
-        // ---- P2: angle-major sweep (out of line: keeps the hot loop's register allocation apart) ----
-        {
-            const Score sc = sweep_group<S>(Score{lmax, bestv, bestkey}, L.u_off, L.win_off, L.sii_off, L.queue_off,
-                                            arow, wpitch, wh, rh, rw, s, Kg, a0, A.dbg_cycles);
-            lmax = sc.lmax; bestv = sc.bestv; bestkey = sc.bestkey;
-        }
-        __syncthreads();
+#ifndef SID_ABLATE_SWEEP
+        sc = ph_sweep<S>(sc, a0, Kg, A.dbg_cycles);
+#else
+        sc.bestv = 0.5f; sc.bestkey = 17;
+#endif
         SID_STAMP(4);
-        // ---- exact (double) evaluation of the queued candidates of this group ----
-        {
-            const int nq = (int)(m->qcount < (u32)kQueueCap ? m->qcount : (u32)kQueueCap);
-            for (int idx = tid; idx < nq; idx += kBlockM) {
-                const uint4 rec = queue[idx];
-                const int key = (int)rec.w;
-                const int a = key / npos;
-                const double swd = (double)(int)rec.y, siid = (double)rec.z;
-                const double dI = nd * siid - swd * swd;
-                const double s2 = siid + 256.0 * swd + 16384.0 * nd;
-                const bool lowvar = (2.0 * dI <= nd) && (dI * 8388608.0 <= 10.0 * nd * s2);
-                const double numer = nd * (double)(int)rec.x - swd * m->sTd[a];
-                const float rv = exact_ncc(numer, dI, m->rTd[a], m->constT[a] != 0, lowvar);
-                if (rv > bestv || (rv == bestv && key < bestkey)) { bestv = rv; bestkey = key; }
-            }
-        }
-        __syncthreads();                                           // afrag / queue are rewritten by the next group
-        if (tid == 0) m->qcount = 0;
     }
 
     // ---- P3: block arg-max (first angle, then first row-major index on ties) ----
     {
-        const float wbest = wave_max_dpp(bestv);                   // exact values: no NaN (exact_ncc never returns one)
-        bestkey = wave_min_dpp(bestv == wbest ? bestkey : 0x7fffffff);
-        bestv = wbest;
+        const float wbest = wave_max_dpp(sc.bestv);                    // exact values: never NaN
+        sc.bestkey = wave_min_dpp(sc.bestv == wbest ? sc.bestkey : 0x7fffffff);
+        sc.bestv = wbest;
     }
-    if (lane == 0) { m->red_f[wv] = bestv; m->red_i[wv] = bestkey; }
+    if (lane == 0) { m->red_f[wv] = sc.bestv; m->red_i[wv] = sc.bestkey; }
     __syncthreads();
     if (tid == 0) {
         float bv = m->red_f[0]; int bk = m->red_i[0];
@@ -781,143 +1020,21 @@ __global__ __launch_bounds__(kBlockM, 3) void pm_kernel_mfma(const PMArgs A)
     const int iy = bidx / rw, ix = bidx - iy * rw;
     SID_STAMP(5);
 
-    // ---- P4: winner's NCC matrix, row-major MFMA.  trow[g][16 + i][16 B], zero rows around ----
-    const int trows = s + 32;
-    for (int idx = tid; idx < 2 * L.trow_bytes / 4; idx += kBlockM) reinterpret_cast<u32 *>(trow)[idx] = 0;
-    __syncthreads();
-    for (int idx = tid; idx < s * s; idx += kBlockM) {
-        const int i = idx / s, j = idx - i * s;
-        const uint8_t v = sample_template(A, P, A.rot + 4 * ka, c1, r1, i, j);
-        const int off = ((j >> 4) * trows + 16 + i) * 16 + (j & 15);
-        trow[off] = v ^ 0x80;
-        trow1[off] = 1;
-    }
-    __syncthreads();
-    SID_STAMP(13);
-    {
-        const double sT = m->sTd[ka], rT = m->rTd[ka];
-        const bool cT = m->constT[ka] != 0;
-        const int nty = (rh + 15) / 16, ntx = (rw + 15) / 16;
-        for (int item = wv; item < nty * ntx; item += kWavesM) {
-            const int yt = item / ntx, xt = item - yt * ntx;
-            const int y0 = yt * 16, x0 = xt * 16;
-            const int rows_here = (rh - y0) < 16 ? (rh - y0) : 16;
-            const int nsteps = rows_here + s - 1;
-            const u32 sbyte = (u32)(x0 + n_l + 16 * q_l);
-            const u32 sh = sbyte & 3u;
-            const uint8_t *bbase = win + (sbyte & ~3u);
-            // lane (m = n_l, g = q_l): template row i = step - m  ->  trow[g][16 + step - m]
-            const uint8_t *ta = trow + (q_l * trows + 16 - n_l) * 16;
-            const uint8_t *ta1 = trow1 + (q_l * trows + 16 - n_l) * 16;
-            v4i accT = {0, 0, 0, 0}, accS = {0, 0, 0, 0};
-            // depth-2 software pipeline: the LDS reads of step+2 are in flight while step's MFMAs issue
-            struct Ops { u32 r[5]; v4i at, a1; };
-            auto issue = [&](int step) {
-                const int st = step < nsteps ? step : nsteps - 1;        // clamped: harmless re-read past the end
-                const u32 *q = reinterpret_cast<const u32 *>(bbase + (y0 + st) * wpitch);
-                Ops o;
-                o.r[0] = q[0]; o.r[1] = q[1]; o.r[2] = q[2]; o.r[3] = q[3]; o.r[4] = q[4];
-                o.at = *reinterpret_cast<const v4i *>(ta + st * 16);
-                o.a1 = *reinterpret_cast<const v4i *>(ta1 + st * 16);
-                return o;
-            };
-            Ops o0 = issue(0), o1 = issue(1);
-            for (int step = 0; step < nsteps; step += 2) {
-                const Ops o2 = issue(step + 2), o3 = issue(step + 3);
-                {
-                    v4i bb;
-                    bb[0] = (int)__builtin_amdgcn_alignbyte(o0.r[1], o0.r[0], sh); bb[1] = (int)__builtin_amdgcn_alignbyte(o0.r[2], o0.r[1], sh);
-                    bb[2] = (int)__builtin_amdgcn_alignbyte(o0.r[3], o0.r[2], sh); bb[3] = (int)__builtin_amdgcn_alignbyte(o0.r[4], o0.r[3], sh);
-                    accT = __builtin_amdgcn_mfma_i32_16x16x64_i8(o0.at, bb, accT, 0, 0, 0);
-                    accS = __builtin_amdgcn_mfma_i32_16x16x64_i8(o0.a1, bb, accS, 0, 0, 0);
-                }
-                if (step + 1 < nsteps) {
-                    v4i bb;
-                    bb[0] = (int)__builtin_amdgcn_alignbyte(o1.r[1], o1.r[0], sh); bb[1] = (int)__builtin_amdgcn_alignbyte(o1.r[2], o1.r[1], sh);
-                    bb[2] = (int)__builtin_amdgcn_alignbyte(o1.r[3], o1.r[2], sh); bb[3] = (int)__builtin_amdgcn_alignbyte(o1.r[4], o1.r[3], sh);
-                    accT = __builtin_amdgcn_mfma_i32_16x16x64_i8(o1.at, bb, accT, 0, 0, 0);
-                    accS = __builtin_amdgcn_mfma_i32_16x16x64_i8(o1.a1, bb, accS, 0, 0, 0);
-                }
-                o0 = o2; o1 = o3;
-            }
-            const int x = x0 + n_l;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int y = y0 + 4 * q_l + r;
-                if (y < rh && x < rw) {
-                    const double swd = (double)accS[r];
-                    const double siid = (double)sii[y * rw + x];
-                    const double dI = nd * siid - swd * swd;
-                    const double s2 = siid + 256.0 * swd + 16384.0 * nd;
-                    const bool lowvar = (2.0 * dI <= nd) && (dI * 8388608.0 <= 10.0 * nd * s2);
-                    const double numer = nd * (double)accT[r] - swd * sT;
-                    ccm[y * rw + x] = exact_ncc(numer, dI, rT, cT, lowvar);
-                }
-            }
-        }
-    }
-    __syncthreads();
+#ifndef SID_ABLATE_WINNER
+    ph_winner<S>(A.rot + 4 * ka, A.rows1, A.cols1, ka, A.dbg_cycles);
+#endif
     SID_STAMP(6);
-
-    // ---- P5: Hessian at the peak (pmlib.py:36-59, :167); hes aliases sii ----
-    double sx = 0.0, sxx = 0.0;
-    {
-        // np.gradient twice (unit spacing, one-sided edges) without branches:
-        //   g(j) = (f[min(j+1,n-1)] - f[max(j-1,0)]) * (0 < j < n-1 ? 0.5 : 1),  d2(k) = same formula on g
-        auto d2 = [&](const float *f, int stride, int k, int n) {
-            const int kp = k + 1 < n ? k + 1 : n - 1, km = k > 0 ? k - 1 : 0;
-            const int kpp = kp + 1 < n ? kp + 1 : n - 1, kpm = kp > 0 ? kp - 1 : 0;
-            const int kmp = km + 1 < n ? km + 1 : n - 1, kmm = km > 0 ? km - 1 : 0;
-            const float fa = f[kpp * stride], fb = f[kpm * stride], fc = f[kmp * stride], fd = f[kmm * stride];
-            const float gp = (fa - fb) * ((kp > 0 && kp < n - 1) ? 0.5f : 1.0f);
-            const float gm = (fc - fd) * ((km > 0 && km < n - 1) ? 0.5f : 1.0f);
-            return (gp - gm) * ((k > 0 && k < n - 1) ? 0.5f : 1.0f);
-        };
-#pragma unroll 2
-        for (int idx = tid; idx < npos; idx += kBlockM) {
-            const int y = idx / rw, x = idx - y * rw;
-            const float d2x = d2(ccm + y * rw, 1, x, rw);
-            const float d2y = d2(ccm + x, rw, y, rh);
-            const double hh = (double)d2x * (double)d2x + (double)d2y * (double)d2y;
-            const float hv = (float)sqrt(hh);                      // hypotf: double sqrt, narrowed
-            hes[idx] = hv;
-            sx += (double)hv; sxx += (double)hv * (double)hv;
-        }
-    }
-    __syncthreads();
-    if (A.dbg_ccm || A.dbg_hes) {
-        for (int idx = tid; idx < npos && idx < A.dbg_cap; idx += kBlockM) {
-            if (A.dbg_ccm) A.dbg_ccm[idx] = ccm[idx];
-            if (A.dbg_hes) A.dbg_hes[idx] = hes[idx];
-        }
-    }
     if (A.dbg_shape && tid == 0) { A.dbg_shape[0] = rh; A.dbg_shape[1] = rw; }
-    SID_STAMP(14);
-    float h = hes[iy * rw + ix];
-    if (A.flags & 1u) {
-        sx = block_sum(sx, m);
-        sxx = block_sum(sxx, m);
-        const float sd = std_from_sums(sx, sxx, npos);
-        const float med = block_median(hes, npos, m, reinterpret_cast<u32 *>(trow));   // winner operands are dead: 4 KB of histograms
-        h = (h - med) / sd;
-    }
-    float rr = best_r;
-    if (A.flags & 4u) {
-        double cx = 0.0, cxx = 0.0;
-        for (int idx = tid; idx < npos; idx += kBlockM) { const double v = (double)ccm[idx]; cx += v; cxx += v * v; }
-        cx = block_sum(cx, m);
-        cxx = block_sum(cxx, m);
-        const float sd = std_from_sums(cx, cxx, npos);
-        const float med = block_median(ccm, npos, m, reinterpret_cast<u32 *>(trow));
-        rr = (best_r - med) / sd;
-    }
+#ifndef SID_ABLATE_HESSIAN
+    ph_hessian(A.flags, iy, ix, best_r, A.dbg_ccm, A.dbg_hes, A.dbg_cap, A.dbg_cycles);
+#endif
     SID_STAMP(7);
     if (tid == 0) {
         out[0] = c2fg + ((double)ix - (double)(ww - s) / 2.0);
         out[1] = r2fg + ((double)iy - (double)(wh - s) / 2.0);
         out[2] = A.angles[ka];
-        out[3] = (double)rr;
-        out[4] = (double)h;
+        out[3] = (double)m->red_f[1];
+        out[4] = (double)m->red_f[0];
         if (oij) { oij[0] = iy; oij[1] = ix; oij[2] = ka; }
     }
 }
