@@ -26,6 +26,7 @@
 // Compile with -ffp-contract=off.
 #include <hip/hip_runtime.h>
 #include <math.h>
+#include <type_traits>
 #include "pm_kernel.h"
 
 namespace sid {
@@ -372,7 +373,7 @@ __device__ __noinline__ void ph_patch(const uint8_t *img1, long long rows1, long
 // whenever the rounding or the image-bounds decision could depend on the last bits (|doubt| < kGuard,
 // float error < 2.5e-5) the sample is flagged and redone afterwards with scipy's double arithmetic.
 struct SampleGeom {
-    const uint8_t *patch; int ppitch, pr0, pc0, s, ngrp, ig, j; bool act;
+    const uint8_t *patch; int ppitch, pr0, pc0, s, ngrp, ig, j; bool act, inside;
     float lo_r, hi_r, lo_c, hi_c;
     double c1, r1, rmax1, cmax1;
 };
@@ -386,6 +387,8 @@ __device__ __forceinline__ SampleGeom sample_geom(const Geo &G, int s, long long
     g.ngrp = kBlockM / s;
     g.ig = (int)threadIdx.x / s; g.j = (int)threadIdx.x - g.ig * s;
     g.act = g.ig < g.ngrp;
+    // whole patch at least one pixel inside image 1: the image-bounds tests can be skipped (block-uniform)
+    g.inside = G.pr0 >= 1 && G.pc0 >= 1 && (long long)G.pr0 + G.pdim <= rows1 - 1 && (long long)G.pc0 + G.pdim <= cols1 - 1;
     g.lo_r = (float)(-G.pr0); g.hi_r = (float)(rows1 - 1 - G.pr0);
     g.lo_c = (float)(-G.pc0); g.hi_c = (float)(cols1 - 1 - G.pc0);
     g.c1 = G.c1; g.r1 = G.r1; g.rmax1 = (double)(rows1 - 1); g.cmax1 = (double)(cols1 - 1);
@@ -412,8 +415,11 @@ __device__ __forceinline__ int sample_exact(const SampleGeom &g, const double *r
 }
 
 // Fast pass for rows ig + (k0..k0+4)*ngrp of column j of one angle.  Returns the doubt bits; sure
-// samples are stored and summed, doubtful ones are left to the caller.
-template <typename Store>
+// samples are stored and summed, doubtful ones are left to the caller.  Branch-free: a rejected sample
+// is handed to `store` with take = false (it writes a scratch byte), so that all the chains of a chunk
+// - and of the angles in flight - sit in one basic block and overlap.  INSIDE: the patch lies wholly
+// inside image 1, no bounds tests.
+template <bool INSIDE, typename Store>
 __device__ __forceinline__ u32 sample_fast5(const SampleGeom &g, const double *rot4, bool angle_ok, int k0,
                                             int &st, int &stt, int &sawzero, Store store)
 {
@@ -421,32 +427,34 @@ __device__ __forceinline__ u32 sample_fast5(const SampleGeom &g, const double *r
     const float cf = (float)cosa, sf = (float)sina;
     const float orf = (float)((g.r1 - rot4[2]) - (double)g.pr0), ocf = (float)((g.c1 - rot4[3]) - (double)g.pc0);
     const float fj = (float)g.j, fig = (float)g.ig;
-    const float base_r = fmaf(fig, cf, fmaf(fj, sf, orf)), step_r = (float)g.ngrp * cf;
-    const float base_c = fmaf(fig, -sf, fmaf(fj, cf, ocf)), step_c = -(float)g.ngrp * sf;
+    const float base_r = fmaf(fig, cf, fmaf(fj, sf, orf)) + 0.5f, step_r = (float)g.ngrp * cf;
+    const float base_c = fmaf(fig, -sf, fmaf(fj, cf, ocf)) + 0.5f, step_c = -(float)g.ngrp * sf;
+    const bool lane_ok = angle_ok && g.act;
     u32 doubt = 0;
 #pragma unroll
     for (int u = 0; u < kRowsPerThread; ++u) {
         const int k = k0 + u;
         const int i = g.ig + k * g.ngrp;
-        const bool valid = angle_ok && g.act && i < g.s;
+        const bool valid = lane_ok && i < g.s;
         const float fk = (float)k;
-        const float rrf = fmaf(fk, step_r, base_r);
-        const float ccf = fmaf(fk, step_c, base_c);
-        const float tr = rrf + 0.5f, tc_ = ccf + 0.5f;
+        const float tr = fmaf(fk, step_r, base_r), tc_ = fmaf(fk, step_c, base_c);   // coordinate + 0.5
         const float flr = floorf(tr), flc = floorf(tc_);
-        const float frr = tr - flr, frc = tc_ - flc;
-        const bool in_f = rrf >= g.lo_r + kGuard && rrf <= g.hi_r - kGuard && ccf >= g.lo_c + kGuard && ccf <= g.hi_c - kGuard;
-        const bool out_f = rrf < g.lo_r - kGuard || rrf > g.hi_r + kGuard || ccf < g.lo_c - kGuard || ccf > g.hi_c + kGuard;
-        const bool sure = (in_f || out_f) && frr > kGuard && frr < 1.0f - kGuard && frc > kGuard && frc < 1.0f - kGuard;
+        // doubtful when the coordinate is within kGuard of a rounding boundary
+        bool sure = fabsf((tr - flr) - 0.5f) < 0.5f - kGuard && fabsf((tc_ - flc) - 0.5f) < 0.5f - kGuard;
+        bool in_f = true;
+        if (!INSIDE) {
+            const float rrf = tr - 0.5f, ccf = tc_ - 0.5f;
+            in_f = rrf >= g.lo_r + kGuard && rrf <= g.hi_r - kGuard && ccf >= g.lo_c + kGuard && ccf <= g.hi_c - kGuard;
+            const bool out_f = rrf < g.lo_r - kGuard || rrf > g.hi_r + kGuard || ccf < g.lo_c - kGuard || ccf > g.hi_c + kGuard;
+            sure = sure && (in_f || out_f);
+        }
         const int ri = in_f ? (int)flr : 0, ci = in_f ? (int)flc : 0; // in-image samples always lie inside the patch
         int v = g.patch[ri * g.ppitch + ci];
         v = in_f ? v : 0;
         const bool take = valid && sure;
         doubt |= ((valid && !sure) ? 1u : 0u) << u;
-        // branch-free: a rejected sample is written to a scratch byte, so that all the chains of a
-        // chunk (and of the angles in flight) sit in one basic block and overlap
         sawzero |= (take && v == 0) ? 1 : 0;
-        store(i, g.j, v, take);
+        store(k, i, v, take);
         const int sv = take ? v - 128 : 0;
         st += sv; stt += sv * sv;
     }
@@ -479,41 +487,58 @@ __device__ __noinline__ void ph_templates(const double *rot, int a0, int Kg, lon
 #define SID_SKIP_SAMPLING_LOOP 1
 #endif
     const int dump = (s + 1) * arow;                                   // 16 scratch bytes behind the operand table
+    // byte offset of (row ig + k*ngrp, column j, slot a) = wbase + k*wstep + 16 a
+    const int wbase = g.ig * arow + (g.j >> 4) * 256 + (g.j & 15), wstep = g.ngrp * arow;
     int sawzero = 0;
     u32 anydoubt = 0;
 #ifndef SID_SKIP_SAMPLING_LOOP
-    for (int k0 = 0; k0 * g.ngrp < s; k0 += kRowsPerThread) {
-        for (int a = 0; a < Kg; a += 3) {                              // three angles in flight: their chains interleave
-            int st[3] = {0, 0, 0}, stt[3] = {0, 0, 0};
-            u32 db[3];
+    auto run = [&](auto inside_tag) {
+        constexpr bool INSIDE = decltype(inside_tag)::value;
+        unsigned long long dlo = 0, dhi = 0;
+        for (int k0 = 0; k0 * g.ngrp < s; k0 += kRowsPerThread) {
+            for (int a = 0; a < Kg; a += 3) {                          // three angles in flight: their chains interleave
+                int st[3] = {0, 0, 0}, stt[3] = {0, 0, 0};
+                u32 db[3];
 #pragma unroll
-            for (int q = 0; q < 3; ++q) {
-                const int aa = a + q < Kg ? a + q : Kg - 1;
-                db[q] = sample_fast5(g, m->rot[aa], a + q < Kg, k0, st[q], stt[q], sawzero, [&](int i, int j, int v, bool take) {
-                    const int off = i * arow + ((j >> 4) * 16 + aa) * 16 + (j & 15);
-                    afrag[take ? off : dump] = (uint8_t)(v ^ 0x80); });
-            }
-#pragma unroll
-            for (int q = 0; q < 3; ++q) {
-                if (a + q < Kg) {                                      // wavefront-uniform
-                    const int ws = wave_sum_dpp(st[q]), wss = wave_sum_dpp(stt[q]);
-                    if (lane == 0) { atomicAdd(&m->isT[a + q], ws); atomicAdd(&m->isTT[a + q], wss); }
+                for (int q = 0; q < 3; ++q) {
+                    const int aa = a + q < Kg ? a + q : Kg - 1;
+                    db[q] = sample_fast5<INSIDE>(g, m->rot[aa], a + q < Kg, k0, st[q], stt[q], sawzero,
+                        [&](int k, int, int v, bool take) { afrag[take ? wbase + k * wstep + 16 * aa : dump] = (uint8_t)(v ^ 0x80); });
                 }
-                anydoubt |= db[q];
-                if (db[q]) {                                           // rare: redo the doubtful samples exactly
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    if (a + q < Kg) {                                  // wavefront-uniform
+                        const int ws = wave_sum_dpp(st[q]), wss = wave_sum_dpp(stt[q]);
+                        if (lane == 0) { atomicAdd(&m->isT[a + q], ws); atomicAdd(&m->isTT[a + q], wss); }
+                        // remember the doubtful samples: bit 5*(a+q) + u of a 128-bit mask
+                        const int pos = 5 * (a + q);
+                        const unsigned long long d = (unsigned long long)db[q];
+                        if (pos < 64) { dlo |= d << pos; if (pos > 59) dhi |= d >> (64 - pos); }
+                        else dhi |= d << (pos - 64);
+                    }
+                }
+            }
+            // rare: redo the doubtful samples of this chunk with scipy's double arithmetic (kept apart
+            // from the DPP reductions above: no divergent code between them)
+            if (dlo | dhi) {
+                for (int aa = 0; aa < Kg; ++aa) {
+                    const int pos = 5 * aa;
+                    const u32 dbits = (u32)((pos < 64 ? (dlo >> pos) | (pos > 59 ? dhi << (64 - pos) : 0ull) : dhi >> (pos - 64)) & 31ull);
                     for (int u = 0; u < kRowsPerThread; ++u) {
-                        if ((db[q] >> u) & 1u) {
-                            const int i = g.ig + (k0 + u) * g.ngrp, aa = a + q;
+                        if ((dbits >> u) & 1u) {
+                            const int i = g.ig + (k0 + u) * g.ngrp;
                             const int v = sample_exact(g, m->rot[aa], i, g.j);
                             sawzero |= (v == 0) ? 1 : 0;
-                            afrag[i * arow + ((g.j >> 4) * 16 + aa) * 16 + (g.j & 15)] = (uint8_t)(v ^ 0x80);
+                            afrag[wbase + (k0 + u) * wstep + 16 * aa] = (uint8_t)(v ^ 0x80);
                             atomicAdd(&m->isT[aa], v - 128); atomicAdd(&m->isTT[aa], (v - 128) * (v - 128));
                         }
                     }
                 }
             }
+            dlo = 0; dhi = 0;
         }
-    }
+    };
+    if (g.inside) run(std::true_type{}); else run(std::false_type{});
 #else
     (void)anydoubt; (void)dump;
 #endif
@@ -797,7 +822,8 @@ __device__ __noinline__ void ph_winner(const double *rot4, long long rows1, long
         };
         for (int k0 = 0; k0 * g.ngrp < s; k0 += kRowsPerThread) {
             int st = 0, stt = 0, sz = 0;
-            const u32 db = sample_fast5(g, m->rot[0], true, k0, st, stt, sz, put);
+            const u32 db = sample_fast5<false>(g, m->rot[0], true, k0, st, stt, sz,
+                                               [&](int, int i, int v, bool take) { put(i, g.j, v, take); });
             for (int u = 0; u < kRowsPerThread; ++u)
                 if ((db >> u) & 1u) { const int i = g.ig + (k0 + u) * g.ngrp; put(i, g.j, sample_exact(g, m->rot[0], i, g.j)); }
         }
