@@ -845,19 +845,22 @@ __device__ __noinline__ void ph_winner(const double *rot4, long long rows1, long
         const uint8_t *ta = trow + (q_l * trows + 16 - n_l) * 16;
         const uint8_t *ta1 = trow1 + (q_l * trows + 16 - n_l) * 16;
         v4i accT = {0, 0, 0, 0}, accS = {0, 0, 0, 0};
-        // depth-2 software pipeline: the LDS reads of step+2 are in flight while step's MFMAs issue
+        // depth-2 software pipeline on running pointers: the LDS reads of steps +2/+3 are in flight while
+        // the MFMAs of the current pair issue.  Reads past the last step touch the zero rows below the
+        // window / behind the template and are never used.
         struct Ops { Raw5 w; v4i at, a1; };
-        auto issue = [&](int step) {
-            const int st = step < nsteps ? step : nsteps - 1;          // clamped: harmless re-read past the end
+        auto issue = [&]() {
             Ops o;
-            o.w = read_raw(bp + st * wpitch);
-            o.at = *reinterpret_cast<const v4i *>(ta + st * 16);
-            o.a1 = *reinterpret_cast<const v4i *>(ta1 + st * 16);
+            o.w = read_raw(bp);
+            o.at = *reinterpret_cast<const v4i *>(ta);
+            o.a1 = *reinterpret_cast<const v4i *>(ta1);
+            bp += wpitch; ta += 16; ta1 += 16;
             return o;
         };
-        Ops o0 = issue(0), o1 = issue(1);
+        Ops o0 = issue(), o1 = issue();
         for (int step = 0; step < nsteps; step += 2) {
-            const Ops o2 = issue(step + 2), o3 = issue(step + 3);
+            Ops o2 = o0, o3 = o1;
+            if (step + 2 < nsteps) { o2 = issue(); o3 = issue(); }       // wavefront-uniform
             {
                 const v4i bb = align_raw(o0.w, sh);
                 accT = __builtin_amdgcn_mfma_i32_16x16x64_i8(o0.at, bb, accT, 0, 0, 0);
