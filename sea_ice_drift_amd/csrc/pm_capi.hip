@@ -408,8 +408,14 @@ SID_EXPORT int sid_pm_run(sid_pm_ctx *ctx)
         b.lds = std::min(b.lds + lds_pad, sid::max_lds_bytes());
         A.order = ctx->order.p + b.offset;
         A.n_launch = b.count;
+        // 256 threads per point; 768 when the LDS footprint leaves room for one point per CU only, so that
+        // the CU still carries 12 wavefronts (3 per SIMD = the register budget).  (Measured: 384- and
+        // 512-thread groups lose to 2 x 256 - they do not pack onto the SIMDs and serialise the phases.)
+        const int per_cu = std::max(1, sid::max_lds_bytes() / b.lds);
+        static const int force_nt = getenv("SID_PM_THREADS") ? atoi(getenv("SID_PM_THREADS")) : 0;   // A/B experiments
+        const int nthreads = force_nt ? force_nt : (per_cu == 1 ? 768 : 256);
         const int e = ctx->kernel == KERNEL_DOT4 ? sid::launch_pm(A, b.lds, ctx->stream)
-                                                 : sid::launch_pm_mfma(A, b.lds, ctx->stream);
+                                                 : sid::launch_pm_mfma(A, b.lds, nthreads, ctx->stream);
         if (e != 0) return fail(SID_PM_ERR_HIP, "kernel launch failed: %s", hipGetErrorString((hipError_t)e));
     }
     return SID_PM_OK;
@@ -534,7 +540,7 @@ SID_EXPORT int sid_pm_debug_point(sid_pm_ctx *ctx, double c1, double r1, double 
         A.dbg_templates = dt.p; A.dbg_ccm = dccm.p; A.dbg_hes = dhes.p; A.dbg_shape = dshape.p; A.dbg_cap = cap;
         A.dbg_cycles = dcyc.p;
         step((hipError_t)(ctx->kernel == KERNEL_DOT4 ? sid::launch_pm(A, lds, ctx->stream)
-                                                     : sid::launch_pm_mfma(A, lds, ctx->stream)));
+                                                     : sid::launch_pm_mfma(A, lds, getenv("SID_PM_THREADS") ? atoi(getenv("SID_PM_THREADS")) : 256, ctx->stream)));
         step(hipStreamSynchronize(ctx->stream));
         if (templates) step(hipMemcpy(templates, dt.p, tcount, hipMemcpyDeviceToHost));
         if (ccm && cap > 0) step(hipMemcpy(ccm, dccm.p, sizeof(float) * cap, hipMemcpyDeviceToHost));

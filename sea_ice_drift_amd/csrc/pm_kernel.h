@@ -102,7 +102,7 @@ __host__ __device__ inline MfmaLdsLayout mfma_lds_layout(int wh, int ww, int s)
     return L;
 }
 
-int launch_pm_mfma(const PMArgs &args, int lds_bytes, void *stream);
+int launch_pm_mfma(const PMArgs &args, int lds_bytes, int nthreads, void *stream);
 bool mfma_img_size_supported(int s);
 
 // host-side launcher implemented in pm_kernel.hip; returns a hipError_t as int

@@ -22,7 +22,7 @@
 //   The double-precision normalisation of the spec is evaluated only for arg-max candidates picked
 //   by a float32 pre-filter (|r~ - r| <= 4e-7 << margin 1e-5) and for the winner's matrix.
 //
-// One workgroup of 512 threads (8 wavefronts) per grid point.
+// One workgroup per grid point; 256 or 768 threads by LDS-footprint class (see kMaxBlockM).
 // Compile with -ffp-contract=off.
 #include <hip/hip_runtime.h>
 #include <math.h>
@@ -36,8 +36,11 @@ namespace {
 typedef uint32_t u32;
 typedef int v4i __attribute__((ext_vector_type(4)));
 
-constexpr int kBlockM = 256;          // threads per grid point in this kernel: 4 wavefronts
-constexpr int kWavesM = kBlockM / 64;
+// Threads per grid point are chosen at launch: 256, or 768 for the LDS-footprint class that fits one
+// point per CU only (12 wavefronts = 3 per SIMD, the register budget).
+constexpr int kMaxBlockM = 768;
+#define kBlockM ((int)blockDim.x)
+#define kWavesM ((int)(blockDim.x >> 6))
 constexpr int kBand = 4;             // output rows per sweep work item
 constexpr int kOccM = 3;             // wavefronts per SIMD the register allocation must allow
 constexpr int kSlots = 16;           // MFMA M: 15 angles + ones
@@ -45,9 +48,9 @@ constexpr int kAnglesPerGroup = 15;
 constexpr float kMargin = 1e-5f;     // pre-filter margin (see header)
 
 struct MiscM {                       // LDS offset 0, kMiscMfmaBytes reserved
-    double red_d[8];
-    float red_f[8];
-    int red_i[8];
+    double red_d[16];
+    float red_f[16];
+    int red_i[16];
     u32 sel_key, sel_cle;
     int zero_flag;
     int best_key; float best_val;
@@ -72,7 +75,7 @@ struct Geo {
     long long r0, c0;                // window origin on image 2
     double c1, r1, nd;
 };
-constexpr int kGeoOff = 2432;
+constexpr int kGeoOff = 2560;
 static_assert(sizeof(MiscM) <= kGeoOff, "misc header too large");
 static_assert(kGeoOff + sizeof(Geo) <= kMiscMfmaBytes, "geometry block does not fit the LDS header");
 
@@ -143,7 +146,6 @@ __device__ __forceinline__ double block_sum(double v, MiscM *m) {
     if ((threadIdx.x & 63) == 0) m->red_d[threadIdx.x >> 6] = v;
     __syncthreads();
     double t = 0.0;
-#pragma unroll
     for (int w = 0; w < kWavesM; ++w) t += m->red_d[w];
     return t;
 }
@@ -153,7 +155,6 @@ __device__ __forceinline__ u32 block_min(u32 v, MiscM *m) {
     if ((threadIdx.x & 63) == 0) m->red_i[threadIdx.x >> 6] = (int)v;
     __syncthreads();
     u32 a = (u32)m->red_i[0];
-#pragma unroll
     for (int w = 1; w < kWavesM; ++w) { const u32 b = (u32)m->red_i[w]; a = a < b ? a : b; }
     return a;
 }
@@ -952,7 +953,7 @@ __device__ __noinline__ void ph_hessian(unsigned flags, int iy, int ix, float be
 }
 
 template <int S>
-__global__ __launch_bounds__(kBlockM, kOccM) void pm_kernel_mfma(const PMArgs A)
+__global__ __launch_bounds__(kMaxBlockM, kOccM) void pm_kernel_mfma(const PMArgs A)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     MiscM *m = reinterpret_cast<MiscM *>(smem);
@@ -1072,7 +1073,7 @@ __global__ __launch_bounds__(kBlockM, kOccM) void pm_kernel_mfma(const PMArgs A)
 
 bool mfma_img_size_supported(int s) { return s >= 2 && s + 15 <= 64; }
 
-int launch_pm_mfma(const PMArgs &args, int lds_bytes, void *stream)
+int launch_pm_mfma(const PMArgs &args, int lds_bytes, int nthreads, void *stream)
 {
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (args.n_launch <= 0) return (int)hipSuccess;
@@ -1082,7 +1083,8 @@ int launch_pm_mfma(const PMArgs &args, int lds_bytes, void *stream)
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(kern, dim3(args.n_launch), dim3(kBlockM), lds_bytes, st, args);
+    if (nthreads != 256 && nthreads != 384 && nthreads != 512 && nthreads != 768) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(kern, dim3(args.n_launch), dim3(nthreads), lds_bytes, st, args);
     return (int)hipGetLastError();
 }
 
