@@ -124,6 +124,15 @@ void make_rot(const double *angles, int n_angles, double alpha0, int s, const do
 }
 
 // window geometry of one point, the same arithmetic as the kernel (pmlib.py:200-202)
+// Workgroups of `lds` bytes that fit one CU.  gfx950 hands LDS out in 1280-byte granules (160 KB / 128;
+// measured with tools/ubench/lds_granule.hip: 53760 B -> 3 per CU, 53761 B -> 2).
+int blocks_per_cu(int lds)
+{
+    constexpr int kLdsGranule = 1280;
+    const int granules = (lds + kLdsGranule - 1) / kLdsGranule;
+    return granules > 0 ? (sid::max_lds_bytes() / kLdsGranule) / granules : 8;
+}
+
 bool window_dims(double c2fg, double r2fg, double border, int s, int64_t rows2, int64_t cols2,
                  int &wh, int &ww)
 {
@@ -335,7 +344,7 @@ SID_EXPORT int sid_pm_set_points(sid_pm_ctx *ctx, const double *c1, const double
             bytes += (double)wh * ww + 51.0 * 51.0 + 40.0 + 52.0;
             valid += 1;
         }
-        p.cls = std::min(8, sid::max_lds_bytes() / p.lds);
+        p.cls = std::min(8, blocks_per_cu(p.lds));
         lds_max = std::max(lds_max, p.lds);
         pts[(size_t)i] = p;
     }
@@ -411,7 +420,7 @@ SID_EXPORT int sid_pm_run(sid_pm_ctx *ctx)
         // 256 threads per point; 768 when the LDS footprint leaves room for one point per CU only, so that
         // the CU still carries 12 wavefronts (3 per SIMD = the register budget).  (Measured: 384- and
         // 512-thread groups lose to 2 x 256 - they do not pack onto the SIMDs and serialise the phases.)
-        const int per_cu = std::max(1, sid::max_lds_bytes() / b.lds);
+        const int per_cu = std::max(1, blocks_per_cu(b.lds));
         static const int force_nt = getenv("SID_PM_THREADS") ? atoi(getenv("SID_PM_THREADS")) : 0;   // A/B experiments
         const int nthreads = force_nt ? force_nt : (per_cu == 1 ? 768 : 256);
         const int e = ctx->kernel == KERNEL_DOT4 ? sid::launch_pm(A, b.lds, ctx->stream)
