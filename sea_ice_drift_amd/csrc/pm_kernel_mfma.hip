@@ -659,14 +659,6 @@ __device__ __forceinline__ void sweep_item(v4i (&acc)[kBand], const uint8_t *ap,
     }
 }
 
-// Cold path: the candidate queue is full (only with massive exact ties).  Out of line so that its
-// double-precision sqrt/divide sequence does not inflate the register allocation of the sweep.
-__device__ __noinline__ Score overflow_eval(Score sc, int p, int swp, u32 siiv, int key, double nd, double sT, double rTd, int cT)
-{
-    take_better(sc, exact_from_sums(p, swp, siiv, nd, sT, rTd, cT != 0), key);
-    return sc;
-}
-
 // ---------------------------------------------------------------------------------------------
 // Phase 2: angle-major sweep of one group.  Every wavefront takes work items wv, wv+W, ... and scores
 // the kBand x 16 x 15 results of each item:
@@ -756,6 +748,7 @@ __device__ __noinline__ Score ph_sweep(Score sc, int a0, int Kg, long long *dbg_
         sc.lmax = fmaxf(sc.lmax, wavemax);
         if (need_b) {
             const float thr = sc.lmax - kMargin;
+            u32 ovf = 0;                                              // candidates that found the queue full
 #pragma unroll
             for (int t = 0; t < kBand; ++t) {
                 float e[4];
@@ -767,8 +760,32 @@ __device__ __noinline__ Score ph_sweep(Score sc, int a0, int Kg, long long *dbg_
                         const int key = ((a0 + a) * rh + y0 + t) * rw + x;
                         const u32 slot = atomicAdd(&m->qcount, 1u);
                         if (slot < (u32)kQueueCap) queue[slot] = make_uint4((u32)acc[t][r], (u32)swp[t], siiv[t], (u32)key);
-                        else sc = overflow_eval(sc, acc[t][r], swp[t], siiv[t], key, nd, sT4[r], m->rTd[a0 + a], m->constT[a0 + a]);
+                        else ovf |= 1u << (4 * t + r);
                     }
+                }
+            }
+            // Cold path (queue full: massive exact ties, flat windows): evaluate the left-over candidates
+            // here, one at a time.  A rolled loop with one copy of the double-precision sequence and
+            // operand selection by compare chains - no call, so the sweep stays a leaf function and
+            // needs no callee-saved registers.
+            if (ovf) {
+#pragma unroll 1
+                for (int b = 0; b < 4 * kBand; ++b) {
+                    if (!((ovf >> b) & 1u)) continue;
+                    const int t = b >> 2, r = b & 3;
+                    int pv = 0, sw = 0; u32 si = 0; double sTr = 0.0;
+#pragma unroll
+                    for (int tt = 0; tt < kBand; ++tt) {
+                        sw = t == tt ? swp[tt] : sw;
+                        si = t == tt ? siiv[tt] : si;
+#pragma unroll
+                        for (int rr = 0; rr < 4; ++rr) pv = b == 4 * tt + rr ? acc[tt][rr] : pv;
+                    }
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr) sTr = r == rr ? sT4[rr] : sTr;
+                    const int a = 4 * q_l + r;
+                    const int key = ((a0 + a) * rh + y0 + t) * rw + x;
+                    take_better(sc, exact_from_sums(pv, sw, si, nd, sTr, m->rTd[a0 + a], m->constT[a0 + a] != 0), key);
                 }
             }
         }
