@@ -173,6 +173,19 @@ def main():
         kern_s = kern_ms * 1e-3
         hbm_achieved = info['hbm_bytes'] / kern_s / 1e9
         mfma_achieved = 2.0 * info['macs'] / kern_s / 1e12
+        # HBM traffic per launch from the committed PMC profile (rocprofv3 cannot run inside this process);
+        # only quoted when the profile was collected on this very workload
+        traffic, traffic_note = None, 'no PMC profile for this workload under profiles/'
+        try:
+            with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'traffic.json')) as fh:
+                tj = json.load(fh)
+            if tj.get('workload') == {'size': args.size, 'grid': args.grid, 'angles': args.angles,
+                                      'border': args.border if args.border == 'mixed' else int(args.border),
+                                      'img_size': s}:
+                traffic = tj['hbm_bytes_per_launch'] * tj['launches_per_step'] / launches
+                traffic_note = 'bytes per launch, PMC FETCH_SIZE x2 + WRITE_SIZE (profiles/traffic.json): ' + tj['note']
+        except (OSError, ValueError, KeyError):
+            pass
         line = {
             'metric': 'PM grid-points/sec (10000x10000 px pair, 34px template)',
             'value': value, 'unit': 'grid-points/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
@@ -186,7 +199,7 @@ def main():
             'roofline': {
                 # the sweep runs on v_mfma_i32_16x16x64_i8: the matrix cores are the roofline that bounds it
                 'bound': 'mfma', 'achieved': mfma_achieved, 'peak': MFMA_I8_PEAK_TOPS, 'unit': 'TFLOP/s',
-                'frac': mfma_achieved / MFMA_I8_PEAK_TOPS, 'traffic': None,
+                'frac': mfma_achieved / MFMA_I8_PEAK_TOPS, 'traffic': traffic, 'traffic_note': traffic_note,
                 'kernel': 'sid::pm_kernel_mfma<%d>' % (s if s in (34, 35) else 0), 'launches_per_step': launches,
                 'kernel_ms_per_step': kern_ms, 'avg_launch_ms': kern_ms / launches,
                 'algorithmic_macs_per_step': info['macs'], 'algorithmic_bytes_per_step': info['hbm_bytes'],
