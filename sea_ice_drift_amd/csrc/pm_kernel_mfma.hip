@@ -71,7 +71,8 @@ struct Geo {
     int wh, ww, rh, rw, npos, wpitch, arow, s, K;
     int win_off, sii_off, u_off, patch_off, ppitch, pdim, pradius, queue_off, trow_bytes;
     int pr0, pc0;                    // patch origin on image 1
-    int pad_;
+    u32 win_magic;                   // floor(2^32 / (wpitch/4)) + 1: idx / (wpitch/4) == umulhi(idx, win_magic) for idx < 2^16
+    u32 patch_magic, pad_[2];        // same for ppitch/4
     long long r0, c0;                // window origin on image 2
     double c1, r1, nd;
 };
@@ -266,35 +267,43 @@ __device__ __noinline__ void ph_window(const uint8_t *img2, long long rows2, lon
     SID_PHASE_LOCALS;
     uint8_t *win = smem + G.win_off;
     const int wpitch = G.wpitch, ww = G.ww, wh = G.wh;
-    const long long r0 = G.r0, c0 = G.c0;
-    const int dw_per_row = wpitch / 4, ndw = (wh + kBand - 1) * dw_per_row;    // + kBand-1 zero rows below
-    const uintptr_t last_dw = (reinterpret_cast<uintptr_t>(img2 + (rows2 - 1) * stride2 + cols2) - 1) & ~(uintptr_t)3;
+    const int dw_per_row = wpitch >> 2, ndw = (wh + kBand - 1) * dw_per_row;    // + kBand-1 zero rows below
+    const u32 magic = G.win_magic;
+    const int st = (int)stride2;
+    // all addresses as 32-bit offsets from the (dword-aligned) window origin: no 64-bit multiplies, no divisions
+    const uint8_t *org = img2 + G.r0 * stride2 + G.c0;
+    const u32 mis = (u32)(reinterpret_cast<uintptr_t>(org) & 3);
+    const uint8_t *org4 = org - mis;
+    const long long last_ll = (long long)((reinterpret_cast<uintptr_t>(img2 + (rows2 - 1) * stride2 + cols2) - 1) & ~(uintptr_t)3) -
+                              (long long)reinterpret_cast<uintptr_t>(org4);
+    const u32 last_off = last_ll > 0x7ffffff0ll ? 0x7ffffff0u : (u32)last_ll;  // offset of the last legal dword
     for (int base = 0; base < ndw; base += 4 * kBlockM) {
         u32 lo[4], hi[4], shv[4];
+        int rowv[4], dqv[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int idx = base + u * kBlockM + tid;
             const int idc = idx < ndw ? idx : 0;
-            int row = idc / dw_per_row;
+            const int row = (int)__umulhi((u32)idc, magic);
             const int dq = idc - row * dw_per_row;
-            row = row < wh ? row : wh - 1;                             // clamp so that the loads are always legal
+            rowv[u] = row; dqv[u] = dq;
+            const int rc = row < wh ? row : wh - 1;                    // clamp so that the loads are always legal
             const int dqc = 4 * dq < ww ? dq : 0;
-            const uint8_t *gp = img2 + (r0 + row) * stride2 + c0 + 4 * dqc;
-            const uintptr_t ga = reinterpret_cast<uintptr_t>(gp) & ~(uintptr_t)3;
-            const uintptr_t gb = ga + 4 <= last_dw ? ga + 4 : last_dw;
-            shv[u] = (u32)(reinterpret_cast<uintptr_t>(gp) & 3);
-            lo[u] = *reinterpret_cast<const u32 *>(ga);
-            hi[u] = *reinterpret_cast<const u32 *>(gb);
+            const u32 o = (u32)(rc * st + 4 * dqc) + mis;
+            const u32 oa = o & ~3u;
+            const u32 ob = oa + 4 <= last_off ? oa + 4 : last_off;
+            shv[u] = o & 3u;
+            lo[u] = *reinterpret_cast<const u32 *>(org4 + oa);
+            hi[u] = *reinterpret_cast<const u32 *>(org4 + ob);
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int idx = base + u * kBlockM + tid;
             if (idx < ndw) {
-                const int row = idx / dw_per_row, dq = idx - row * dw_per_row;
                 u32 v = __builtin_amdgcn_alignbyte(hi[u], lo[u], shv[u]) ^ 0x80808080u;
-                const int nvalid = row < wh ? ww - 4 * dq : 0;
+                const int nvalid = rowv[u] < wh ? ww - 4 * dqv[u] : 0;
                 if (nvalid < 4) v = nvalid > 0 ? (v & ((1u << (8 * nvalid)) - 1u)) : 0u;
-                reinterpret_cast<u32 *>(win + row * wpitch)[dq] = v;
+                reinterpret_cast<u32 *>(win)[idx] = v;                 // idx == row * dw_per_row + dq
             }
         }
     }
@@ -348,6 +357,42 @@ __device__ __noinline__ void ph_patch(const uint8_t *img1, long long rows1, long
     uint8_t *patch = smem + G.patch_off;
     const int pdim = G.pdim, ppitch = G.ppitch, np = pdim * pdim;
     const long long pr0 = G.pr0, pc0 = G.pc0;
+    if (pr0 >= 0 && pc0 >= 0 && pr0 + pdim <= rows1 && pc0 + ppitch <= cols1) {
+        // the patch lies inside image 1 (block-uniform): dword loads re-aligned in registers, 32-bit offsets,
+        // division by the row pitch through the precomputed reciprocal
+        const int pdw = ppitch >> 2, ndw = pdim * pdw;
+        const u32 magic = G.patch_magic;
+        const int st = (int)stride1;
+        const uint8_t *org = img1 + pr0 * stride1 + pc0;
+        const u32 mis = (u32)(reinterpret_cast<uintptr_t>(org) & 3);
+        const uint8_t *org4 = org - mis;
+        const long long last_ll = (long long)((reinterpret_cast<uintptr_t>(img1 + (rows1 - 1) * stride1 + cols1) - 1) & ~(uintptr_t)3) -
+                                  (long long)reinterpret_cast<uintptr_t>(org4);
+        const u32 last_off = last_ll > 0x7ffffff0ll ? 0x7ffffff0u : (u32)last_ll;
+        for (int base = 0; base < ndw; base += 4 * kBlockM) {
+            u32 lo[4], hi[4], shv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int idx = base + u * kBlockM + tid;
+                const int idc = idx < ndw ? idx : 0;
+                const int row = (int)__umulhi((u32)idc, magic);
+                const int dq = idc - row * pdw;
+                const u32 o = (u32)(row * st + 4 * dq) + mis;
+                const u32 oa = o & ~3u;
+                const u32 ob = oa + 4 <= last_off ? oa + 4 : last_off;
+                shv[u] = o & 3u;
+                lo[u] = *reinterpret_cast<const u32 *>(org4 + oa);
+                hi[u] = *reinterpret_cast<const u32 *>(org4 + ob);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int idx = base + u * kBlockM + tid;
+                if (idx < ndw) reinterpret_cast<u32 *>(patch)[idx] = __builtin_amdgcn_alignbyte(hi[u], lo[u], shv[u]);
+            }
+        }
+        return;
+    }
+    // near the image border: byte loads with clamped coordinates
     for (int base = 0; base < np; base += 8 * kBlockM) {
         uint8_t pv[8];
 #pragma unroll
@@ -683,13 +728,15 @@ __device__ __noinline__ Score ph_sweep(Score sc, int a0, int Kg, long long *dbg_
     const uint8_t *abase = zero_a ? afrag + s * arow : afrag + lane * 16;
     const int arow_l = zero_a ? 0 : arow;
 
-    double sT4[4];
-    float rT4[4];
+    // estimate of slot r at a placement: float(acc * A4[r] - Sw' * B4[r]) * rsq(dI), with the template's
+    // 1/sqrt(dT) folded into both per-slot factors (NaN for a constant template => always a candidate)
+    double A4[4], B4[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int a = 4 * q_l + r;
-        sT4[r] = a < Kg ? m->sTd[a0 + a] : 0.0;
-        rT4[r] = a < Kg ? m->rTf[a0 + a] : 0.0f;
+        const double rTa = a < Kg ? (m->constT[a0 + a] ? (double)NAN : m->rTd[a0 + a]) : 0.0;
+        A4[r] = nd * rTa;
+        B4[r] = (a < Kg ? m->sTd[a0 + a] : 0.0) * rTa;
     }
     const u32 livebits = (4 * q_l + 0 < Kg ? 1u : 0u) | (4 * q_l + 1 < Kg ? 2u : 0u) |
                          (4 * q_l + 2 < Kg ? 4u : 0u) | (4 * q_l + 3 < Kg ? 8u : 0u);
@@ -729,8 +776,7 @@ __device__ __noinline__ Score ph_sweep(Score sc, int a0, int Kg, long long *dbg_
             const u32 lv = (xok & (y0 + t < rh)) ? livebits : 0u;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const double numer = nd * (double)acc[t][r] - swd * sT4[r];   // exact
-                const float v = ((float)numer * rIf) * rT4[r];
+                const float v = (float)__builtin_fma((double)acc[t][r], A4[r], -(swd * B4[r])) * rIf;
                 e[r] = ((lv >> r) & 1u) ? v : -INFINITY;
             }
         };
@@ -773,7 +819,7 @@ __device__ __noinline__ Score ph_sweep(Score sc, int a0, int Kg, long long *dbg_
                 for (int b = 0; b < 4 * kBand; ++b) {
                     if (!((ovf >> b) & 1u)) continue;
                     const int t = b >> 2, r = b & 3;
-                    int pv = 0, sw = 0; u32 si = 0; double sTr = 0.0;
+                    int pv = 0, sw = 0; u32 si = 0;
 #pragma unroll
                     for (int tt = 0; tt < kBand; ++tt) {
                         sw = t == tt ? swp[tt] : sw;
@@ -781,11 +827,9 @@ __device__ __noinline__ Score ph_sweep(Score sc, int a0, int Kg, long long *dbg_
 #pragma unroll
                         for (int rr = 0; rr < 4; ++rr) pv = b == 4 * tt + rr ? acc[tt][rr] : pv;
                     }
-#pragma unroll
-                    for (int rr = 0; rr < 4; ++rr) sTr = r == rr ? sT4[rr] : sTr;
                     const int a = 4 * q_l + r;
                     const int key = ((a0 + a) * rh + y0 + t) * rw + x;
-                    take_better(sc, exact_from_sums(pv, sw, si, nd, sTr, m->rTd[a0 + a], m->constT[a0 + a] != 0), key);
+                    take_better(sc, exact_from_sums(pv, sw, si, nd, m->sTd[a0 + a], m->rTd[a0 + a], m->constT[a0 + a] != 0), key);
                 }
             }
         }
@@ -1010,6 +1054,7 @@ __global__ __launch_bounds__(kMaxBlockM, kOccM) void pm_kernel_mfma(const PMArgs
         G->ppitch = L.ppitch; G->pdim = L.pdim; G->pradius = L.pradius; G->queue_off = L.queue_off;
         G->trow_bytes = L.trow_bytes;
         G->pr0 = (int)floor(r1) - L.pradius; G->pc0 = (int)floor(c1) - L.pradius;
+        G->win_magic = 0xffffffffu / (u32)(L.wpitch >> 2) + 1u; G->patch_magic = 0xffffffffu / (u32)(L.ppitch >> 2) + 1u;
         G->r0 = r0; G->c0 = c0; G->c1 = c1; G->r1 = r1; G->nd = (double)(s * s);
         m->zero_flag = 0; m->gmax_key = 0x007fffffu /* f2key(-inf) */; m->qcount = 0;
     }
