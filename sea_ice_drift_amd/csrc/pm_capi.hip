@@ -87,6 +87,8 @@ struct sid_pm_ctx {
     DevBuf<double> vec;                 // 5 * n
     DevBuf<int32_t> order;
     DevBuf<double> angles, rot;
+    DevBuf<uint16_t> samp;              // sampling table of the MFMA kernel (make_samp)
+    bool have_samp = false;             // SID_PM_NO_SAMP_TABLE=1 keeps the on-the-fly sampling (A/B runs, tests)
     DevBuf<double> out;
     DevBuf<int32_t> out_ij;
     double *user_out = nullptr;         // caller-owned result arrays (bind_results)
@@ -120,6 +122,39 @@ void make_rot(const double *angles, int n_angles, double alpha0, int s, const do
         rot[4 * k + 0] = ca; rot[4 * k + 1] = sa;
         rot[4 * k + 2] = tc * ca + tc * sa;
         rot[4 * k + 3] = tc * (-sa) + tc * ca;
+    }
+}
+
+// Sampling table of the MFMA kernel.  The reference rounds the template centres to integers before the
+// dispatch (pmlib.py:401), and for an integral centre (R, C) the nearest-neighbour sample positions of
+// get_template (pmlib.py:105-113; scipy order 0: floor(x + 0.5)) are those of the centre (0, 0) shifted by
+// (R, C) - unless a coordinate lies so close to k + 1/2 that the float64 roundings at the magnitude of R
+// could tip it.  Those entries (|frac - boundary| < kSampGuard; expected: none or a handful per table) carry
+// a flag and are recomputed per point in the kernel with the reference's operation order.
+// Entry = (row + pradius) * ppitch + (col + pradius): the byte offset inside the kernel's LDS patch.
+void make_samp(const std::vector<double> &rot, int K, int s, std::vector<uint16_t> &tab)
+{
+    const sid::MfmaLdsLayout L = sid::mfma_lds_layout(s + 1, s + 1, s);
+    const int sp = sid::samp_pitch(s);
+    tab.assign((size_t)K * s * sp, 0);
+    for (int k = 0; k < K; ++k) {
+        const double cosa = rot[4 * k + 0], sina = rot[4 * k + 1];
+        const double off0 = 0.0 - rot[4 * k + 2], off1 = 0.0 - rot[4 * k + 3];
+        for (int i = 0; i < s; ++i)
+            for (int j = 0; j < s; ++j) {
+                double rr = 0.0 + (double)i * cosa;                    // NI_GeometricTransform order (matrix = transform.T)
+                rr = rr + (double)j * sina;
+                rr = rr + off0;
+                double cc = 0.0 + (double)i * (-sina);
+                cc = cc + (double)j * cosa;
+                cc = cc + off1;
+                const double fr = floor(rr + 0.5), fc = floor(cc + 0.5);
+                const double dr = (rr + 0.5) - fr, dc = (cc + 0.5) - fc;
+                bool doubt = !(dr >= sid::kSampGuard && dr <= 1.0 - sid::kSampGuard && dc >= sid::kSampGuard && dc <= 1.0 - sid::kSampGuard);
+                int pr = (int)fr + L.pradius, pc = (int)fc + L.pradius;
+                if (!(pr >= 0 && pr < L.pdim && pc >= 0 && pc < L.pdim)) { pr = 0; pc = 0; doubt = true; }
+                tab[((size_t)k * s + i) * sp + j] = (uint16_t)((pr * L.ppitch + pc) | (doubt ? 0x8000 : 0));
+            }
     }
 }
 
@@ -188,7 +223,7 @@ int fill_args(sid_pm_ctx *ctx, sid::PMArgs &A)
     A.c1 = ctx->vec.p; A.r1 = ctx->vec.p + n; A.c2fg = ctx->vec.p + 2 * n; A.r2fg = ctx->vec.p + 3 * n;
     A.border = ctx->vec.p + 4 * n;
     A.img_size = ctx->img_size; A.n_angles = ctx->n_angles; A.flags = ctx->flags;
-    A.angles = ctx->angles.p; A.rot = ctx->rot.p;
+    A.angles = ctx->angles.p; A.rot = ctx->rot.p; A.samp = ctx->have_samp ? ctx->samp.p : nullptr;
     A.out = ctx->user_out ? ctx->user_out : ctx->out.p;
     A.out_ij = ctx->user_out ? ctx->user_ij : ctx->out_ij.p;
     return SID_PM_OK;
@@ -251,7 +286,7 @@ SID_EXPORT void sid_pm_destroy(sid_pm_ctx *ctx)
     Guard g(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     for (auto &pair : ctx->own) for (auto &b : pair) b.release();
-    ctx->vec.release(); ctx->order.release(); ctx->angles.release(); ctx->rot.release();
+    ctx->vec.release(); ctx->order.release(); ctx->angles.release(); ctx->rot.release(); ctx->samp.release();
     ctx->out.release(); ctx->out_ij.release();
     delete ctx;
 }
@@ -366,7 +401,10 @@ SID_EXPORT int sid_pm_set_points(sid_pm_ctx *ctx, const double *c1, const double
 
     std::vector<double> rotv;
     make_rot(angles, K, alpha0, s, rot, rotv);
+    std::vector<uint16_t> sampv;
+    if (ctx->kernel == KERNEL_MFMA && !getenv("SID_PM_NO_SAMP_TABLE")) make_samp(rotv, K, s, sampv);
 
+    if (int rc = ctx->samp.reserve(sampv.size() + 4)) return rc;
     if (int rc = ctx->vec.reserve((size_t)(5 * n))) return rc;
     if (int rc = ctx->order.reserve((size_t)n)) return rc;
     if (int rc = ctx->angles.reserve((size_t)K)) return rc;
@@ -381,6 +419,8 @@ SID_EXPORT int sid_pm_set_points(sid_pm_ctx *ctx, const double *c1, const double
     if (n > 0) HIP_TRY(hipMemcpy(ctx->order.p, order.data(), sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(ctx->angles.p, angles, sizeof(double) * (size_t)K, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(ctx->rot.p, rotv.data(), sizeof(double) * rotv.size(), hipMemcpyHostToDevice));
+    if (!sampv.empty()) HIP_TRY(hipMemcpy(ctx->samp.p, sampv.data(), sizeof(uint16_t) * sampv.size(), hipMemcpyHostToDevice));
+    ctx->have_samp = !sampv.empty();
 
     ctx->user_out = nullptr; ctx->user_ij = nullptr;
     ctx->n = n; ctx->img_size = s; ctx->n_angles = K; ctx->flags = flags;
@@ -515,16 +555,20 @@ SID_EXPORT int sid_pm_debug_point(sid_pm_ctx *ctx, double c1, double r1, double 
     DevBuf<double> dv, dang, drot, dout;
     DevBuf<int32_t> dord, dij, dshape;
     DevBuf<uint8_t> dt;
+    DevBuf<uint16_t> dsamp;
+    std::vector<uint16_t> sampv;
+    if (ctx->kernel == KERNEL_MFMA && !getenv("SID_PM_NO_SAMP_TABLE")) make_samp(rotv, K, s, sampv);
     DevBuf<float> dccm, dhes;
     DevBuf<long long> dcyc;
     int rc = SID_PM_OK;
     auto cleanup = [&]() { dv.release(); dang.release(); drot.release(); dout.release(); dord.release();
-                           dij.release(); dshape.release(); dt.release(); dccm.release(); dhes.release(); dcyc.release(); };
+                           dij.release(); dshape.release(); dt.release(); dccm.release(); dhes.release(); dcyc.release(); dsamp.release(); };
     const size_t tcount = (size_t)K * s * s;
     if ((rc = dv.reserve(5)) || (rc = dang.reserve((size_t)K)) || (rc = drot.reserve(4 * (size_t)K)) ||
         (rc = dout.reserve(5)) || (rc = dord.reserve(1)) || (rc = dij.reserve(3)) || (rc = dshape.reserve(2)) ||
         (rc = dt.reserve(tcount)) || (rc = dccm.reserve((size_t)std::max<int64_t>(cap, 1))) ||
-        (rc = dhes.reserve((size_t)std::max<int64_t>(cap, 1))) || (rc = dcyc.reserve(16))) { cleanup(); return rc; }
+        (rc = dhes.reserve((size_t)std::max<int64_t>(cap, 1))) || (rc = dcyc.reserve(16)) ||
+        (rc = dsamp.reserve(sampv.size() + 4))) { cleanup(); return rc; }
     const double v5[5] = {c1, r1, c2fg, r2fg, border};
     const int32_t zero = 0, shape0[2] = {0, 0};
     hipError_t e = hipSuccess;
@@ -534,6 +578,7 @@ SID_EXPORT int sid_pm_debug_point(sid_pm_ctx *ctx, double c1, double r1, double 
     step(hipMemcpy(dang.p, angles, sizeof(double) * K, hipMemcpyHostToDevice));
     step(hipMemcpy(drot.p, rotv.data(), sizeof(double) * rotv.size(), hipMemcpyHostToDevice));
     step(hipMemcpy(dord.p, &zero, sizeof zero, hipMemcpyHostToDevice));
+    if (!sampv.empty()) step(hipMemcpy(dsamp.p, sampv.data(), sizeof(uint16_t) * sampv.size(), hipMemcpyHostToDevice));
     step(hipMemcpy(dshape.p, shape0, sizeof shape0, hipMemcpyHostToDevice));
     step(hipMemset(dt.p, 0, tcount));
     step(hipMemset(dcyc.p, 0, sizeof(long long) * 16));
@@ -548,6 +593,7 @@ SID_EXPORT int sid_pm_debug_point(sid_pm_ctx *ctx, double c1, double r1, double 
         A.angles = dang.p; A.rot = drot.p; A.out = dout.p; A.out_ij = dij.p;
         A.dbg_templates = dt.p; A.dbg_ccm = dccm.p; A.dbg_hes = dhes.p; A.dbg_shape = dshape.p; A.dbg_cap = cap;
         A.dbg_cycles = dcyc.p;
+        A.samp = sampv.empty() ? nullptr : dsamp.p;
         step((hipError_t)(ctx->kernel == KERNEL_DOT4 ? sid::launch_pm(A, lds, ctx->stream)
                                                      : sid::launch_pm_mfma(A, lds, getenv("SID_PM_THREADS") ? atoi(getenv("SID_PM_THREADS")) : 256, ctx->stream)));
         step(hipStreamSynchronize(ctx->stream));

@@ -21,6 +21,9 @@ struct PMArgs {
     uint32_t flags;
     const double *angles;                           // [K] degrees (reported as-is)
     const double *rot;                              // [K][4] cos, sin, tcT0, tcT1
+    // MFMA kernel: sampling table [K][s][samp_pitch(s)] of LDS patch offsets for integral template centres
+    // (bit 15: coordinate too close to a rounding boundary - redo in double); null = always sample on the fly
+    const uint16_t *samp;
     double *out;                                    // [n_total][5]
     int32_t *out_ij;                                // [n_total][3]
     // diagnostics (debug_point only; null in production launches)
@@ -101,6 +104,9 @@ __host__ __device__ inline MfmaLdsLayout mfma_lds_layout(int wh, int ww, int s)
     L.total = round_up(L.u_off + u, 16);
     return L;
 }
+
+__host__ __device__ inline int samp_pitch(int s) { return round_up(s, 4); }
+constexpr double kSampGuard = 1e-5;   // table entries whose coordinate is this close to k + 1/2 are flagged
 
 int launch_pm_mfma(const PMArgs &args, int lds_bytes, int nthreads, void *stream);
 bool mfma_img_size_supported(int s);

@@ -507,13 +507,35 @@ __device__ __forceinline__ u32 sample_fast5(const SampleGeom &g, const double *r
     return doubt;
 }
 
+// Table path (integral template centre, patch inside image 1): four samples of one template row through the
+// host-built offset table (pm_capi.hip make_samp).  Returns the packed raw pixels j = 4*jq .. 4*jq+3.
+__device__ __forceinline__ u32 sample_quad(const SampleGeom &g, const uint2 e, const double *rot4, int i, int jq)
+{
+    const uint8_t *patch = g.patch;
+    u32 raw = (u32)patch[e.x & 0x7fffu] | ((u32)patch[(e.x >> 16) & 0x7fffu] << 8) |
+              ((u32)patch[e.y & 0x7fffu] << 16) | ((u32)patch[(e.y >> 16) & 0x7fffu] << 24);
+    if ((e.x | e.y) & 0x80008000u) {                                   // rare: redo flagged samples in double
+        const u32 fl = ((e.x >> 15) & 1u) | ((e.x >> 30) & 2u) | (((e.y >> 15) & 1u) << 2) | ((e.y >> 28) & 8u);
+        for (int q = 0; q < 4; ++q)
+            if (((fl >> q) & 1u) && 4 * jq + q < g.s) {
+                const u32 v = (u32)sample_exact(g, rot4, i, 4 * jq + q);
+                raw = (raw & ~(0xffu << (8 * q))) | (v << (8 * q));
+            }
+    }
+    return raw;
+}
+__device__ __forceinline__ bool table_usable(const SampleGeom &g)
+{
+    return g.inside && g.c1 == floor(g.c1) && g.r1 == floor(g.r1) && fabs(g.c1) < 1e9 && fabs(g.r1) < 1e9;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Phase 0c: operands of one group of <= 15 angles.  afrag[i][lane = g*16 + slot][16 bytes], byte jj
 // <-> column c = 16 g + jj; slot 15 is the all-ones template; row s is all zero.
 // ---------------------------------------------------------------------------------------------
 template <int S>
-__device__ __noinline__ void ph_templates(const double *rot, int a0, int Kg, long long rows1, long long cols1,
-                                          uint8_t *dbg_templates, long long *dbg_cycles)
+__device__ __noinline__ void ph_templates(const double *rot, const uint16_t *samp, int a0, int Kg, long long rows1,
+                                          long long cols1, uint8_t *dbg_templates, long long *dbg_cycles)
 {
     SID_PHASE_LOCALS;
     uint8_t *afrag = smem + G.u_off;
@@ -584,7 +606,30 @@ __device__ __noinline__ void ph_templates(const double *rot, int a0, int Kg, lon
             dlo = 0; dhi = 0;
         }
     };
-    if (g.inside) run(std::true_type{}); else run(std::false_type{});
+    if (samp && table_usable(g)) {
+        // one wavefront per angle: four samples per lane and step through the offset table, one dword store
+        // into the operand table; pixel sums by v_dot4 on the packed raw bytes, converted to the re-centred
+        // domain per angle: sum(v-128) = sum v - 128 N, sum(v-128)^2 = sum v^2 - 256 sum v + 16384 N
+        const int sp = samp_pitch(s), nq = sp >> 2, upa = s * nq;
+        const u32 tailmask = (s & 3) ? (1u << (8 * (s & 3))) - 1u : 0xffffffffu;
+        for (int a = wv; a < Kg; a += kWavesM) {
+            const uint2 *ta = reinterpret_cast<const uint2 *>(samp + (size_t)(a0 + a) * s * sp);
+            u32 sv = 0, svv = 0, zero = 0;
+            for (int u = lane; u < upa; u += 64) {
+                const int i = u / nq, jq = u - i * nq;
+                const u32 vm = jq == nq - 1 ? tailmask : 0xffffffffu;
+                const u32 raw = sample_quad(g, ta[u], m->rot[a], i, jq) & vm;
+                const u32 z = raw | ~vm;
+                zero |= (z - 0x01010101u) & ~z & 0x80808080u;          // some valid byte == 0
+                sv = __builtin_amdgcn_udot4(raw, 0x01010101u, sv, false);
+                svv = __builtin_amdgcn_udot4(raw, raw, svv, false);
+                *reinterpret_cast<u32 *>(afrag + i * arow + (jq >> 2) * 256 + a * 16 + (jq & 3) * 4) = (raw ^ 0x80808080u) & vm;
+            }
+            const int ws = wave_sum_dpp((int)sv), wss = wave_sum_dpp((int)svv);
+            if (lane == 0) { m->isT[a] = ws - 128 * s * s; m->isTT[a] = wss - 256 * ws + 16384 * s * s; }
+            sawzero |= zero != 0u ? 1 : 0;
+        }
+    } else if (g.inside) run(std::true_type{}); else run(std::false_type{});
 #else
     (void)anydoubt; (void)dump;
 #endif
@@ -858,7 +903,8 @@ __device__ __noinline__ Score ph_sweep(Score sc, int a0, int Kg, long long *dbg_
 // trow[g][16 + i][16 B] holds the winner's template, trow1 the all-ones one; zero rows around.
 // ---------------------------------------------------------------------------------------------
 template <int S>
-__device__ __noinline__ void ph_winner(const double *rot4, long long rows1, long long cols1, int ka, long long *dbg_cycles)
+__device__ __noinline__ void ph_winner(const double *rot4, const uint16_t *samp, long long rows1, long long cols1, int ka,
+                                       long long *dbg_cycles)
 {
     SID_PHASE_LOCALS;
     const uint8_t *win = smem + G.win_off;
@@ -882,6 +928,19 @@ __device__ __noinline__ void ph_winner(const double *rot4, long long rows1, long
             trow[off] = (uint8_t)(v ^ 0x80);
             trow1[off] = take ? 1 : 0;
         };
+        if (samp && table_usable(g)) {
+            const int sp = samp_pitch(s), nq = sp >> 2, upa = s * nq;
+            const u32 tailmask = (s & 3) ? (1u << (8 * (s & 3))) - 1u : 0xffffffffu;
+            const uint2 *ta = reinterpret_cast<const uint2 *>(samp + (size_t)ka * s * sp);
+            for (int u = tid; u < upa; u += kBlockM) {
+                const int i = u / nq, jq = u - i * nq;
+                const u32 vm = jq == nq - 1 ? tailmask : 0xffffffffu;
+                const u32 raw = sample_quad(g, ta[u], m->rot[0], i, jq);
+                const int off = ((jq >> 2) * trows + 16 + i) * 16 + (jq & 3) * 4;
+                *reinterpret_cast<u32 *>(trow + off) = (raw ^ 0x80808080u) & vm;
+                *reinterpret_cast<u32 *>(trow1 + off) = 0x01010101u & vm;
+            }
+        } else
         for (int k0 = 0; k0 * g.ngrp < s; k0 += kRowsPerThread) {
             int st = 0, stt = 0, sz = 0;
             const u32 db = sample_fast5<false>(g, m->rot[0], true, k0, st, stt, sz,
@@ -1072,7 +1131,7 @@ __global__ __launch_bounds__(kMaxBlockM, kOccM) void pm_kernel_mfma(const PMArgs
     Score sc{-INFINITY, -INFINITY, 0x7fffffff};
     for (int a0 = 0; a0 < K; a0 += kAnglesPerGroup) {
         const int Kg = (K - a0) < kAnglesPerGroup ? (K - a0) : kAnglesPerGroup;
-        ph_templates<S>(A.rot, a0, Kg, A.rows1, A.cols1, A.dbg_templates, A.dbg_cycles);
+        ph_templates<S>(A.rot, A.samp, a0, Kg, A.rows1, A.cols1, A.dbg_templates, A.dbg_cycles);
         if (m->zero_flag) {                                            // pmlib.py:152-154
             if (tid < 5) out[tid] = NAN;
             if (oij && tid < 3) oij[tid] = -1;
@@ -1113,7 +1172,7 @@ __global__ __launch_bounds__(kMaxBlockM, kOccM) void pm_kernel_mfma(const PMArgs
     SID_STAMP(5);
 
 #ifndef SID_ABLATE_WINNER
-    ph_winner<S>(A.rot + 4 * ka, A.rows1, A.cols1, ka, A.dbg_cycles);
+    ph_winner<S>(A.rot + 4 * ka, A.samp, A.rows1, A.cols1, ka, A.dbg_cycles);
 #endif
     SID_STAMP(6);
     if (A.dbg_shape && tid == 0) { A.dbg_shape[0] = rh; A.dbg_shape[1] = rw; }
