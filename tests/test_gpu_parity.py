@@ -51,6 +51,31 @@ def test_small_pair_matches_oracle(pm_ctx, c_oracle, s, alpha0, angles):
     assert_parity(got, got_ij, exp, exp_ij)
 
 
+def test_sampling_table_flagged_entries_and_fractional_centres(pm_ctx, c_oracle):
+    """The offset table serves integral template centres; entries whose coordinate sits on a rounding
+    boundary are flagged and recomputed per point (forced here with tc.T = 17.5: every row coordinate is
+    k + 1/2), and fractional centres / templates at the image border take the on-the-fly path.  All must
+    equal the oracle (get_template, pmlib.py:105-113)."""
+    img1, img2 = syn.make_pair(600, 600, seed=21)
+    g = syn.make_grid(600, 600, 10, margin=90)
+    s, angles = 34, [-2.0, 0.0, 2.0]
+    rot = rot_for(angles, 0.0, s)
+    rot[1] = [1.0, 0.0, 17.5, 18.0]                  # caller-supplied terms: rr = i - 17.5 + r1 -> floor(rr + .5) on the boundary
+    c1, r1 = g['c1'].copy(), g['r1'].copy()
+    c1[::3] += 0.3                                   # fractional centres (on-the-fly path)
+    r1[::3] -= 0.45
+    c1[1], r1[1] = 10.0, 300.0                       # patch reaches over the left image edge -> zero pixels -> NaN
+    c1[2], r1[2] = 40.0, 41.0                        # integral centre, patch not inside the image: on-the-fly path
+    exp, exp_ij = c_oracle.pm_batch(img1, img2, c1, r1, g['c2fg'], g['r2fg'], g['border'], s, 0.0, angles, rot=rot,
+                                    nthreads=8)
+    pm_ctx.upload_pair(img1, img2)
+    pm_ctx.set_points(c1, r1, g['c2fg'], g['r2fg'], g['border'], s, 0.0, angles, rot=rot)
+    pm_ctx.run()
+    got, got_ij = pm_ctx.fetch()
+    assert_parity(got, got_ij, exp, exp_ij)
+    assert np.isnan(exp[1, 0]) and (exp_ij[:, 2] == 1).any()           # the edge case fired, the boundary angle won somewhere
+
+
 def test_debug_point_intermediates(pm_ctx):
     img1, img2 = syn.make_pair(400, 400, seed=11)
     pm_ctx.upload_pair(img1, img2)
