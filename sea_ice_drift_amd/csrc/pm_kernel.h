@@ -62,6 +62,7 @@ __host__ __device__ inline LdsLayout lds_layout(int wh, int ww, int s, int K)
 // ---- MFMA kernel (pm_kernel_mfma.hip) ----
 constexpr int kMiscMfmaBytes = 2816;
 constexpr int kBandRowsPad = 3;     // zero rows below the window: the sweep steps past it without clamping
+constexpr int kTrowPad = 36;         // zero rows around a winner operand block: 16 above, 20 below (the step loop runs in fours)
 constexpr int kQueueCap = 192;       // arg-max candidates waiting for exact evaluation (16 B each)
 
 struct MfmaLdsLayout {
@@ -72,7 +73,7 @@ struct MfmaLdsLayout {
     int arow;          // bytes per template row in the sweep operand table (48 or 64 lanes x 16 B)
     int patch_off, ppitch, pdim, pradius;   // image-1 patch the templates are sampled from
     int queue_off;
-    int trow_bytes;    // one winner operand block: 4 k-groups x (s+32) rows x 16 B
+    int trow_bytes;    // one winner operand block: 4 k-groups x (s+kTrowPad) rows x 16 B
     int total;
 };
 
@@ -96,7 +97,7 @@ __host__ __device__ inline MfmaLdsLayout mfma_lds_layout(int wh, int ww, int s)
     L.ppitch = round_up(L.pdim, 4);
     L.patch_off = L.u_off + round_up((s + 1) * L.arow + 16, 16);  // + one all-zero row + 16 scratch bytes
     L.queue_off = round_up(L.patch_off + L.pdim * L.ppitch, 16);
-    L.trow_bytes = 4 * (s + 32) * 16;
+    L.trow_bytes = 4 * (s + kTrowPad) * 16;
     int u = rh * ww * 4;                                          // column sums
     const int sweep = L.queue_off + kQueueCap * 16 - L.u_off;
     if (u < sweep) u = sweep;

@@ -84,7 +84,9 @@ static_assert(kGeoOff + sizeof(Geo) <= kMiscMfmaBytes, "geometry block does not 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];                         \
     [[maybe_unused]] MiscM *m = reinterpret_cast<MiscM *>(smem);                                 \
     [[maybe_unused]] const Geo &G = *reinterpret_cast<const Geo *>(smem + kGeoOff);              \
-    [[maybe_unused]] const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;                \
+    [[maybe_unused]] const int tid = threadIdx.x, lane = tid & 63;                               \
+    /* wavefront index as a scalar: loops over work items become uniform (SALU counters, scalar branches) */ \
+    [[maybe_unused]] const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);                    \
     [[maybe_unused]] const int n_l = lane & 15, q_l = lane >> 4
 
 
@@ -915,7 +917,7 @@ __device__ __noinline__ void ph_winner(const double *rot4, const uint16_t *samp,
     float *ccm = reinterpret_cast<float *>(smem + G.u_off + 2 * G.trow_bytes);
     const int s = S > 0 ? S : G.s, rh = G.rh, rw = G.rw, wpitch = G.wpitch;
     const double nd = G.nd;
-    const int trows = s + 32;
+    const int trows = s + kTrowPad;
     for (int idx = tid; idx < 2 * G.trow_bytes / 4; idx += kBlockM) reinterpret_cast<u32 *>(trow)[idx] = 0;
     __syncthreads();
     {
@@ -965,10 +967,14 @@ __device__ __noinline__ void ph_winner(const double *rot4, const uint16_t *samp,
         // lane (m = n_l, g = q_l): template row i = step - m  ->  trow[g][16 + step - m]
         const uint8_t *ta = trow + (q_l * trows + 16 - n_l) * 16;
         const uint8_t *ta1 = trow1 + (q_l * trows + 16 - n_l) * 16;
-        v4i accT = {0, 0, 0, 0}, accS = {0, 0, 0, 0};
-        // depth-2 software pipeline on running pointers: the LDS reads of steps +2/+3 are in flight while
-        // the MFMAs of the current pair issue.  Reads past the last step touch the zero rows below the
-        // window / behind the template and are never used.
+        // even and odd steps accumulate separately: four independent MFMA chains instead of two
+        v4i accT = {0, 0, 0, 0}, accS = {0, 0, 0, 0}, accT1 = {0, 0, 0, 0}, accS1 = {0, 0, 0, 0};
+        // Software pipeline on running pointers: the LDS reads of step k+2 are issued before the MFMAs of
+        // step k, three operand sets used in turn.  Five LDS instructions per step keep at most 15 reads in
+        // flight - the lgkmcnt counter saturates at 15, beyond that the compiler must wait for everything.
+        // S > 0: fixed trip count (a full 16-row tile), fully unrolled, so every wait names exactly the reads
+        // of one step; a partial last tile runs the same steps against the zero rows behind the template
+        // (kTrowPad).  Reads past the last step are never used.
         struct Ops { Raw5 w; v4i at, a1; };
         auto issue = [&]() {
             Ops o;
@@ -978,22 +984,29 @@ __device__ __noinline__ void ph_winner(const double *rot4, const uint16_t *samp,
             bp += wpitch; ta += 16; ta1 += 16;
             return o;
         };
-        Ops o0 = issue(), o1 = issue();
-        for (int step = 0; step < nsteps; step += 2) {
-            Ops o2 = o0, o3 = o1;
-            if (step + 2 < nsteps) { o2 = issue(); o3 = issue(); }       // wavefront-uniform
-            {
-                const v4i bb = align_raw(o0.w, sh);
-                accT = __builtin_amdgcn_mfma_i32_16x16x64_i8(o0.at, bb, accT, 0, 0, 0);
-                accS = __builtin_amdgcn_mfma_i32_16x16x64_i8(o0.a1, bb, accS, 0, 0, 0);
-            }
-            if (step + 1 < nsteps) {
-                const v4i bb = align_raw(o1.w, sh);
-                accT = __builtin_amdgcn_mfma_i32_16x16x64_i8(o1.at, bb, accT, 0, 0, 0);
-                accS = __builtin_amdgcn_mfma_i32_16x16x64_i8(o1.a1, bb, accS, 0, 0, 0);
-            }
-            o0 = o2; o1 = o3;
+        auto mma = [&](const Ops &o, v4i &aT, v4i &aS) {
+            const v4i bb = align_raw(o.w, sh);
+            aT = __builtin_amdgcn_mfma_i32_16x16x64_i8(o.at, bb, aT, 0, 0, 0);
+            aS = __builtin_amdgcn_mfma_i32_16x16x64_i8(o.a1, bb, aS, 0, 0, 0);
+        };
+        Ops o0 = issue(), o1 = issue(), o2;
+        constexpr int kStepsFixed = S > 0 ? 16 + S - 1 : 0;
+        const int nloop = S > 0 ? kStepsFixed : nsteps;
+#pragma unroll
+        for (int step = 0; step < nloop; step += 6) {                  // even and odd steps: separate accumulators
+            o2 = issue(); __builtin_amdgcn_sched_barrier(0); mma(o0, accT, accS); __builtin_amdgcn_sched_barrier(0);
+            if (step + 1 >= nloop) break;
+            o0 = issue(); __builtin_amdgcn_sched_barrier(0); mma(o1, accT1, accS1); __builtin_amdgcn_sched_barrier(0);
+            if (step + 2 >= nloop) break;
+            o1 = issue(); __builtin_amdgcn_sched_barrier(0); mma(o2, accT, accS); __builtin_amdgcn_sched_barrier(0);
+            if (step + 3 >= nloop) break;
+            o2 = issue(); __builtin_amdgcn_sched_barrier(0); mma(o0, accT1, accS1); __builtin_amdgcn_sched_barrier(0);
+            if (step + 4 >= nloop) break;
+            o0 = issue(); __builtin_amdgcn_sched_barrier(0); mma(o1, accT, accS); __builtin_amdgcn_sched_barrier(0);
+            if (step + 5 >= nloop) break;
+            o1 = issue(); __builtin_amdgcn_sched_barrier(0); mma(o2, accT1, accS1); __builtin_amdgcn_sched_barrier(0);
         }
+        accT += accT1; accS += accS1;
         const int x = x0 + n_l;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -1078,7 +1091,7 @@ __global__ __launch_bounds__(kMaxBlockM, kOccM) void pm_kernel_mfma(const PMArgs
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     MiscM *m = reinterpret_cast<MiscM *>(smem);
     Geo *G = reinterpret_cast<Geo *>(smem + kGeoOff);
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int pt = A.order[blockIdx.x];
     const int s = S > 0 ? S : A.img_size, K = A.n_angles;
 
