@@ -279,11 +279,14 @@ __device__ __noinline__ void ph_window(const uint8_t *img2, long long rows2, lon
     const long long last_ll = (long long)((reinterpret_cast<uintptr_t>(img2 + (rows2 - 1) * stride2 + cols2) - 1) & ~(uintptr_t)3) -
                               (long long)reinterpret_cast<uintptr_t>(org4);
     const u32 last_off = last_ll > 0x7ffffff0ll ? 0x7ffffff0u : (u32)last_ll;  // offset of the last legal dword
-    for (int base = 0; base < ndw; base += 4 * kBlockM) {
-        u32 lo[4], hi[4], shv[4];
-        int rowv[4], dqv[4];
+    // kWin dwords per thread and round trip: the common small windows (border <= 23 at 256 threads) load in
+    // one trip, i.e. one HBM/L2 latency per point
+    constexpr int kWin = 10;
+    for (int base = 0; base < ndw; base += kWin * kBlockM) {
+        u32 lo[kWin], hi[kWin], shv[kWin];
+        int rowv[kWin], dqv[kWin];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < kWin; ++u) {
             const int idx = base + u * kBlockM + tid;
             const int idc = idx < ndw ? idx : 0;
             const int row = (int)__umulhi((u32)idc, magic);
@@ -299,7 +302,7 @@ __device__ __noinline__ void ph_window(const uint8_t *img2, long long rows2, lon
             hi[u] = *reinterpret_cast<const u32 *>(org4 + ob);
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < kWin; ++u) {
             const int idx = base + u * kBlockM + tid;
             if (idx < ndw) {
                 u32 v = __builtin_amdgcn_alignbyte(hi[u], lo[u], shv[u]) ^ 0x80808080u;
@@ -321,30 +324,47 @@ __device__ __noinline__ void ph_sums()
     u32 *sii = reinterpret_cast<u32 *>(smem + G.sii_off);
     u32 *colsum = reinterpret_cast<u32 *>(smem + G.u_off);
     const int s = G.s, ww = G.ww, rh = G.rh, rw = G.rw, wpitch = G.wpitch;
-    for (int x = tid; x < ww; x += kBlockM) {
-        const int8_t *col = reinterpret_cast<const int8_t *>(win) + x;
-        int c = 0;
+    // Both passes cut their running sums into segments so that the whole workgroup works and the chain of
+    // dependent LDS reads is short: a segment starts from a directly summed value (s independent reads)
+    // and slides over its few rows / columns.
+    {   // down the columns: thread = (column x, segment of rows)
+        int nseg = kBlockM / ww; nseg = nseg < 1 ? 1 : (nseg > rh ? rh : nseg);
+        const int per = (rh + nseg - 1) / nseg;
+        for (int task = tid; task < ww * nseg; task += kBlockM) {
+            const int seg = task / ww, x = task - seg * ww;
+            const int ya = seg * per, yb = ya + per < rh ? ya + per : rh;
+            if (ya >= yb) continue;
+            const int8_t *col = reinterpret_cast<const int8_t *>(win) + x + ya * wpitch;
+            int c = 0;
 #pragma unroll 8
-        for (int i = 0; i < s; ++i) { const int v = col[i * wpitch]; c += v * v; }
-        colsum[x] = (u32)c;
-#pragma unroll 8
-        for (int y = 1; y < rh; ++y) {
-            const int vo = col[(y - 1) * wpitch], vn = col[(y + s - 1) * wpitch];
-            c += vn * vn - vo * vo;
-            colsum[y * ww + x] = (u32)c;
+            for (int i = 0; i < s; ++i) { const int v = col[i * wpitch]; c += v * v; }
+            colsum[ya * ww + x] = (u32)c;
+#pragma unroll 4
+            for (int y = 1; y < yb - ya; ++y) {
+                const int vo = col[(y - 1) * wpitch], vn = col[(y + s - 1) * wpitch];
+                c += vn * vn - vo * vo;
+                colsum[(ya + y) * ww + x] = (u32)c;
+            }
         }
     }
     __syncthreads();
-    for (int y = tid; y < rh; y += kBlockM) {
-        const u32 *cr = colsum + y * ww;
-        u32 acc = 0;
+    {   // along the rows: thread = (row y, segment of columns)
+        int nseg = kBlockM / rh; nseg = nseg < 1 ? 1 : (nseg > rw ? rw : nseg);
+        const int per = (rw + nseg - 1) / nseg;
+        for (int task = tid; task < rh * nseg; task += kBlockM) {
+            const int y = task / nseg, seg = task - y * nseg;
+            const int xa = seg * per, xb = xa + per < rw ? xa + per : rw;
+            if (xa >= xb) continue;
+            const u32 *cr = colsum + y * ww + xa;
+            u32 acc = 0;
 #pragma unroll 8
-        for (int j = 0; j < s; ++j) acc += cr[j];
-        sii[y * rw] = acc;
-#pragma unroll 8
-        for (int x = 1; x < rw; ++x) {
-            acc += cr[x + s - 1] - cr[x - 1];
-            sii[y * rw + x] = acc;
+            for (int j = 0; j < s; ++j) acc += cr[j];
+            sii[y * rw + xa] = acc;
+#pragma unroll 4
+            for (int x = 1; x < xb - xa; ++x) {
+                acc += cr[x + s - 1] - cr[x - 1];
+                sii[y * rw + xa + x] = acc;
+            }
         }
     }
     __syncthreads();
@@ -511,19 +531,27 @@ __device__ __forceinline__ u32 sample_fast5(const SampleGeom &g, const double *r
 
 // Table path (integral template centre, patch inside image 1): four samples of one template row through the
 // host-built offset table (pm_capi.hip make_samp).  Returns the packed raw pixels j = 4*jq .. 4*jq+3.
+__device__ __forceinline__ u32 gather_quad(const uint8_t *patch, const uint2 e)
+{
+    return (u32)patch[e.x & 0x7fffu] | ((u32)patch[(e.x >> 16) & 0x7fffu] << 8) |
+           ((u32)patch[e.y & 0x7fffu] << 16) | ((u32)patch[(e.y >> 16) & 0x7fffu] << 24);
+}
+__device__ __forceinline__ bool quad_flagged(const uint2 e) { return ((e.x | e.y) & 0x80008000u) != 0u; }
+// rare: redo the flagged samples of a quad with the reference's float64 operation order
+__device__ __forceinline__ u32 fix_quad(const SampleGeom &g, u32 raw, const uint2 e, const double *rot4, int i, int jq)
+{
+    const u32 fl = ((e.x >> 15) & 1u) | ((e.x >> 30) & 2u) | (((e.y >> 15) & 1u) << 2) | ((e.y >> 28) & 8u);
+    for (int q = 0; q < 4; ++q)
+        if (((fl >> q) & 1u) && 4 * jq + q < g.s) {
+            const u32 v = (u32)sample_exact(g, rot4, i, 4 * jq + q);
+            raw = (raw & ~(0xffu << (8 * q))) | (v << (8 * q));
+        }
+    return raw;
+}
 __device__ __forceinline__ u32 sample_quad(const SampleGeom &g, const uint2 e, const double *rot4, int i, int jq)
 {
-    const uint8_t *patch = g.patch;
-    u32 raw = (u32)patch[e.x & 0x7fffu] | ((u32)patch[(e.x >> 16) & 0x7fffu] << 8) |
-              ((u32)patch[e.y & 0x7fffu] << 16) | ((u32)patch[(e.y >> 16) & 0x7fffu] << 24);
-    if ((e.x | e.y) & 0x80008000u) {                                   // rare: redo flagged samples in double
-        const u32 fl = ((e.x >> 15) & 1u) | ((e.x >> 30) & 2u) | (((e.y >> 15) & 1u) << 2) | ((e.y >> 28) & 8u);
-        for (int q = 0; q < 4; ++q)
-            if (((fl >> q) & 1u) && 4 * jq + q < g.s) {
-                const u32 v = (u32)sample_exact(g, rot4, i, 4 * jq + q);
-                raw = (raw & ~(0xffu << (8 * q))) | (v << (8 * q));
-            }
-    }
+    u32 raw = gather_quad(g.patch, e);
+    if (quad_flagged(e)) raw = fix_quad(g, raw, e, rot4, i, jq);
     return raw;
 }
 __device__ __forceinline__ bool table_usable(const SampleGeom &g)
@@ -614,18 +642,53 @@ __device__ __noinline__ void ph_templates(const double *rot, const uint16_t *sam
         // domain per angle: sum(v-128) = sum v - 128 N, sum(v-128)^2 = sum v^2 - 256 sum v + 16384 N
         const int sp = samp_pitch(s), nq = sp >> 2, upa = s * nq;
         const u32 tailmask = (s & 3) ? (1u << (8 * (s & 3))) - 1u : 0xffffffffu;
-        for (int a = wv; a < Kg; a += kWavesM) {
+        // table entries are fetched a whole chunk (kCh steps of 64 lanes) ahead - those of the next angle while
+        // this one is gathered - so that the L2 latency of the table is paid once per wavefront, not per step
+        constexpr int kCh = S > 0 ? (S * ((S + 3) / 4) + 63) / 64 : 4;
+        auto fetch = [&](int a, int u0, uint2 (&e)[kCh]) {
             const uint2 *ta = reinterpret_cast<const uint2 *>(samp + (size_t)(a0 + a) * s * sp);
+#pragma unroll
+            for (int c = 0; c < kCh; ++c) {
+                const int u = u0 + 64 * c + lane;
+                e[c] = ta[u < upa ? u : 0];
+            }
+        };
+        uint2 cur[kCh] = {}, nxt[kCh] = {};
+        if (wv < Kg) fetch(wv, 0, cur);
+        for (int a = wv; a < Kg; a += kWavesM) {
             u32 sv = 0, svv = 0, zero = 0;
-            for (int u = lane; u < upa; u += 64) {
-                const int i = u / nq, jq = u - i * nq;
-                const u32 vm = jq == nq - 1 ? tailmask : 0xffffffffu;
-                const u32 raw = sample_quad(g, ta[u], m->rot[a], i, jq) & vm;
-                const u32 z = raw | ~vm;
-                zero |= (z - 0x01010101u) & ~z & 0x80808080u;          // some valid byte == 0
-                sv = __builtin_amdgcn_udot4(raw, 0x01010101u, sv, false);
-                svv = __builtin_amdgcn_udot4(raw, raw, svv, false);
-                *reinterpret_cast<u32 *>(afrag + i * arow + (jq >> 2) * 256 + a * 16 + (jq & 3) * 4) = (raw ^ 0x80808080u) & vm;
+            for (int u0 = 0; u0 < upa; u0 += 64 * kCh) {
+                // what comes next: the following chunk of this angle, else the first chunk of the next angle
+                const bool more = u0 + 64 * kCh < upa;
+                if (more) fetch(a, u0 + 64 * kCh, nxt);
+                else if (a + kWavesM < Kg) fetch(a + kWavesM, 0, nxt);
+                // all gathers of the chunk first (branch-free: their LDS latencies overlap), flagged quads after
+                u32 rawv[kCh];
+                bool anyflag = false;
+#pragma unroll
+                for (int c = 0; c < kCh; ++c) { rawv[c] = gather_quad(patch, cur[c]); anyflag |= quad_flagged(cur[c]); }
+                if (anyflag) {
+                    for (int c = 0; c < kCh; ++c) {
+                        const int u = u0 + 64 * c + lane;
+                        if (u < upa && quad_flagged(cur[c])) rawv[c] = fix_quad(g, rawv[c], cur[c], m->rot[a], u / nq, u % nq);
+                    }
+                }
+#pragma unroll
+                for (int c = 0; c < kCh; ++c) {
+                    const int u = u0 + 64 * c + lane;
+                    if (u < upa) {
+                        const int i = u / nq, jq = u - i * nq;
+                        const u32 vm = jq == nq - 1 ? tailmask : 0xffffffffu;
+                        const u32 raw = rawv[c] & vm;
+                        const u32 z = raw | ~vm;
+                        zero |= (z - 0x01010101u) & ~z & 0x80808080u;  // some valid byte == 0
+                        sv = __builtin_amdgcn_udot4(raw, 0x01010101u, sv, false);
+                        svv = __builtin_amdgcn_udot4(raw, raw, svv, false);
+                        *reinterpret_cast<u32 *>(afrag + i * arow + (jq >> 2) * 256 + a * 16 + (jq & 3) * 4) = (raw ^ 0x80808080u) & vm;
+                    }
+                }
+#pragma unroll
+                for (int c = 0; c < kCh; ++c) cur[c] = nxt[c];
             }
             const int ws = wave_sum_dpp((int)sv), wss = wave_sum_dpp((int)svv);
             if (lane == 0) { m->isT[a] = ws - 128 * s * s; m->isTT[a] = wss - 256 * ws + 16384 * s * s; }
