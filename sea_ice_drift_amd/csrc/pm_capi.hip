@@ -89,6 +89,7 @@ struct sid_pm_ctx {
     DevBuf<double> angles, rot;
     DevBuf<uint16_t> samp;              // sampling table of the MFMA kernel (make_samp)
     bool have_samp = false;             // SID_PM_NO_SAMP_TABLE=1 keeps the on-the-fly sampling (A/B runs, tests)
+    int samp_nflag = 0;
     DevBuf<double> out;
     DevBuf<int32_t> out_ij;
     double *user_out = nullptr;         // caller-owned result arrays (bind_results)
@@ -130,10 +131,11 @@ void make_rot(const double *angles, int n_angles, double alpha0, int s, const do
 // get_template (pmlib.py:105-113; scipy order 0: floor(x + 0.5)) are those of the centre (0, 0) shifted by
 // (R, C) - unless a coordinate lies so close to k + 1/2 that the float64 roundings at the magnitude of R
 // could tip it.  Those entries (|frac - boundary| < kSampGuard; expected: none or a handful per table) carry
-// a flag and are recomputed per point in the kernel with the reference's operation order.
+// a flag and are recomputed per point in the kernel (ph_tpl_fix) with the reference's operation order.
 // Entry = (row + pradius) * ppitch + (col + pradius): the byte offset inside the kernel's LDS patch.
-void make_samp(const std::vector<double> &rot, int K, int s, std::vector<uint16_t> &tab)
+int make_samp(const std::vector<double> &rot, int K, int s, std::vector<uint16_t> &tab)
 {
+    int nflag = 0;
     const sid::MfmaLdsLayout L = sid::mfma_lds_layout(s + 1, s + 1, s);
     const int sp = sid::samp_pitch(s);
     tab.assign((size_t)K * s * sp, 0);
@@ -152,10 +154,13 @@ void make_samp(const std::vector<double> &rot, int K, int s, std::vector<uint16_
                 const double dr = (rr + 0.5) - fr, dc = (cc + 0.5) - fc;
                 bool doubt = !(dr >= sid::kSampGuard && dr <= 1.0 - sid::kSampGuard && dc >= sid::kSampGuard && dc <= 1.0 - sid::kSampGuard);
                 int pr = (int)fr + L.pradius, pc = (int)fc + L.pradius;
-                if (!(pr >= 0 && pr < L.pdim && pc >= 0 && pc < L.pdim)) { pr = 0; pc = 0; doubt = true; }
-                tab[((size_t)k * s + i) * sp + j] = (uint16_t)((pr * L.ppitch + pc) | (doubt ? 0x8000 : 0));
+                if (!(pr >= 0 && pr < L.pdim && pc >= 0 && pc < L.pdim)) doubt = true;
+                // flagged: gather the spare byte behind the patch (128), the kernel's fix pass supplies the sample
+                tab[((size_t)k * s + i) * sp + j] = doubt ? (uint16_t)((L.pdim * L.ppitch) | 0x8000) : (uint16_t)(pr * L.ppitch + pc);
+                nflag += doubt ? 1 : 0;
             }
     }
+    return nflag;
 }
 
 // window geometry of one point, the same arithmetic as the kernel (pmlib.py:200-202)
@@ -223,7 +228,7 @@ int fill_args(sid_pm_ctx *ctx, sid::PMArgs &A)
     A.c1 = ctx->vec.p; A.r1 = ctx->vec.p + n; A.c2fg = ctx->vec.p + 2 * n; A.r2fg = ctx->vec.p + 3 * n;
     A.border = ctx->vec.p + 4 * n;
     A.img_size = ctx->img_size; A.n_angles = ctx->n_angles; A.flags = ctx->flags;
-    A.angles = ctx->angles.p; A.rot = ctx->rot.p; A.samp = ctx->have_samp ? ctx->samp.p : nullptr;
+    A.angles = ctx->angles.p; A.rot = ctx->rot.p; A.samp = ctx->have_samp ? ctx->samp.p : nullptr; A.samp_nflag = ctx->samp_nflag;
     A.out = ctx->user_out ? ctx->user_out : ctx->out.p;
     A.out_ij = ctx->user_out ? ctx->user_ij : ctx->out_ij.p;
     return SID_PM_OK;
@@ -402,7 +407,8 @@ SID_EXPORT int sid_pm_set_points(sid_pm_ctx *ctx, const double *c1, const double
     std::vector<double> rotv;
     make_rot(angles, K, alpha0, s, rot, rotv);
     std::vector<uint16_t> sampv;
-    if (ctx->kernel == KERNEL_MFMA && !getenv("SID_PM_NO_SAMP_TABLE")) make_samp(rotv, K, s, sampv);
+    int nflag = 0;
+    if (ctx->kernel == KERNEL_MFMA && !getenv("SID_PM_NO_SAMP_TABLE")) nflag = make_samp(rotv, K, s, sampv);
 
     if (int rc = ctx->samp.reserve(sampv.size() + 4)) return rc;
     if (int rc = ctx->vec.reserve((size_t)(5 * n))) return rc;
@@ -420,7 +426,7 @@ SID_EXPORT int sid_pm_set_points(sid_pm_ctx *ctx, const double *c1, const double
     HIP_TRY(hipMemcpy(ctx->angles.p, angles, sizeof(double) * (size_t)K, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(ctx->rot.p, rotv.data(), sizeof(double) * rotv.size(), hipMemcpyHostToDevice));
     if (!sampv.empty()) HIP_TRY(hipMemcpy(ctx->samp.p, sampv.data(), sizeof(uint16_t) * sampv.size(), hipMemcpyHostToDevice));
-    ctx->have_samp = !sampv.empty();
+    ctx->have_samp = !sampv.empty(); ctx->samp_nflag = nflag;
 
     ctx->user_out = nullptr; ctx->user_ij = nullptr;
     ctx->n = n; ctx->img_size = s; ctx->n_angles = K; ctx->flags = flags;
@@ -557,7 +563,8 @@ SID_EXPORT int sid_pm_debug_point(sid_pm_ctx *ctx, double c1, double r1, double 
     DevBuf<uint8_t> dt;
     DevBuf<uint16_t> dsamp;
     std::vector<uint16_t> sampv;
-    if (ctx->kernel == KERNEL_MFMA && !getenv("SID_PM_NO_SAMP_TABLE")) make_samp(rotv, K, s, sampv);
+    int nflag = 0;
+    if (ctx->kernel == KERNEL_MFMA && !getenv("SID_PM_NO_SAMP_TABLE")) nflag = make_samp(rotv, K, s, sampv);
     DevBuf<float> dccm, dhes;
     DevBuf<long long> dcyc;
     int rc = SID_PM_OK;
@@ -593,7 +600,7 @@ SID_EXPORT int sid_pm_debug_point(sid_pm_ctx *ctx, double c1, double r1, double 
         A.angles = dang.p; A.rot = drot.p; A.out = dout.p; A.out_ij = dij.p;
         A.dbg_templates = dt.p; A.dbg_ccm = dccm.p; A.dbg_hes = dhes.p; A.dbg_shape = dshape.p; A.dbg_cap = cap;
         A.dbg_cycles = dcyc.p;
-        A.samp = sampv.empty() ? nullptr : dsamp.p;
+        A.samp = sampv.empty() ? nullptr : dsamp.p; A.samp_nflag = nflag;
         step((hipError_t)(ctx->kernel == KERNEL_DOT4 ? sid::launch_pm(A, lds, ctx->stream)
                                                      : sid::launch_pm_mfma(A, lds, getenv("SID_PM_THREADS") ? atoi(getenv("SID_PM_THREADS")) : 256, ctx->stream)));
         step(hipStreamSynchronize(ctx->stream));

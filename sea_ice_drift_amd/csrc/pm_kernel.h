@@ -21,9 +21,12 @@ struct PMArgs {
     uint32_t flags;
     const double *angles;                           // [K] degrees (reported as-is)
     const double *rot;                              // [K][4] cos, sin, tcT0, tcT1
-    // MFMA kernel: sampling table [K][s][samp_pitch(s)] of LDS patch offsets for integral template centres
-    // (bit 15: coordinate too close to a rounding boundary - redo in double); null = always sample on the fly
+    // MFMA kernel: sampling table [K][s][samp_pitch(s)] of LDS patch offsets for integral template centres;
+    // bit 15 = coordinate too close to a rounding boundary: the offset then points at the spare byte behind
+    // the patch (value 128 = re-centred 0) and the sample is redone in double by ph_tpl_fix.
+    // null = always sample on the fly
     const uint16_t *samp;
+    int32_t samp_nflag;                             // number of flagged entries in samp (0 almost always)
     double *out;                                    // [n_total][5]
     int32_t *out_ij;                                // [n_total][3]
     // diagnostics (debug_point only; null in production launches)
@@ -96,7 +99,7 @@ __host__ __device__ inline MfmaLdsLayout mfma_lds_layout(int wh, int ww, int s)
     L.pdim = 2 * L.pradius + 2;
     L.ppitch = round_up(L.pdim, 4);
     L.patch_off = L.u_off + round_up((s + 1) * L.arow + 16, 16);  // + one all-zero row + 16 scratch bytes
-    L.queue_off = round_up(L.patch_off + L.pdim * L.ppitch, 16);
+    L.queue_off = round_up(L.patch_off + L.pdim * L.ppitch + 1, 16);  // + one byte = 128 behind the patch (flagged table entries)
     L.trow_bytes = 4 * (s + kTrowPad) * 16;
     int u = rh * ww * 4;                                          // column sums
     const int sweep = L.queue_off + kQueueCap * 16 - L.u_off;

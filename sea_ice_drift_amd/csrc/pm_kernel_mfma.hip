@@ -379,6 +379,7 @@ __device__ __noinline__ void ph_patch(const uint8_t *img1, long long rows1, long
     uint8_t *patch = smem + G.patch_off;
     const int pdim = G.pdim, ppitch = G.ppitch, np = pdim * pdim;
     const long long pr0 = G.pr0, pc0 = G.pc0;
+    if (tid == 0) patch[pdim * ppitch] = 128;                          // spare byte: what a flagged table entry gathers
     if (pr0 >= 0 && pc0 >= 0 && pr0 + pdim <= rows1 && pc0 + ppitch <= cols1) {
         // the patch lies inside image 1 (block-uniform): dword loads re-aligned in registers, 32-bit offsets,
         // division by the row pitch through the precomputed reciprocal
@@ -530,66 +531,52 @@ __device__ __forceinline__ u32 sample_fast5(const SampleGeom &g, const double *r
 }
 
 // Table path (integral template centre, patch inside image 1): four samples of one template row through the
-// host-built offset table (pm_capi.hip make_samp).  Returns the packed raw pixels j = 4*jq .. 4*jq+3.
+// host-built offset table (pm_capi.hip make_samp) -> packed raw pixels j = 4*jq .. 4*jq+3.  A flagged entry
+// points at the spare byte behind the patch (128 = re-centred 0); ph_tpl_fix supplies the real sample.
 __device__ __forceinline__ u32 gather_quad(const uint8_t *patch, const uint2 e)
 {
     return (u32)patch[e.x & 0x7fffu] | ((u32)patch[(e.x >> 16) & 0x7fffu] << 8) |
            ((u32)patch[e.y & 0x7fffu] << 16) | ((u32)patch[(e.y >> 16) & 0x7fffu] << 24);
 }
-__device__ __forceinline__ bool quad_flagged(const uint2 e) { return ((e.x | e.y) & 0x80008000u) != 0u; }
-// rare: redo the flagged samples of a quad with the reference's float64 operation order
-__device__ __forceinline__ u32 fix_quad(const SampleGeom &g, u32 raw, const uint2 e, const double *rot4, int i, int jq)
+// block-uniform: integral template centre and the patch at least one pixel inside image 1
+__device__ __forceinline__ bool table_usable(const Geo &G, long long rows1, long long cols1)
 {
-    const u32 fl = ((e.x >> 15) & 1u) | ((e.x >> 30) & 2u) | (((e.y >> 15) & 1u) << 2) | ((e.y >> 28) & 8u);
-    for (int q = 0; q < 4; ++q)
-        if (((fl >> q) & 1u) && 4 * jq + q < g.s) {
-            const u32 v = (u32)sample_exact(g, rot4, i, 4 * jq + q);
-            raw = (raw & ~(0xffu << (8 * q))) | (v << (8 * q));
-        }
-    return raw;
-}
-__device__ __forceinline__ u32 sample_quad(const SampleGeom &g, const uint2 e, const double *rot4, int i, int jq)
-{
-    u32 raw = gather_quad(g.patch, e);
-    if (quad_flagged(e)) raw = fix_quad(g, raw, e, rot4, i, jq);
-    return raw;
-}
-__device__ __forceinline__ bool table_usable(const SampleGeom &g)
-{
-    return g.inside && g.c1 == floor(g.c1) && g.r1 == floor(g.r1) && fabs(g.c1) < 1e9 && fabs(g.r1) < 1e9;
+    const bool inside = G.pr0 >= 1 && G.pc0 >= 1 && (long long)G.pr0 + G.pdim <= rows1 - 1 && (long long)G.pc0 + G.pdim <= cols1 - 1;
+    return inside && G.c1 == floor(G.c1) && G.r1 == floor(G.r1) && fabs(G.c1) < 1e9 && fabs(G.r1) < 1e9;
 }
 
 // ---------------------------------------------------------------------------------------------
 // Phase 0c: operands of one group of <= 15 angles.  afrag[i][lane = g*16 + slot][16 bytes], byte jj
 // <-> column c = 16 g + jj; slot 15 is the all-ones template; row s is all zero.
+// Four small functions (begin / one of the two samplers / end) so that the common sampler - the table
+// path - does not inherit the register appetite (and callee-saved spills) of the general one.
 // ---------------------------------------------------------------------------------------------
 template <int S>
-__device__ __noinline__ void ph_templates(const double *rot, const uint16_t *samp, int a0, int Kg, long long rows1,
-                                          long long cols1, uint8_t *dbg_templates, long long *dbg_cycles)
+__device__ __noinline__ void ph_tpl_begin(const double *rot, int a0, int Kg, long long *dbg_cycles)
+{
+    SID_PHASE_LOCALS;
+    uint8_t *afrag = smem + G.u_off;
+    const int s = S > 0 ? S : G.s, arow = G.arow;
+    if (tid < 4 * Kg) (&m->rot[0][0])[tid] = rot[4 * a0 + tid];        // one global round trip for the whole group
+    for (int idx = tid; idx < (s + 1) * arow / 16; idx += kBlockM) reinterpret_cast<uint4 *>(afrag)[idx] = make_uint4(0, 0, 0, 0);
+    if (tid < kSlots) { m->isT[tid] = 0; m->isTT[tid] = 0; }
+    __syncthreads();                                                   // also: patch complete
+    if (dbg_cycles && tid == 0) dbg_cycles[8] = (long long)clock64();
+}
+
+// general sampler: any centre, any position relative to the image border
+template <int S>
+__device__ __noinline__ void ph_tpl_general(int a0, int Kg, long long rows1, long long cols1)
 {
     SID_PHASE_LOCALS;
     uint8_t *afrag = smem + G.u_off;
     const uint8_t *patch = smem + G.patch_off;
     const int s = S > 0 ? S : G.s, arow = G.arow;                      // compile-time s: divisions by s become multiplies
-    const double nd = G.nd;
-    if (tid < 4 * Kg) (&m->rot[0][0])[tid] = rot[4 * a0 + tid];        // one global round trip for the whole group
-    for (int idx = tid; idx < (s + 1) * arow / 4; idx += kBlockM) reinterpret_cast<u32 *>(afrag)[idx] = 0;
-    if (tid < kSlots) { m->isT[tid] = 0; m->isTT[tid] = 0; }
-    __syncthreads();                                                   // also: patch complete
-    if (dbg_cycles && tid == 0) dbg_cycles[8] = (long long)clock64();
     const SampleGeom g = sample_geom(G, s, rows1, cols1, patch);
-#ifdef SID_ABLATE_SAMPLING
-    for (int idx = tid; idx < s * arow; idx += kBlockM) afrag[idx] = (uint8_t)(idx * 37 + 11);
-    if (tid < Kg) { m->isT[tid] = 1000 + tid; m->isTT[tid] = 9000000 + tid; }
-    Kg = Kg > 0 ? Kg : 0;
-#define SID_SKIP_SAMPLING_LOOP 1
-#endif
     const int dump = (s + 1) * arow;                                   // 16 scratch bytes behind the operand table
     // byte offset of (row ig + k*ngrp, column j, slot a) = wbase + k*wstep + 16 a
     const int wbase = g.ig * arow + (g.j >> 4) * 256 + (g.j & 15), wstep = g.ngrp * arow;
     int sawzero = 0;
-    u32 anydoubt = 0;
-#ifndef SID_SKIP_SAMPLING_LOOP
     auto run = [&](auto inside_tag) {
         constexpr bool INSIDE = decltype(inside_tag)::value;
         unsigned long long dlo = 0, dhi = 0;
@@ -636,7 +623,20 @@ __device__ __noinline__ void ph_templates(const double *rot, const uint16_t *sam
             dlo = 0; dhi = 0;
         }
     };
-    if (samp && table_usable(g)) {
+    if (g.inside) run(std::true_type{}); else run(std::false_type{});
+    if (sawzero) m->zero_flag = 1;
+}
+
+// table sampler: integral template centre, patch inside image 1 (table_usable)
+template <int S>
+__device__ __noinline__ void ph_tpl_table(const uint16_t *samp, int a0, int Kg, long long rows1, long long cols1)
+{
+    SID_PHASE_LOCALS;
+    uint8_t *afrag = smem + G.u_off;
+    const uint8_t *patch = smem + G.patch_off;
+    const int s = S > 0 ? S : G.s, arow = G.arow;
+    int sawzero = 0;
+    {
         // one wavefront per angle: four samples per lane and step through the offset table, one dword store
         // into the operand table; pixel sums by v_dot4 on the packed raw bytes, converted to the re-centred
         // domain per angle: sum(v-128) = sum v - 128 N, sum(v-128)^2 = sum v^2 - 256 sum v + 16384 N
@@ -662,17 +662,10 @@ __device__ __noinline__ void ph_templates(const double *rot, const uint16_t *sam
                 const bool more = u0 + 64 * kCh < upa;
                 if (more) fetch(a, u0 + 64 * kCh, nxt);
                 else if (a + kWavesM < Kg) fetch(a + kWavesM, 0, nxt);
-                // all gathers of the chunk first (branch-free: their LDS latencies overlap), flagged quads after
+                // all gathers of the chunk first (branch-free: their LDS latencies overlap)
                 u32 rawv[kCh];
-                bool anyflag = false;
 #pragma unroll
-                for (int c = 0; c < kCh; ++c) { rawv[c] = gather_quad(patch, cur[c]); anyflag |= quad_flagged(cur[c]); }
-                if (anyflag) {
-                    for (int c = 0; c < kCh; ++c) {
-                        const int u = u0 + 64 * c + lane;
-                        if (u < upa && quad_flagged(cur[c])) rawv[c] = fix_quad(g, rawv[c], cur[c], m->rot[a], u / nq, u % nq);
-                    }
-                }
+                for (int c = 0; c < kCh; ++c) rawv[c] = gather_quad(patch, cur[c]);
 #pragma unroll
                 for (int c = 0; c < kCh; ++c) {
                     const int u = u0 + 64 * c + lane;
@@ -694,16 +687,52 @@ __device__ __noinline__ void ph_templates(const double *rot, const uint16_t *sam
             if (lane == 0) { m->isT[a] = ws - 128 * s * s; m->isTT[a] = wss - 256 * ws + 16384 * s * s; }
             sawzero |= zero != 0u ? 1 : 0;
         }
-    } else if (g.inside) run(std::true_type{}); else run(std::false_type{});
-#else
-    (void)anydoubt; (void)dump;
-#endif
+    }
+    if (sawzero) m->zero_flag = 1;
+}
+
+// Rare (only when the host flagged table entries, A.samp_nflag > 0): the samples whose coordinate sits
+// within kSampGuard of a rounding boundary, recomputed with the reference's float64 operation order.
+// winner_ka < 0: operand table of the angle group (+ template sums, zero guard); else: the winner's operands.
+template <int S>
+__device__ __noinline__ void ph_tpl_fix(const uint16_t *samp, int a0, int Kg, long long rows1, long long cols1, int winner_ka)
+{
+    SID_PHASE_LOCALS;
+    __syncthreads();                                                   // the sampler's stores and sums are complete
+    const uint8_t *patch = smem + G.patch_off;
+    const int s = S > 0 ? S : G.s, arow = G.arow, sp = samp_pitch(s);
+    const SampleGeom g = sample_geom(G, s, rows1, cols1, patch);
+    const int a_lo = winner_ka < 0 ? 0 : 0, a_n = winner_ka < 0 ? Kg : 1;
+    for (int idx = tid; idx < a_n * s * sp; idx += kBlockM) {
+        const int a = idx / (s * sp), rem = idx - a * s * sp;
+        const int i = rem / sp, j = rem - i * sp;
+        const int ag = winner_ka < 0 ? a0 + a_lo + a : winner_ka;      // angle index in the table
+        if (j >= s || !(samp[(size_t)ag * s * sp + rem] & 0x8000u)) continue;
+        const double *rot4 = winner_ka < 0 ? m->rot[a] : m->rot[0];
+        const int v = sample_exact(g, rot4, i, j);
+        if (winner_ka < 0) {
+            (smem + G.u_off)[i * arow + ((j >> 4) * 16 + a) * 16 + (j & 15)] = (uint8_t)(v ^ 0x80);
+            atomicAdd(&m->isT[a], v - 128); atomicAdd(&m->isTT[a], (v - 128) * (v - 128));
+            if (v == 0) m->zero_flag = 1;
+        } else {
+            const int trows = s + kTrowPad;
+            (smem + G.u_off)[((j >> 4) * trows + 16 + i) * 16 + (j & 15)] = (uint8_t)(v ^ 0x80);
+        }
+    }
+}
+
+template <int S>
+__device__ __noinline__ void ph_tpl_end(int a0, int Kg, uint8_t *dbg_templates, long long *dbg_cycles)
+{
+    SID_PHASE_LOCALS;
+    uint8_t *afrag = smem + G.u_off;
+    const int s = S > 0 ? S : G.s, arow = G.arow;
+    const double nd = G.nd;
     if (dbg_cycles && tid == 0) dbg_cycles[15] = (long long)clock64();
     for (int idx = tid; idx < s * s; idx += kBlockM) {                  // slot 15: all-ones template
         const int i = idx / s, j = idx - i * s;
         afrag[i * arow + ((j >> 4) * 16 + 15) * 16 + (j & 15)] = 1;
     }
-    if (sawzero) m->zero_flag = 1;
     __syncthreads();
     if (dbg_cycles && tid == 0) dbg_cycles[9] = (long long)clock64();
     if (dbg_templates) {
@@ -964,22 +993,18 @@ __device__ __noinline__ Score ph_sweep(Score sc, int a0, int Kg, long long *dbg_
 }
 
 // ---------------------------------------------------------------------------------------------
-// Phase 4: NCC matrix of the winning angle, row-major MFMA (M = 16 output rows).
+// Phase 4: NCC matrix of the winning angle, row-major MFMA (M = 16 output rows): ph_winner_stage builds the
+// operands, ph_winner runs the tiles.
 // trow[g][16 + i][16 B] holds the winner's template, trow1 the all-ones one; zero rows around.
 // ---------------------------------------------------------------------------------------------
 template <int S>
-__device__ __noinline__ void ph_winner(const double *rot4, const uint16_t *samp, long long rows1, long long cols1, int ka,
-                                       long long *dbg_cycles)
+__device__ __noinline__ void ph_winner_stage(const double *rot4, const uint16_t *samp, long long rows1, long long cols1, int ka)
 {
     SID_PHASE_LOCALS;
-    const uint8_t *win = smem + G.win_off;
-    const u32 *sii = reinterpret_cast<const u32 *>(smem + G.sii_off);
     const uint8_t *patch = smem + G.patch_off;
     uint8_t *trow = smem + G.u_off;
     uint8_t *trow1 = trow + G.trow_bytes;
-    float *ccm = reinterpret_cast<float *>(smem + G.u_off + 2 * G.trow_bytes);
-    const int s = S > 0 ? S : G.s, rh = G.rh, rw = G.rw, wpitch = G.wpitch;
-    const double nd = G.nd;
+    const int s = S > 0 ? S : G.s;
     const int trows = s + kTrowPad;
     for (int idx = tid; idx < 2 * G.trow_bytes / 4; idx += kBlockM) reinterpret_cast<u32 *>(trow)[idx] = 0;
     __syncthreads();
@@ -993,14 +1018,14 @@ __device__ __noinline__ void ph_winner(const double *rot4, const uint16_t *samp,
             trow[off] = (uint8_t)(v ^ 0x80);
             trow1[off] = take ? 1 : 0;
         };
-        if (samp && table_usable(g)) {
+        if (samp) {                                                    // caller checked table_usable
             const int sp = samp_pitch(s), nq = sp >> 2, upa = s * nq;
             const u32 tailmask = (s & 3) ? (1u << (8 * (s & 3))) - 1u : 0xffffffffu;
             const uint2 *ta = reinterpret_cast<const uint2 *>(samp + (size_t)ka * s * sp);
             for (int u = tid; u < upa; u += kBlockM) {
                 const int i = u / nq, jq = u - i * nq;
                 const u32 vm = jq == nq - 1 ? tailmask : 0xffffffffu;
-                const u32 raw = sample_quad(g, ta[u], m->rot[0], i, jq);
+                const u32 raw = gather_quad(patch, ta[u]);
                 const int off = ((jq >> 2) * trows + 16 + i) * 16 + (jq & 3) * 4;
                 *reinterpret_cast<u32 *>(trow + off) = (raw ^ 0x80808080u) & vm;
                 *reinterpret_cast<u32 *>(trow1 + off) = 0x01010101u & vm;
@@ -1014,7 +1039,21 @@ __device__ __noinline__ void ph_winner(const double *rot4, const uint16_t *samp,
                 if ((db >> u) & 1u) { const int i = g.ig + (k0 + u) * g.ngrp; put(i, g.j, sample_exact(g, m->rot[0], i, g.j)); }
         }
     }
-    __syncthreads();
+}
+
+template <int S>
+__device__ __noinline__ void ph_winner(int ka, long long *dbg_cycles)
+{
+    SID_PHASE_LOCALS;
+    const uint8_t *win = smem + G.win_off;
+    const u32 *sii = reinterpret_cast<const u32 *>(smem + G.sii_off);
+    const uint8_t *trow = smem + G.u_off;
+    const uint8_t *trow1 = trow + G.trow_bytes;
+    float *ccm = reinterpret_cast<float *>(smem + G.u_off + 2 * G.trow_bytes);
+    const int s = S > 0 ? S : G.s, rh = G.rh, rw = G.rw, wpitch = G.wpitch;
+    const double nd = G.nd;
+    const int trows = s + kTrowPad;
+    __syncthreads();                                                   // the staged operands (and their fixes) are complete
     if (dbg_cycles && tid == 0) dbg_cycles[13] = (long long)clock64();
     const double sT = m->sTd[ka], rT = m->rTd[ka];
     const bool cT = m->constT[ka] != 0;
@@ -1204,10 +1243,16 @@ __global__ __launch_bounds__(kMaxBlockM, kOccM) void pm_kernel_mfma(const PMArgs
     SID_STAMP(2);
     ph_patch(A.img1, A.rows1, A.cols1, A.stride1);
 
+    // offset table for the samplers, or null: on-the-fly sampling (block-uniform)
+    const uint16_t *samp = (A.samp && table_usable(*G, A.rows1, A.cols1)) ? A.samp : nullptr;
     Score sc{-INFINITY, -INFINITY, 0x7fffffff};
     for (int a0 = 0; a0 < K; a0 += kAnglesPerGroup) {
         const int Kg = (K - a0) < kAnglesPerGroup ? (K - a0) : kAnglesPerGroup;
-        ph_templates<S>(A.rot, A.samp, a0, Kg, A.rows1, A.cols1, A.dbg_templates, A.dbg_cycles);
+        ph_tpl_begin<S>(A.rot, a0, Kg, A.dbg_cycles);
+        if (samp) ph_tpl_table<S>(samp, a0, Kg, A.rows1, A.cols1);
+        else ph_tpl_general<S>(a0, Kg, A.rows1, A.cols1);
+        if (samp && A.samp_nflag > 0) ph_tpl_fix<S>(samp, a0, Kg, A.rows1, A.cols1, -1);
+        ph_tpl_end<S>(a0, Kg, A.dbg_templates, A.dbg_cycles);
         if (m->zero_flag) {                                            // pmlib.py:152-154
             if (tid < 5) out[tid] = NAN;
             if (oij && tid < 3) oij[tid] = -1;
@@ -1248,7 +1293,9 @@ __global__ __launch_bounds__(kMaxBlockM, kOccM) void pm_kernel_mfma(const PMArgs
     SID_STAMP(5);
 
 #ifndef SID_ABLATE_WINNER
-    ph_winner<S>(A.rot + 4 * ka, A.samp, A.rows1, A.cols1, ka, A.dbg_cycles);
+    ph_winner_stage<S>(A.rot + 4 * ka, samp, A.rows1, A.cols1, ka);
+    if (samp && A.samp_nflag > 0) ph_tpl_fix<S>(samp, 0, 0, A.rows1, A.cols1, ka);
+    ph_winner<S>(ka, A.dbg_cycles);
 #endif
     SID_STAMP(6);
     if (A.dbg_shape && tid == 0) { A.dbg_shape[0] = rh; A.dbg_shape[1] = rw; }
