@@ -468,7 +468,8 @@ SID_EXPORT int sid_pm_run(sid_pm_ctx *ctx)
         // 512-thread groups lose to 2 x 256 - they do not pack onto the SIMDs and serialise the phases.)
         const int per_cu = std::max(1, blocks_per_cu(b.lds));
         static const int force_nt = getenv("SID_PM_THREADS") ? atoi(getenv("SID_PM_THREADS")) : 0;   // A/B experiments
-        const int nthreads = force_nt ? force_nt : (per_cu == 1 ? 768 : 256);
+        static const int nt2 = getenv("SID_PM_THREADS2") ? atoi(getenv("SID_PM_THREADS2")) : 256;   // A/B: two-per-CU class
+        const int nthreads = force_nt ? force_nt : (per_cu == 1 ? 768 : (per_cu == 2 ? nt2 : 256));
         const int e = ctx->kernel == KERNEL_DOT4 ? sid::launch_pm(A, b.lds, ctx->stream)
                                                  : sid::launch_pm_mfma(A, b.lds, nthreads, ctx->stream);
         if (e != 0) return fail(SID_PM_ERR_HIP, "kernel launch failed: %s", hipGetErrorString((hipError_t)e));
