@@ -221,6 +221,87 @@ __device__ float block_median(const float *v, int n, MiscM *m, u32 *hist4) {
     return (key2f(key1) + key2f(key2)) / 2.0f;
 }
 
+// np.median, fast path: one log-spaced histogram over [min, max] of the keys (1024 buckets: the float bit
+// patterns are spread evenly, no hot bins), the bucket holding the middle rank is compacted into a list and
+// ranked by brute force.  Two passes over the data instead of the radix select's five; falls back to the
+// radix select when the bucket holds more than kMedList elements (massive ties).
+// hist: 1024 counters, list: kMedList keys (LDS scratch); tmin / tmax: this thread's min / max key of v.
+constexpr int kMedList = 256;
+__device__ float block_median_fast(const float *v, int n, MiscM *m, u32 *hist, u32 *list, u32 tmin, u32 tmax)
+{
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    u32 *red_max = reinterpret_cast<u32 *>(m->red_f);
+    tmin = wave_umin_dpp(tmin);
+    tmax = ~wave_umin_dpp(~tmax);
+    __syncthreads();
+    if (lane == 0) { m->red_i[w] = (int)tmin; red_max[w] = tmax; }
+    for (int i = tid; i < 1024; i += kBlockM) hist[i] = 0;
+    if (tid == 0) m->sel_cle = 0;
+    __syncthreads();
+    u32 kmin = (u32)m->red_i[0], kmax = red_max[0];
+    for (int q = 1; q < kWavesM; ++q) { const u32 a = (u32)m->red_i[q], b = red_max[q]; kmin = a < kmin ? a : kmin; kmax = b > kmax ? b : kmax; }
+    const u32 range = kmax - kmin;
+    const int shift = range < 1024u ? 0 : 22 - __clz(range);           // (range >> shift) < 1024
+    for (int i = tid; i < n; i += kBlockM) atomicAdd(&hist[(f2key(v[i]) - kmin) >> shift], 1u);
+    __syncthreads();
+    const bool two = !(n & 1);
+    const u32 k1 = two ? (u32)(n / 2 - 1) : (u32)(n / 2);
+    if (w == 0) {                                                      // 16 buckets per lane + a wavefront prefix sum
+        u32 c[16];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const uint4 c4 = *reinterpret_cast<const uint4 *>(hist + 16 * lane + 4 * q);
+            c[4 * q] = c4.x; c[4 * q + 1] = c4.y; c[4 * q + 2] = c4.z; c[4 * q + 3] = c4.w;
+        }
+        u32 tot = 0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) tot += c[q];
+        const u32 inc = wave_scan_dpp(tot), exc = inc - tot;
+        if (k1 >= exc && k1 < inc) {                                   // exactly one lane
+            u32 e = exc, bin = 16 * lane, cnt = 0;
+            bool found = false;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                if (!found) { if (k1 < e + c[q]) { found = true; bin = 16 * lane + q; cnt = c[q]; } else e += c[q]; }
+            }
+            m->sel_key = bin; m->red_i[14] = (int)e; m->red_i[15] = (int)cnt;
+        }
+    }
+    __syncthreads();
+    const u32 bin = m->sel_key, before = (u32)m->red_i[14], cnt = (u32)m->red_i[15];
+    if (cnt > (u32)kMedList) return block_median(v, n, m, hist);       // block-uniform
+    u32 above = 0xffffffffu;                                           // smallest key beyond the bucket
+    for (int i = tid; i < n; i += kBlockM) {
+        const u32 key = f2key(v[i]), b = (key - kmin) >> shift;
+        if (b == bin) list[atomicAdd(&m->sel_cle, 1u)] = key;
+        else if (b > bin && key < above) above = key;
+    }
+    above = block_min(above, m);                                       // (barriers inside: the list is complete)
+    if ((u32)tid < cnt) {
+        const u32 mine = list[tid];
+        u32 rank = 0;
+        for (u32 j = 0; j < cnt; ++j) { const u32 o = list[j]; rank += (o < mine || (o == mine && j < (u32)tid)) ? 1u : 0u; }
+        if (rank == k1 - before) m->sel_key = mine;
+        if (rank == k1 + 1 - before) m->best_key = (int)mine;
+    }
+    __syncthreads();
+    const u32 key1 = m->sel_key;
+    if (!two) return key2f(key1);
+    const u32 key2 = (k1 + 1 - before < cnt) ? (u32)m->best_key : above;
+    return (key2f(key1) + key2f(key2)) / 2.0f;
+}
+
+// two block sums with one pair of barriers (scratch: the rotation table of the template phase, dead by now)
+__device__ __forceinline__ void block_sum2(double &a, double &b, MiscM *m) {
+    a = wave_sum_dpp_d(a); b = wave_sum_dpp_d(b);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) { m->rot[threadIdx.x >> 6][0] = a; m->rot[threadIdx.x >> 6][1] = b; }
+    __syncthreads();
+    double ta = 0.0, tb = 0.0;
+    for (int w = 0; w < kWavesM; ++w) { ta += m->rot[w][0]; tb += m->rot[w][1]; }
+    a = ta; b = tb;
+}
+
 // np.std of a float32 LDS array from its double sums: sqrt(E[x^2] - E[x]^2) evaluated in double
 // (NumPy works in float32; the difference is ~1e-7 relative, inside the 1e-5 bar on h).
 __device__ __forceinline__ float std_from_sums(double sx, double sxx, int n) {
@@ -1131,8 +1212,10 @@ __device__ __noinline__ void ph_hessian(unsigned flags, int iy, int ix, float be
     float *hes = reinterpret_cast<float *>(smem + G.sii_off);
     const float *ccm = reinterpret_cast<const float *>(smem + G.u_off + 2 * G.trow_bytes);
     u32 *hist4 = reinterpret_cast<u32 *>(smem + G.u_off);             // winner operands are dead: 4 KB of histograms
+    u32 *medlist = hist4 + 1024;                                       // + 1 KB of keys (2 * trow_bytes >= 5 KB for every s)
     const int rh = G.rh, rw = G.rw, npos = G.npos;
     double sx = 0.0, sxx = 0.0;
+    float hmin = INFINITY, hmax = -INFINITY;
     {
         // np.gradient twice (unit spacing, one-sided edges) without branches:
         //   g(j) = (f[min(j+1,n-1)] - f[max(j-1,0)]) * (0 < j < n-1 ? 0.5 : 1),  d2(k) = same formula on g
@@ -1154,6 +1237,7 @@ __device__ __noinline__ void ph_hessian(unsigned flags, int iy, int ix, float be
             const float hv = (float)sqrt(hh);                          // hypotf: double sqrt, narrowed
             hes[idx] = hv;
             sx += (double)hv; sxx += (double)hv * (double)hv;
+            hmin = fminf(hmin, hv); hmax = fmaxf(hmax, hv);
         }
     }
     __syncthreads();
@@ -1166,20 +1250,24 @@ __device__ __noinline__ void ph_hessian(unsigned flags, int iy, int ix, float be
     if (dbg_cycles && tid == 0) dbg_cycles[14] = (long long)clock64();
     float h = hes[iy * rw + ix];
     if (flags & 1u) {
-        sx = block_sum(sx, m);
-        sxx = block_sum(sxx, m);
+        block_sum2(sx, sxx, m);
         const float sd = std_from_sums(sx, sxx, npos);
-        const float med = block_median(hes, npos, m, hist4);
+        const float med = block_median_fast(hes, npos, m, hist4, medlist, f2key(hmin), f2key(hmax));
         h = (h - med) / sd;
     }
     float rr = best_r;
     if (flags & 4u) {
         double cx = 0.0, cxx = 0.0;
-        for (int idx = tid; idx < npos; idx += kBlockM) { const double v = (double)ccm[idx]; cx += v; cxx += v * v; }
-        cx = block_sum(cx, m);
-        cxx = block_sum(cxx, m);
+        float cmin = INFINITY, cmax = -INFINITY;
+        for (int idx = tid; idx < npos; idx += kBlockM) {
+            const float c = ccm[idx];
+            const double v = (double)c;
+            cx += v; cxx += v * v;
+            cmin = fminf(cmin, c); cmax = fmaxf(cmax, c);
+        }
+        block_sum2(cx, cxx, m);
         const float sd = std_from_sums(cx, cxx, npos);
-        const float med = block_median(ccm, npos, m, hist4);
+        const float med = block_median_fast(ccm, npos, m, hist4, medlist, f2key(cmin), f2key(cmax));
         rr = (best_r - med) / sd;
     }
     __syncthreads();
