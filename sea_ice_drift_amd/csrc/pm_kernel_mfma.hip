@@ -72,7 +72,7 @@ struct Geo {
     int win_off, sii_off, u_off, patch_off, ppitch, pdim, pradius, queue_off, trow_bytes;
     int pr0, pc0;                    // patch origin on image 1
     u32 win_magic;                   // floor(2^32 / (wpitch/4)) + 1: idx / (wpitch/4) == umulhi(idx, win_magic) for idx < 2^16
-    u32 patch_magic, pad_[2];        // same for ppitch/4
+    u32 patch_magic, rw_magic, pad_; // same for ppitch/4 and for rw
     long long r0, c0;                // window origin on image 2
     double c1, r1, nd;
 };
@@ -1228,16 +1228,31 @@ __device__ __noinline__ void ph_hessian(unsigned flags, int iy, int ix, float be
             const float gm = (fc - fd) * ((km > 0 && km < n - 1) ? 0.5f : 1.0f);
             return (gp - gm) * ((k > 0 && k < n - 1) ? 0.5f : 1.0f);
         };
-#pragma unroll 2
-        for (int idx = tid; idx < npos; idx += kBlockM) {
-            const int y = idx / rw, x = idx - y * rw;
-            const float d2x = d2(ccm + y * rw, 1, x, rw);
-            const float d2y = d2(ccm + x, rw, y, rh);
-            const double hh = (double)d2x * (double)d2x + (double)d2y * (double)d2y;
-            const float hv = (float)sqrt(hh);                          // hypotf: double sqrt, narrowed
-            hes[idx] = hv;
-            sx += (double)hv; sxx += (double)hv * (double)hv;
-            hmin = fminf(hmin, hv); hmax = fmaxf(hmax, hv);
+        // four placements per thread in flight: the chains (index arithmetic -> 8 LDS reads -> double sqrt)
+        // are long and independent, so their latencies overlap; y = idx / rw through the reciprocal
+        const u32 magic = G.rw_magic;
+        constexpr int kHes = 4;
+        for (int base = 0; base < npos; base += kHes * kBlockM) {
+            float hv[kHes];
+#pragma unroll
+            for (int u = 0; u < kHes; ++u) {
+                const int idx = base + u * kBlockM + tid;
+                const int idc = idx < npos ? idx : 0;
+                const int y = (int)__umulhi((u32)idc, magic), x = idc - y * rw;
+                const float d2x = d2(ccm + y * rw, 1, x, rw);
+                const float d2y = d2(ccm + x, rw, y, rh);
+                const double hh = (double)d2x * (double)d2x + (double)d2y * (double)d2y;
+                hv[u] = (float)sqrt(hh);                               // hypotf: double sqrt, narrowed
+            }
+#pragma unroll
+            for (int u = 0; u < kHes; ++u) {
+                const int idx = base + u * kBlockM + tid;
+                if (idx < npos) {
+                    hes[idx] = hv[u];
+                    sx += (double)hv[u]; sxx += (double)hv[u] * (double)hv[u];
+                    hmin = fminf(hmin, hv[u]); hmax = fmaxf(hmax, hv[u]);
+                }
+            }
         }
     }
     __syncthreads();
@@ -1317,6 +1332,7 @@ __global__ __launch_bounds__(kMaxBlockM, kOccM) void pm_kernel_mfma(const PMArgs
         G->trow_bytes = L.trow_bytes;
         G->pr0 = (int)floor(r1) - L.pradius; G->pc0 = (int)floor(c1) - L.pradius;
         G->win_magic = 0xffffffffu / (u32)(L.wpitch >> 2) + 1u; G->patch_magic = 0xffffffffu / (u32)(L.ppitch >> 2) + 1u;
+        G->rw_magic = 0xffffffffu / (u32)rw + 1u;
         G->r0 = r0; G->c0 = c0; G->c1 = c1; G->r1 = r1; G->nd = (double)(s * s);
         m->zero_flag = 0; m->gmax_key = 0x007fffffu /* f2key(-inf) */; m->qcount = 0;
     }
