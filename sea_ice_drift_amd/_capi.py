@@ -26,6 +26,9 @@ SYMBOLS = (
     'sid_pm_debug_rsqrt',
 )
 
+# every symbol include/sid_ft.h declares (feature-tracking matcher, same library)
+FT_SYMBOLS = ('sid_ft_knn2', 'sid_ft_knn2_device', 'sid_ft_workspace_bytes', 'sid_ft_last_error')
+
 _u8p = C.POINTER(C.c_uint8)
 _f64p = C.POINTER(C.c_double)
 _f32p = C.POINTER(C.c_float)
@@ -78,6 +81,11 @@ def lib():
                                                                       C.c_uint32, _u8p, _f32p, _f32p, C.c_int64,
                                                                       _i32p, _f64p, _i32p, C.POINTER(C.c_int64)]
     L.sid_pm_debug_rsqrt.argtypes = [C.c_void_p, _f64p, _f64p, C.c_int64]
+    L.sid_ft_knn2.argtypes = [C.c_int, _u8p, C.c_int64, _u8p, C.c_int64, _i32p, _i32p]
+    L.sid_ft_knn2_device.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.sid_ft_workspace_bytes.argtypes = [C.c_int64, C.c_int64]
+    L.sid_ft_workspace_bytes.restype = C.c_int64
+    L.sid_ft_last_error.restype = C.c_char_p
     for name in SYMBOLS:
         getattr(L, name)                      # AttributeError here = header/library mismatch
     if L.sid_pm_abi_version() != ABI_VERSION:
@@ -267,3 +275,19 @@ class PMContext(object):
         y = np.empty_like(x)
         _check(lib().sid_pm_debug_rsqrt(self._h, _p(x, _f64p), _p(y, _f64p), x.size))
         return y
+
+
+def ft_knn2(desc1, desc2, device=0):
+    """Two nearest train descriptors (Hamming) of every query descriptor: include/sid_ft.h sid_ft_knn2.
+
+    desc1 [n1,32], desc2 [n2,32] uint8 -> (idx [n1,2] int32, dist [n1,2] int32), -1 where absent."""
+    d1 = np.ascontiguousarray(desc1, dtype=np.uint8).reshape(-1, 32)
+    d2 = np.ascontiguousarray(desc2, dtype=np.uint8).reshape(-1, 32)
+    idx = np.empty((len(d1), 2), dtype=np.int32)
+    dist = np.empty((len(d1), 2), dtype=np.int32)
+    L = lib()
+    rc = L.sid_ft_knn2(int(device), d1.ctypes.data_as(_u8p), len(d1), d2.ctypes.data_as(_u8p), len(d2),
+                       idx.ctypes.data_as(_i32p), dist.ctypes.data_as(_i32p))
+    if rc != 0:
+        raise SidPmError(rc, L.sid_ft_last_error().decode())
+    return idx, dist

@@ -1,4 +1,4 @@
-"""CPU test: the C-ABI library loads and exports every symbol include/sid_pm.h declares.
+"""CPU test: the C-ABI library loads and exports every symbol include/sid_pm.h and include/sid_ft.h declare.
 No compute call is made (there is no GPU here)."""
 import ctypes
 import os
@@ -15,14 +15,21 @@ def header_functions():
     return sorted(set(re.findall(r'\b(sid_pm_[a-z_0-9]+)\s*\(', src)))
 
 
+def ft_header_functions():
+    src = open(os.path.join(ROOT, 'include', 'sid_ft.h')).read()
+    src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
+    return sorted(set(re.findall(r'\b(sid_ft_[a-z_0-9]+)\s*\(', src)))
+
+
 def test_header_and_binding_agree():
     assert header_functions() == sorted(_capi.SYMBOLS)
+    assert ft_header_functions() == sorted(_capi.FT_SYMBOLS)
 
 
 def test_library_exports_every_declared_symbol():
     assert os.path.exists(_capi.LIB_PATH), 'build with __graft_entry__.build() first'
     lib = ctypes.CDLL(_capi.LIB_PATH)
-    for name in header_functions():
+    for name in header_functions() + ft_header_functions():
         assert hasattr(lib, name), name
     assert lib.sid_pm_abi_version() == _capi.ABI_VERSION
     lib.sid_pm_strerror.restype = ctypes.c_char_p
@@ -41,3 +48,11 @@ def test_argument_errors_without_a_device():
     assert lib.sid_pm_create(0, None) == -1
     assert lib.sid_pm_run(None) == -1
     assert b'null ctx' in lib.sid_pm_last_error()
+
+
+def test_matcher_argument_errors_without_a_device():
+    lib = _capi.lib()
+    assert lib.sid_ft_knn2(0, None, 4, None, 4, None, None) == -1
+    assert b'null pointer' in lib.sid_ft_last_error()
+    assert lib.sid_ft_knn2(0, None, 0, None, 0, None, None) == 0          # nothing to do
+    assert lib.sid_ft_workspace_bytes(1000, 1000) >= 8 * 1000
