@@ -934,7 +934,7 @@ __device__ __forceinline__ void sweep_item(v4i (&acc)[kBand], const uint8_t *ap,
 //   true arg-max is always queued.
 // ---------------------------------------------------------------------------------------------
 template <int S>
-__device__ __noinline__ Score ph_sweep(Score sc, int a0, int Kg, long long *dbg_cycles)
+__device__ __forceinline__ Score ph_sweep(Score sc, int a0, int Kg, long long *dbg_cycles)
 {
     SID_PHASE_LOCALS;
     const uint8_t *afrag = smem + G.u_off;
