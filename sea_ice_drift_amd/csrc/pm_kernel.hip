@@ -46,10 +46,6 @@ struct Misc {                       // lives at LDS offset 0, kMiscBytes reserve
 };
 static_assert(sizeof(Misc) <= kMiscBytes, "misc header too large");
 
-__device__ __forceinline__ float wave_sum(float v) {
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
-}
 __device__ __forceinline__ double wave_sum(double v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
     return v;
@@ -67,14 +63,6 @@ __device__ __forceinline__ double block_sum(double v, Misc *m) {
     if ((threadIdx.x & 63) == 0) m->red_d[w] = v;
     __syncthreads();
     return (m->red_d[0] + m->red_d[1]) + (m->red_d[2] + m->red_d[3]);
-}
-__device__ __forceinline__ u32 block_sum(u32 v, Misc *m) {
-    v = wave_sum(v);
-    const int w = threadIdx.x >> 6;
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) m->red_i[w] = (int)v;
-    __syncthreads();
-    return (u32)m->red_i[0] + (u32)m->red_i[1] + (u32)m->red_i[2] + (u32)m->red_i[3];
 }
 __device__ __forceinline__ u32 block_min(u32 v, Misc *m) {
     for (int o = 32; o > 0; o >>= 1) { u32 t = __shfl_xor(v, o); v = t < v ? t : v; }

@@ -143,15 +143,6 @@ __device__ __forceinline__ double wave_sum_dpp_d(double v) {
 
 // ---- small block utilities (same semantics as in pm_kernel.hip) ----
 
-__device__ __forceinline__ double block_sum(double v, MiscM *m) {
-    v = wave_sum_dpp_d(v);
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) m->red_d[threadIdx.x >> 6] = v;
-    __syncthreads();
-    double t = 0.0;
-    for (int w = 0; w < kWavesM; ++w) t += m->red_d[w];
-    return t;
-}
 __device__ __forceinline__ u32 block_min(u32 v, MiscM *m) {
     v = wave_umin_dpp(v);
     __syncthreads();
@@ -1174,21 +1165,26 @@ __device__ __noinline__ void ph_winner(int ka, long long *dbg_cycles)
         };
         Ops o0 = issue(), o1 = issue(), o2;
         constexpr int kStepsFixed = S > 0 ? 16 + S - 1 : 0;
-        const int nloop = S > 0 ? kStepsFixed : nsteps;
+        // six steps per trip (three operand sets x even / odd accumulators), leaving the loop after the last step
+#define SID_WINNER_SIX(step, n)                                                                                        \
+        o2 = issue(); __builtin_amdgcn_sched_barrier(0); mma(o0, accT, accS); __builtin_amdgcn_sched_barrier(0);      \
+        if ((step) + 1 >= (n)) break;                                                                                  \
+        o0 = issue(); __builtin_amdgcn_sched_barrier(0); mma(o1, accT1, accS1); __builtin_amdgcn_sched_barrier(0);    \
+        if ((step) + 2 >= (n)) break;                                                                                  \
+        o1 = issue(); __builtin_amdgcn_sched_barrier(0); mma(o2, accT, accS); __builtin_amdgcn_sched_barrier(0);      \
+        if ((step) + 3 >= (n)) break;                                                                                  \
+        o2 = issue(); __builtin_amdgcn_sched_barrier(0); mma(o0, accT1, accS1); __builtin_amdgcn_sched_barrier(0);    \
+        if ((step) + 4 >= (n)) break;                                                                                  \
+        o0 = issue(); __builtin_amdgcn_sched_barrier(0); mma(o1, accT, accS); __builtin_amdgcn_sched_barrier(0);      \
+        if ((step) + 5 >= (n)) break;                                                                                  \
+        o1 = issue(); __builtin_amdgcn_sched_barrier(0); mma(o2, accT1, accS1); __builtin_amdgcn_sched_barrier(0);
+        if (S > 0) {
 #pragma unroll
-        for (int step = 0; step < nloop; step += 6) {                  // even and odd steps: separate accumulators
-            o2 = issue(); __builtin_amdgcn_sched_barrier(0); mma(o0, accT, accS); __builtin_amdgcn_sched_barrier(0);
-            if (step + 1 >= nloop) break;
-            o0 = issue(); __builtin_amdgcn_sched_barrier(0); mma(o1, accT1, accS1); __builtin_amdgcn_sched_barrier(0);
-            if (step + 2 >= nloop) break;
-            o1 = issue(); __builtin_amdgcn_sched_barrier(0); mma(o2, accT, accS); __builtin_amdgcn_sched_barrier(0);
-            if (step + 3 >= nloop) break;
-            o2 = issue(); __builtin_amdgcn_sched_barrier(0); mma(o0, accT1, accS1); __builtin_amdgcn_sched_barrier(0);
-            if (step + 4 >= nloop) break;
-            o0 = issue(); __builtin_amdgcn_sched_barrier(0); mma(o1, accT, accS); __builtin_amdgcn_sched_barrier(0);
-            if (step + 5 >= nloop) break;
-            o1 = issue(); __builtin_amdgcn_sched_barrier(0); mma(o2, accT1, accS1); __builtin_amdgcn_sched_barrier(0);
+            for (int step = 0; step < kStepsFixed; step += 6) { SID_WINNER_SIX(step, kStepsFixed) }
+        } else {
+            for (int step = 0; step < nsteps; step += 6) { SID_WINNER_SIX(step, nsteps) }
         }
+#undef SID_WINNER_SIX
         accT += accT1; accS += accS1;
         const int x = x0 + n_l;
 #pragma unroll
