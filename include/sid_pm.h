@@ -95,10 +95,14 @@ void sid_pm_destroy(sid_pm_ctx *ctx);
 /* HIP stream (hipStream_t as void*) all later work of this handle is enqueued on; NULL = default */
 int sid_pm_set_stream(sid_pm_ctx *ctx, void *hip_stream);
 
-/* Copy a host image pair into handle-owned device buffers (asynchronous on the stream;
- * the host buffers must stay valid until sid_pm_sync).  `slot` 0/1 selects one of two
- * device pairs so pair k+1 can upload while pair k is matched; sid_pm_select_pair picks
- * the one the next run uses. */
+/* Copy a host image pair into handle-owned device buffers.  The copy is enqueued on the
+ * handle's own copy stream: it overlaps the kernels of a run in flight (truly asynchronous
+ * when the host buffers are pinned - hipHostRegister / hipHostMalloc / torch pin_memory -
+ * and staged synchronously otherwise); the host buffers must stay valid until the run that
+ * uses the pair has been synchronised.  `slot` 0/1 selects one of two device pairs so that
+ * pair k+1 uploads while pair k is matched (BASELINE config 5); sid_pm_select_pair picks the
+ * one the next run uses.  Ordering is handled inside: a run waits for the upload of its
+ * slot, an upload waits for the runs that still read its slot. */
 int sid_pm_upload_pair(sid_pm_ctx *ctx, int slot,
                        const uint8_t *img1, int64_t rows1, int64_t cols1, int64_t stride1,
                        const uint8_t *img2, int64_t rows2, int64_t cols2, int64_t stride2);

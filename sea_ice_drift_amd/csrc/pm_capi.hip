@@ -83,6 +83,11 @@ struct sid_pm_ctx {
     Image cur[2];
     bool have_pair = false;
     int cur_slot = -1;                  // -1: borrowed binding (or none)
+    // pair streaming: uploads run on their own stream; slot_ready[s] = upload of slot s complete,
+    // slot_done[s] = last kernels reading slot s complete (an upload into s waits for it)
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t slot_ready[2] = {nullptr, nullptr}, slot_done[2] = {nullptr, nullptr};
+    bool ready_rec[2] = {false, false}, done_rec[2] = {false, false};
     // resident points
     DevBuf<double> vec;                 // 5 * n
     DevBuf<int32_t> order;
@@ -279,6 +284,15 @@ SID_EXPORT int sid_pm_create(int device, sid_pm_ctx **out)
     sid_pm_ctx *ctx = new (std::nothrow) sid_pm_ctx();
     if (!ctx) return fail(SID_PM_ERR_NOMEM, "host allocation failed");
     ctx->device = device;
+    {
+        Guard g(device);
+        hipError_t e = hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking);
+        for (int k = 0; k < 2 && e == hipSuccess; ++k) {
+            e = hipEventCreateWithFlags(&ctx->slot_ready[k], hipEventDisableTiming);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->slot_done[k], hipEventDisableTiming);
+        }
+        if (e != hipSuccess) { sid_pm_destroy(ctx); return fail(SID_PM_ERR_HIP, "stream/event creation failed: %s", hipGetErrorString(e)); }
+    }
     const char *kk = getenv("SID_PM_KERNEL");
     if (kk && strcmp(kk, "dot4") == 0) ctx->kernel = KERNEL_DOT4;
     *out = ctx;
@@ -290,6 +304,11 @@ SID_EXPORT void sid_pm_destroy(sid_pm_ctx *ctx)
     if (!ctx) return;
     Guard g(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->copy_stream) { (void)hipStreamSynchronize(ctx->copy_stream); (void)hipStreamDestroy(ctx->copy_stream); }
+    for (int k = 0; k < 2; ++k) {
+        if (ctx->slot_ready[k]) (void)hipEventDestroy(ctx->slot_ready[k]);
+        if (ctx->slot_done[k]) (void)hipEventDestroy(ctx->slot_done[k]);
+    }
     for (auto &pair : ctx->own) for (auto &b : pair) b.release();
     ctx->vec.release(); ctx->order.release(); ctx->angles.release(); ctx->rot.release(); ctx->samp.release();
     ctx->out.release(); ctx->out_ij.release();
@@ -312,14 +331,25 @@ SID_EXPORT int sid_pm_upload_pair(sid_pm_ctx *ctx, int slot,
     Image h[2] = {{img1, rows1, cols1, stride1}, {img2, rows2, cols2, stride2}};
     if (int rc = check_images(h[0], h[1])) return rc;
     Guard g(ctx->device);
+    // The copy runs on the context's copy stream, so that the upload of the next pair overlaps the kernels
+    // of the current one (asynchronous when the host buffers are pinned, e.g. hipHostRegister /
+    // torch pin_memory; staged synchronously otherwise).  It waits for the kernels that still read this slot.
+    if (ctx->done_rec[slot]) HIP_TRY(hipStreamWaitEvent(ctx->copy_stream, ctx->slot_done[slot], 0));
     for (int k = 0; k < 2; ++k) {
         // device copy is packed to a 256-byte multiple pitch (coalesced, dword-aligned rows)
         const int64_t pitch = (h[k].cols + 255) / 256 * 256;
-        if (int rc = ctx->own[slot][k].reserve((size_t)(pitch * h[k].rows))) return rc;
+        const size_t need = (size_t)(pitch * h[k].rows);
+        if (ctx->own[slot][k].cap < need) {                // growing frees the old buffer: nothing may still read it
+            HIP_TRY(hipStreamSynchronize(ctx->stream));
+            HIP_TRY(hipStreamSynchronize(ctx->copy_stream));
+        }
+        if (int rc = ctx->own[slot][k].reserve(need)) return rc;
         HIP_TRY(hipMemcpy2DAsync(ctx->own[slot][k].p, (size_t)pitch, h[k].ptr, (size_t)h[k].stride,
-                                 (size_t)h[k].cols, (size_t)h[k].rows, hipMemcpyHostToDevice, ctx->stream));
+                                 (size_t)h[k].cols, (size_t)h[k].rows, hipMemcpyHostToDevice, ctx->copy_stream));
         ctx->slot_img[slot][k] = Image{ctx->own[slot][k].p, h[k].rows, h[k].cols, pitch};
     }
+    HIP_TRY(hipEventRecord(ctx->slot_ready[slot], ctx->copy_stream));
+    ctx->ready_rec[slot] = true;
     if (!ctx->have_pair || ctx->cur_slot == slot) {       // first pair, or refresh of the selected slot
         ctx->cur[0] = ctx->slot_img[slot][0]; ctx->cur[1] = ctx->slot_img[slot][1];
         ctx->have_pair = true; ctx->cur_slot = slot;
@@ -457,6 +487,8 @@ SID_EXPORT int sid_pm_run(sid_pm_ctx *ctx)
     Guard g(ctx->device);
     sid::PMArgs A;
     fill_args(ctx, A);
+    if (ctx->cur_slot >= 0 && ctx->ready_rec[ctx->cur_slot])
+        HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->slot_ready[ctx->cur_slot], 0));
     static const int lds_pad = getenv("SID_PM_LDS_PAD") ? atoi(getenv("SID_PM_LDS_PAD")) : 0;   // occupancy experiments
     for (const Bucket &b0 : ctx->buckets) {
         Bucket b = b0;
@@ -473,6 +505,10 @@ SID_EXPORT int sid_pm_run(sid_pm_ctx *ctx)
         const int e = ctx->kernel == KERNEL_DOT4 ? sid::launch_pm(A, b.lds, ctx->stream)
                                                  : sid::launch_pm_mfma(A, b.lds, nthreads, ctx->stream);
         if (e != 0) return fail(SID_PM_ERR_HIP, "kernel launch failed: %s", hipGetErrorString((hipError_t)e));
+    }
+    if (ctx->cur_slot >= 0) {
+        HIP_TRY(hipEventRecord(ctx->slot_done[ctx->cur_slot], ctx->stream));
+        ctx->done_rec[ctx->cur_slot] = true;
     }
     return SID_PM_OK;
 }
@@ -582,6 +618,7 @@ SID_EXPORT int sid_pm_debug_point(sid_pm_ctx *ctx, double c1, double r1, double 
     hipError_t e = hipSuccess;
     auto step = [&](hipError_t x) { if (e == hipSuccess) e = x; };
     step(hipStreamSynchronize(ctx->stream));
+    if (ctx->copy_stream) step(hipStreamSynchronize(ctx->copy_stream));   // a pending upload of the selected pair
     step(hipMemcpy(dv.p, v5, sizeof v5, hipMemcpyHostToDevice));
     step(hipMemcpy(dang.p, angles, sizeof(double) * K, hipMemcpyHostToDevice));
     step(hipMemcpy(drot.p, rotv.data(), sizeof(double) * rotv.size(), hipMemcpyHostToDevice));

@@ -142,3 +142,27 @@ def test_ties_and_degenerate_inputs(pm_ctx, c_oracle):
     np.testing.assert_array_equal(got[:, :4], exp[:, :4])
     assert exp[0, 3] == 1.0 and exp[1, 3] == 1.0 and exp[2, 3] == 0.0
     assert tuple(exp_ij[1]) == (0, 0, 0) and tuple(exp_ij[2]) == (0, 0, 0)
+
+
+def test_pair_streaming_through_two_slots(pm_ctx, c_oracle):
+    """BASELINE config 5 in miniature: pairs streamed back to back through the two device slots (upload of
+    pair k+1 on the copy stream while pair k is matched) give the results of matching each pair alone."""
+    import torch
+    pairs = [syn.make_pair(500, 500, seed=40 + k) for k in range(5)]
+    pinned = [[torch.from_numpy(im).pin_memory() for im in p] for p in pairs]     # pinned: the copies are asynchronous
+    g = syn.make_grid(500, 500, 8, margin=90)
+    rot = rot_for(ANGLES7, 0.0, 34)
+    pm_ctx.upload_pair(pinned[0][0].numpy(), pinned[0][1].numpy(), slot=0)
+    pm_ctx.set_points(g['c1'], g['r1'], g['c2fg'], g['r2fg'], g['border'], 34, 0.0, ANGLES7, rot=rot)
+    results = []
+    for k in range(len(pairs)):
+        pm_ctx.select_pair(k % 2)
+        if k + 1 < len(pairs):
+            pm_ctx.upload_pair(pinned[k + 1][0].numpy(), pinned[k + 1][1].numpy(), slot=(k + 1) % 2)
+        pm_ctx.run()
+        results.append(pm_ctx.fetch())
+    for k, (img1, img2) in enumerate(pairs):
+        exp, exp_ij = c_oracle.pm_batch(img1, img2, g['c1'], g['r1'], g['c2fg'], g['r2fg'], g['border'], 34, 0.0,
+                                        ANGLES7, rot=rot, nthreads=8)
+        assert_parity(results[k][0], results[k][1], exp, exp_ij)
+    assert not np.array_equal(results[0][1], results[1][1])            # the pairs really differ
