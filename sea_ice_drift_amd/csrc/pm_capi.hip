@@ -51,7 +51,7 @@ struct Image {
     int64_t rows = 0, cols = 0, stride = 0;
 };
 
-struct Bucket { int offset, count, lds; };
+struct Bucket { int offset, count, lds, band; };   // band: output rows per sweep work item of this launch (4 or 8)
 
 template <typename T>
 struct DevBuf {
@@ -205,9 +205,9 @@ bool size_supported(int kernel, int s)
     return kernel == KERNEL_DOT4 ? sid::img_size_supported(s) : sid::mfma_img_size_supported(s);
 }
 
-int lds_need(int kernel, int wh, int ww, int s, int K)
+int lds_need(int kernel, int wh, int ww, int s, int K, int band = 4)
 {
-    return kernel == KERNEL_DOT4 ? sid::lds_layout(wh, ww, s, K).total : sid::mfma_lds_layout(wh, ww, s).total;
+    return kernel == KERNEL_DOT4 ? sid::lds_layout(wh, ww, s, K).total : sid::mfma_lds_layout(wh, ww, s, band).total;
 }
 
 int check_sweep(int kernel, int img_size, const double *angles, int n_angles, uint32_t flags)
@@ -393,20 +393,29 @@ SID_EXPORT int sid_pm_set_points(sid_pm_ctx *ctx, const double *c1, const double
     const int64_t rows2 = ctx->cur[1].rows, cols2 = ctx->cur[1].cols;
 
     // classify: LDS footprint -> residency class (blocks per CU), work for ordering
-    struct P { int idx; int lds; int cls; double work; };
+    struct P { int idx; int lds; int cls; double work; int band = 4; bool force1 = false; };
+    static const bool no_band8 = getenv("SID_PM_NO_BAND8") != nullptr;                      // A/B runs
+    const bool band8_ok = ctx->kernel == KERNEL_MFMA && sid::mfma_band8_supported(s) && !no_band8;
     std::vector<P> pts((size_t)n);
     const int lds_min = lds_need(ctx->kernel, s + 1, s + 1, s, K);
     double macs = 0, bytes = 0, valid = 0;
     int lds_max = 0;
     for (int64_t i = 0; i < n; ++i) {
         int wh = 0, ww = 0;
-        P p{(int)i, lds_min, 0, 0.0};
+        P p; p.idx = (int)i; p.lds = lds_min; p.cls = 0; p.work = 0.0;
         if (window_dims(c2fg[i], r2fg[i], border[i], s, rows2, cols2, wh, ww)) {
             const int need = lds_need(ctx->kernel, wh, ww, s, K);
             if (need > sid::max_lds_bytes())
                 return fail(SID_PM_ERR_UNSUPPORTED, "point %lld: search window %dx%d needs %d bytes of LDS (> %d)",
                             (long long)i, wh, ww, need, sid::max_lds_bytes());
             p.lds = need;
+            // the two-per-CU class runs the 8-row-band kernel (two wavefronts per SIMD leave it 256 VGPRs); its
+            // window carries 4 more zero rows, and a point that then no longer fits twice stays with band 4
+            if (band8_ok && blocks_per_cu(need) == 2) {
+                const int need8 = lds_need(ctx->kernel, wh, ww, s, K, 8);
+                if (blocks_per_cu(need8) == 2) { p.lds = need8; p.band = 8; }
+                else p.force1 = true;
+            }
             const double rh = wh - s + 1, rw = ww - s + 1;
             p.work = rh * rw;
             macs += (double)K * rh * rw * s * s;
@@ -414,7 +423,7 @@ SID_EXPORT int sid_pm_set_points(sid_pm_ctx *ctx, const double *c1, const double
             bytes += (double)wh * ww + 51.0 * 51.0 + 40.0 + 52.0;
             valid += 1;
         }
-        p.cls = std::min(8, blocks_per_cu(p.lds));
+        p.cls = p.force1 ? 1 : std::min(8, blocks_per_cu(p.lds));
         lds_max = std::max(lds_max, p.lds);
         pts[(size_t)i] = p;
     }
@@ -428,7 +437,7 @@ SID_EXPORT int sid_pm_set_points(sid_pm_ctx *ctx, const double *c1, const double
     for (int64_t i = 0; i < n; ++i) {
         order[(size_t)i] = pts[(size_t)i].idx;
         if (ctx->buckets.empty() || pts[(size_t)i].cls != pts[(size_t)(i - 1)].cls)
-            ctx->buckets.push_back(Bucket{(int)i, 0, 0});
+            ctx->buckets.push_back(Bucket{(int)i, 0, 0, pts[(size_t)i].band});
         Bucket &b = ctx->buckets.back();
         b.count += 1;
         b.lds = std::max(b.lds, pts[(size_t)i].lds);
@@ -498,12 +507,12 @@ SID_EXPORT int sid_pm_run(sid_pm_ctx *ctx)
         // 256 threads per point; 768 when the LDS footprint leaves room for one point per CU only, so that
         // the CU still carries 12 wavefronts (3 per SIMD = the register budget).  (Measured: 384- and
         // 512-thread groups lose to 2 x 256 - they do not pack onto the SIMDs and serialise the phases.)
-        const int per_cu = std::max(1, blocks_per_cu(b.lds));
+        const int per_cu = b.band == 8 ? 2 : std::max(1, blocks_per_cu(b.lds));
         static const int force_nt = getenv("SID_PM_THREADS") ? atoi(getenv("SID_PM_THREADS")) : 0;   // A/B experiments
         static const int nt2 = getenv("SID_PM_THREADS2") ? atoi(getenv("SID_PM_THREADS2")) : 256;   // A/B: two-per-CU class
         const int nthreads = force_nt ? force_nt : (per_cu == 1 ? 768 : (per_cu == 2 ? nt2 : 256));
         const int e = ctx->kernel == KERNEL_DOT4 ? sid::launch_pm(A, b.lds, ctx->stream)
-                                                 : sid::launch_pm_mfma(A, b.lds, nthreads, ctx->stream);
+                                                 : sid::launch_pm_mfma(A, b.lds, b.band == 8 ? 256 : nthreads, b.band, ctx->stream);
         if (e != 0) return fail(SID_PM_ERR_HIP, "kernel launch failed: %s", hipGetErrorString((hipError_t)e));
     }
     if (ctx->cur_slot >= 0) {
@@ -640,7 +649,7 @@ SID_EXPORT int sid_pm_debug_point(sid_pm_ctx *ctx, double c1, double r1, double 
         A.dbg_cycles = dcyc.p;
         A.samp = sampv.empty() ? nullptr : dsamp.p; A.samp_nflag = nflag;
         step((hipError_t)(ctx->kernel == KERNEL_DOT4 ? sid::launch_pm(A, lds, ctx->stream)
-                                                     : sid::launch_pm_mfma(A, lds, getenv("SID_PM_THREADS") ? atoi(getenv("SID_PM_THREADS")) : 256, ctx->stream)));
+                                                     : sid::launch_pm_mfma(A, lds, getenv("SID_PM_THREADS") ? atoi(getenv("SID_PM_THREADS")) : 256, 4, ctx->stream)));
         step(hipStreamSynchronize(ctx->stream));
         if (templates) step(hipMemcpy(templates, dt.p, tcount, hipMemcpyDeviceToHost));
         if (ccm && cap > 0) step(hipMemcpy(ccm, dccm.p, sizeof(float) * cap, hipMemcpyDeviceToHost));

@@ -64,7 +64,6 @@ __host__ __device__ inline LdsLayout lds_layout(int wh, int ww, int s, int K)
 
 // ---- MFMA kernel (pm_kernel_mfma.hip) ----
 constexpr int kMiscMfmaBytes = 2816;
-constexpr int kBandRowsPad = 3;     // zero rows below the window: the sweep steps past it without clamping
 constexpr int kTrowPad = 36;         // zero rows around a winner operand block: 16 above, 20 below (the step loop runs in fours)
 constexpr int kQueueCap = 192;       // arg-max candidates waiting for exact evaluation (16 B each)
 
@@ -80,7 +79,9 @@ struct MfmaLdsLayout {
     int total;
 };
 
-__host__ __device__ inline MfmaLdsLayout mfma_lds_layout(int wh, int ww, int s)
+// band = output rows per sweep work item (4, or 8 in the two-workgroups-per-CU kernel): band-1 zero rows follow
+// the window so that the sweep steps past it without clamping
+__host__ __device__ inline MfmaLdsLayout mfma_lds_layout(int wh, int ww, int s, int band = 4)
 {
     MfmaLdsLayout L;
     const int rh = wh - s + 1, rw = ww - s + 1;
@@ -88,7 +89,7 @@ __host__ __device__ inline MfmaLdsLayout mfma_lds_layout(int wh, int ww, int s)
     L.wpitch = 16 * ntx + 68;                       // a window fragment reads 5 dwords from (x0+15+48) & ~3
     if (L.wpitch < round_up(ww, 4)) L.wpitch = round_up(ww, 4);
     L.win_off = kMiscMfmaBytes;
-    L.sii_off = round_up(L.win_off + (wh + kBandRowsPad) * L.wpitch, 16);
+    L.sii_off = round_up(L.win_off + (wh + band - 1) * L.wpitch, 16);
     L.u_off = round_up(L.sii_off + rh * rw * 4, 16);
     L.arow = s <= 48 ? 768 : 1024;                  // columns >= 48 of a template row are zero unless s = 49
     // rotated template samples stay within hypot(tc, tc) of the centre, tc = int(s/2)+1 (pmlib.py:105)
@@ -112,7 +113,8 @@ __host__ __device__ inline MfmaLdsLayout mfma_lds_layout(int wh, int ww, int s)
 __host__ __device__ inline int samp_pitch(int s) { return round_up(s, 4); }
 constexpr double kSampGuard = 1e-5;   // table entries whose coordinate is this close to k + 1/2 are flagged
 
-int launch_pm_mfma(const PMArgs &args, int lds_bytes, int nthreads, void *stream);
+int launch_pm_mfma(const PMArgs &args, int lds_bytes, int nthreads, int band, void *stream);
+bool mfma_band8_supported(int s);
 bool mfma_img_size_supported(int s);
 
 // host-side launcher implemented in pm_kernel.hip; returns a hipError_t as int

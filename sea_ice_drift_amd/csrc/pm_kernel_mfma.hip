@@ -41,7 +41,6 @@ typedef int v4i __attribute__((ext_vector_type(4)));
 constexpr int kMaxBlockM = 768;
 #define kBlockM ((int)blockDim.x)
 #define kWavesM ((int)(blockDim.x >> 6))
-constexpr int kBand = 4;             // output rows per sweep work item
 constexpr int kOccM = 3;             // wavefronts per SIMD the register allocation must allow
 constexpr int kSlots = 16;           // MFMA M: 15 angles + ones
 constexpr int kAnglesPerGroup = 15;
@@ -72,7 +71,8 @@ struct Geo {
     int win_off, sii_off, u_off, patch_off, ppitch, pdim, pradius, queue_off, trow_bytes;
     int pr0, pc0;                    // patch origin on image 1
     u32 win_magic;                   // floor(2^32 / (wpitch/4)) + 1: idx / (wpitch/4) == umulhi(idx, win_magic) for idx < 2^16
-    u32 patch_magic, rw_magic, pad_; // same for ppitch/4 and for rw
+    u32 patch_magic, rw_magic;       // same for ppitch/4 and for rw
+    int band;                        // output rows per sweep work item (kernel template parameter)
     long long r0, c0;                // window origin on image 2
     double c1, r1, nd;
 };
@@ -341,7 +341,7 @@ __device__ __noinline__ void ph_window(const uint8_t *img2, long long rows2, lon
     SID_PHASE_LOCALS;
     uint8_t *win = smem + G.win_off;
     const int wpitch = G.wpitch, ww = G.ww, wh = G.wh;
-    const int dw_per_row = wpitch >> 2, ndw = (wh + kBand - 1) * dw_per_row;    // + kBand-1 zero rows below
+    const int dw_per_row = wpitch >> 2, ndw = (wh + G.band - 1) * dw_per_row;   // + band-1 zero rows below
     const u32 magic = G.win_magic;
     const int st = (int)stride2;
     // all addresses as 32-bit offsets from the (dword-aligned) window origin: no 64-bit multiplies, no divisions
@@ -854,7 +854,7 @@ __device__ __forceinline__ v4i align_raw(const Raw5 &w, u32 sh)
     return b;
 }
 
-template <int S>
+template <int S, int kBand>
 __device__ __forceinline__ void sweep_item(v4i (&acc)[kBand], const uint8_t *ap, int arow_l, const uint8_t *bp,
                                            int wpitch, int s, u32 sh)
 {
@@ -924,7 +924,7 @@ __device__ __forceinline__ void sweep_item(v4i (&acc)[kBand], const uint8_t *ap,
 //   of the running maximum are queued for exact evaluation.  |estimate - value| <= 4e-7, so the
 //   true arg-max is always queued.
 // ---------------------------------------------------------------------------------------------
-template <int S>
+template <int S, int kBand>
 __device__ __forceinline__ Score ph_sweep(Score sc, int a0, int Kg, long long *dbg_cycles)
 {
     SID_PHASE_LOCALS;
@@ -961,7 +961,7 @@ __device__ __forceinline__ Score ph_sweep(Score sc, int a0, int Kg, long long *d
         const u32 sh = sbyte & 3u;
         if (item == wv) STAMP2(10);
         v4i acc[kBand];
-        sweep_item<S>(acc, abase, arow_l, win + y0 * wpitch + (sbyte & ~3u), wpitch, s, sh);
+        sweep_item<S, kBand>(acc, abase, arow_l, win + y0 * wpitch + (sbyte & ~3u), wpitch, s, sh);
         if (item == wv) STAMP2(11);
 
         {
@@ -1286,8 +1286,10 @@ __device__ __noinline__ void ph_hessian(unsigned flags, int iy, int ix, float be
     __syncthreads();
 }
 
-template <int S>
-__global__ __launch_bounds__(kMaxBlockM, kOccM) void pm_kernel_mfma(const PMArgs A)
+// BAND = 4: up to 768 threads, three wavefronts per SIMD (168 VGPRs).  BAND = 8: 256 threads, two per SIMD (the
+// class whose LDS footprint admits two workgroups per CU anyway): an 8-row band halves the LDS bytes per MFMA.
+template <int S, int BAND>
+__global__ __launch_bounds__(BAND == 8 ? 256 : kMaxBlockM, BAND == 8 ? 2 : kOccM) void pm_kernel_mfma(const PMArgs A)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     MiscM *m = reinterpret_cast<MiscM *>(smem);
@@ -1319,8 +1321,9 @@ __global__ __launch_bounds__(kMaxBlockM, kOccM) void pm_kernel_mfma(const PMArgs
     const int wh = (int)(r1e - r0), ww = (int)(c1e - c0);
     const int rh = wh - s + 1, rw = ww - s + 1, npos = rh * rw;
     if (tid == 0) {
-        const MfmaLdsLayout L = mfma_lds_layout(wh, ww, s);
+        const MfmaLdsLayout L = mfma_lds_layout(wh, ww, s, BAND);
         const double c1 = A.c1[pt], r1 = A.r1[pt];
+        G->band = BAND;
         G->wh = wh; G->ww = ww; G->rh = rh; G->rw = rw; G->npos = npos; G->wpitch = L.wpitch; G->arow = L.arow;
         G->s = s; G->K = K;
         G->win_off = L.win_off; G->sii_off = L.sii_off; G->u_off = L.u_off; G->patch_off = L.patch_off;
@@ -1361,7 +1364,7 @@ __global__ __launch_bounds__(kMaxBlockM, kOccM) void pm_kernel_mfma(const PMArgs
         }
         SID_STAMP(3);
 #ifndef SID_ABLATE_SWEEP
-        sc = ph_sweep<S>(sc, a0, Kg, A.dbg_cycles);
+        sc = ph_sweep<S, BAND>(sc, a0, Kg, A.dbg_cycles);
 #else
         sc.bestv = 0.5f; sc.bestkey = 17;
 #endif
@@ -1417,13 +1420,19 @@ __global__ __launch_bounds__(kMaxBlockM, kOccM) void pm_kernel_mfma(const PMArgs
 
 bool mfma_img_size_supported(int s) { return s >= 2 && s + 15 <= 64; }
 
-int launch_pm_mfma(const PMArgs &args, int lds_bytes, int nthreads, void *stream)
+bool mfma_band8_supported(int s) { return s == 34 || s == 35; }
+
+int launch_pm_mfma(const PMArgs &args, int lds_bytes, int nthreads, int band, void *stream)
 {
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (args.n_launch <= 0) return (int)hipSuccess;
-    void (*kern)(const PMArgs) = pm_kernel_mfma<0>;
-    if (args.img_size == 34) kern = pm_kernel_mfma<34>;
-    else if (args.img_size == 35) kern = pm_kernel_mfma<35>;
+    void (*kern)(const PMArgs) = pm_kernel_mfma<0, 4>;
+    if (band == 8) {
+        if (!mfma_band8_supported(args.img_size) || nthreads != 256) return (int)hipErrorInvalidValue;
+        kern = args.img_size == 34 ? pm_kernel_mfma<34, 8> : pm_kernel_mfma<35, 8>;
+    } else if (band != 4) return (int)hipErrorInvalidValue;
+    else if (args.img_size == 34) kern = pm_kernel_mfma<34, 4>;
+    else if (args.img_size == 35) kern = pm_kernel_mfma<35, 4>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
     if (e != hipSuccess) return (int)e;
