@@ -393,7 +393,7 @@ SID_EXPORT int sid_pm_set_points(sid_pm_ctx *ctx, const double *c1, const double
     const int64_t rows2 = ctx->cur[1].rows, cols2 = ctx->cur[1].cols;
 
     // classify: LDS footprint -> residency class (blocks per CU), work for ordering
-    struct P { int idx; int lds; int cls; double work; int band = 4; bool force1 = false; };
+    struct P { int idx; int lds; int cls; double work; int band = 4; bool force1 = false, force2 = false; };
     static const bool no_band8 = getenv("SID_PM_NO_BAND8") != nullptr;                      // A/B runs
     const bool band8_ok = ctx->kernel == KERNEL_MFMA && sid::mfma_band8_supported(s) && !no_band8;
     std::vector<P> pts((size_t)n);
@@ -411,10 +411,15 @@ SID_EXPORT int sid_pm_set_points(sid_pm_ctx *ctx, const double *c1, const double
             p.lds = need;
             // the two-per-CU class runs the 8-row-band kernel (two wavefronts per SIMD leave it 256 VGPRs); its
             // window carries 4 more zero rows, and a point that then no longer fits twice stays with band 4
-            if (band8_ok && blocks_per_cu(need) == 2) {
+            static const bool band8_all = getenv("SID_PM_BAND8_ALL") != nullptr;                 // A/B: also the three-per-CU class
+            if (band8_ok && (blocks_per_cu(need) == 2 || (band8_all && blocks_per_cu(need) > 2))) {
                 const int need8 = lds_need(ctx->kernel, wh, ww, s, K, 8);
-                if (blocks_per_cu(need8) == 2) { p.lds = need8; p.band = 8; }
+                if (blocks_per_cu(need8) >= 2) { p.lds = need8; p.band = 8; p.force2 = true; }
                 else p.force1 = true;
+            }
+            static const bool band8_c1 = getenv("SID_PM_BAND8_C1") != nullptr;                     // A/B: the one-per-CU class, 512 threads
+            if (band8_ok && band8_c1 && blocks_per_cu(need) == 1 && lds_need(ctx->kernel, wh, ww, s, K, 8) <= sid::max_lds_bytes()) {
+                p.lds = lds_need(ctx->kernel, wh, ww, s, K, 8); p.band = 8;
             }
             const double rh = wh - s + 1, rw = ww - s + 1;
             p.work = rh * rw;
@@ -423,12 +428,13 @@ SID_EXPORT int sid_pm_set_points(sid_pm_ctx *ctx, const double *c1, const double
             bytes += (double)wh * ww + 51.0 * 51.0 + 40.0 + 52.0;
             valid += 1;
         }
-        p.cls = p.force1 ? 1 : std::min(8, blocks_per_cu(p.lds));
+        p.cls = p.force1 ? 1 : (p.force2 ? 2 : std::min(8, blocks_per_cu(p.lds)));
         lds_max = std::max(lds_max, p.lds);
         pts[(size_t)i] = p;
     }
     std::sort(pts.begin(), pts.end(), [](const P &a, const P &b) {
         if (a.cls != b.cls) return a.cls < b.cls;                 // biggest footprints first
+        if (a.band != b.band) return a.band < b.band;             // one launch per (class, band)
         if (a.work != b.work) return a.work > b.work;             // then longest first
         return a.idx < b.idx;
     });
@@ -436,7 +442,7 @@ SID_EXPORT int sid_pm_set_points(sid_pm_ctx *ctx, const double *c1, const double
     ctx->buckets.clear();
     for (int64_t i = 0; i < n; ++i) {
         order[(size_t)i] = pts[(size_t)i].idx;
-        if (ctx->buckets.empty() || pts[(size_t)i].cls != pts[(size_t)(i - 1)].cls)
+        if (ctx->buckets.empty() || pts[(size_t)i].cls != pts[(size_t)(i - 1)].cls || pts[(size_t)i].band != pts[(size_t)(i - 1)].band)
             ctx->buckets.push_back(Bucket{(int)i, 0, 0, pts[(size_t)i].band});
         Bucket &b = ctx->buckets.back();
         b.count += 1;
@@ -507,12 +513,12 @@ SID_EXPORT int sid_pm_run(sid_pm_ctx *ctx)
         // 256 threads per point; 768 when the LDS footprint leaves room for one point per CU only, so that
         // the CU still carries 12 wavefronts (3 per SIMD = the register budget).  (Measured: 384- and
         // 512-thread groups lose to 2 x 256 - they do not pack onto the SIMDs and serialise the phases.)
-        const int per_cu = b.band == 8 ? 2 : std::max(1, blocks_per_cu(b.lds));
+        const int per_cu = std::max(1, std::min(b.band == 8 ? 2 : 8, blocks_per_cu(b.lds)));
         static const int force_nt = getenv("SID_PM_THREADS") ? atoi(getenv("SID_PM_THREADS")) : 0;   // A/B experiments
         static const int nt2 = getenv("SID_PM_THREADS2") ? atoi(getenv("SID_PM_THREADS2")) : 256;   // A/B: two-per-CU class
         const int nthreads = force_nt ? force_nt : (per_cu == 1 ? 768 : (per_cu == 2 ? nt2 : 256));
         const int e = ctx->kernel == KERNEL_DOT4 ? sid::launch_pm(A, b.lds, ctx->stream)
-                                                 : sid::launch_pm_mfma(A, b.lds, b.band == 8 ? 256 : nthreads, b.band, ctx->stream);
+                                                 : sid::launch_pm_mfma(A, b.lds, b.band == 8 ? (per_cu == 1 ? 512 : 256) : nthreads, b.band, ctx->stream);
         if (e != 0) return fail(SID_PM_ERR_HIP, "kernel launch failed: %s", hipGetErrorString((hipError_t)e));
     }
     if (ctx->cur_slot >= 0) {

@@ -1289,7 +1289,7 @@ __device__ __noinline__ void ph_hessian(unsigned flags, int iy, int ix, float be
 // BAND = 4: up to 768 threads, three wavefronts per SIMD (168 VGPRs).  BAND = 8: 256 threads, two per SIMD (the
 // class whose LDS footprint admits two workgroups per CU anyway): an 8-row band halves the LDS bytes per MFMA.
 template <int S, int BAND>
-__global__ __launch_bounds__(BAND == 8 ? 256 : kMaxBlockM, BAND == 8 ? 2 : kOccM) void pm_kernel_mfma(const PMArgs A)
+__global__ __launch_bounds__(BAND == 8 ? 512 : kMaxBlockM, BAND == 8 ? 2 : kOccM) void pm_kernel_mfma(const PMArgs A)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     MiscM *m = reinterpret_cast<MiscM *>(smem);
@@ -1428,7 +1428,7 @@ int launch_pm_mfma(const PMArgs &args, int lds_bytes, int nthreads, int band, vo
     if (args.n_launch <= 0) return (int)hipSuccess;
     void (*kern)(const PMArgs) = pm_kernel_mfma<0, 4>;
     if (band == 8) {
-        if (!mfma_band8_supported(args.img_size) || nthreads != 256) return (int)hipErrorInvalidValue;
+        if (!mfma_band8_supported(args.img_size) || (nthreads != 256 && nthreads != 512)) return (int)hipErrorInvalidValue;
         kern = args.img_size == 34 ? pm_kernel_mfma<34, 8> : pm_kernel_mfma<35, 8>;
     } else if (band != 4) return (int)hipErrorInvalidValue;
     else if (args.img_size == 34) kern = pm_kernel_mfma<34, 4>;
