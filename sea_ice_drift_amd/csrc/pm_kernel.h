@@ -86,7 +86,9 @@ __host__ __device__ inline MfmaLdsLayout mfma_lds_layout(int wh, int ww, int s, 
     MfmaLdsLayout L;
     const int rh = wh - s + 1, rw = ww - s + 1;
     const int ntx = (rw + 15) / 16;
-    L.wpitch = 16 * ntx + 68;                       // a window fragment reads 5 dwords from (x0+15+48) & ~3
+    // a window fragment reads 5 dwords from (x0 + 15 + 16 g) & ~3; for s <= 48 the lanes of k-group g = 3 only
+    // multiply zero template columns and read along with k-group 0, so the last needed byte is x0 + 63
+    L.wpitch = 16 * ntx + (s <= 48 ? 52 : 68);
     if (L.wpitch < round_up(ww, 4)) L.wpitch = round_up(ww, 4);
     L.win_off = kMiscMfmaBytes;
     L.sii_off = round_up(L.win_off + (wh + band - 1) * L.wpitch, 16);

@@ -957,7 +957,9 @@ __device__ __forceinline__ Score ph_sweep(Score sc, int a0, int Kg, long long *d
     for (int item = wv; item < nbands * ntx; item += kWavesM) {
         const int band = item / ntx, xt = item - band * ntx;
         const int y0 = band * kBand, x0 = xt * 16;
-        const u32 sbyte = (u32)(x0 + n_l + 16 * q_l);
+        // k-group 3 multiplies the all-zero template columns (s <= 48): its lanes read the window bytes of
+        // k-group 0 (same addresses = LDS broadcast, and the window pitch needs no room for columns 48..63)
+        const u32 sbyte = (u32)(x0 + n_l + 16 * (zero_a ? 0 : q_l));
         const u32 sh = sbyte & 3u;
         if (item == wv) STAMP2(10);
         v4i acc[kBand];
@@ -1135,7 +1137,7 @@ __device__ __noinline__ void ph_winner(int ka, long long *dbg_cycles)
         const int y0 = yt * 16, x0 = xt * 16;
         const int rows_here = (rh - y0) < 16 ? (rh - y0) : 16;
         const int nsteps = rows_here + s - 1;
-        const u32 sbyte = (u32)(x0 + n_l + 16 * q_l);
+        const u32 sbyte = (u32)(x0 + n_l + 16 * ((s <= 48 && q_l == 3) ? 0 : q_l));   // k-group 3: zero template columns
         const u32 sh = sbyte & 3u;
         const uint8_t *bp = win + y0 * wpitch + (sbyte & ~3u);
         // lane (m = n_l, g = q_l): template row i = step - m  ->  trow[g][16 + step - m]
