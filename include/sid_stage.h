@@ -1,0 +1,46 @@
+/* sid_stage.h - C ABI of the uint8 staging step on MI355X (gfx950): SURVEY.md section 8, row f3.
+ *
+ * Replaces, in the reference (sea_ice_drift v0.7.1), lib.py:27-59 get_uint8_image():
+ *
+ *     vmin = np.nanpercentile(image, pmin)          (lib.py:46-48, when vmin is None)
+ *     vmax = np.nanpercentile(image, pmax)          (lib.py:49-51, when vmax is None)
+ *     uint8Image = 1 + 254 * (image - vmin) / (vmax - vmin)        (lib.py:54)
+ *     clip to [1, 255]; pixels whose input is not finite -> 0; astype('uint8')   (lib.py:55-59)
+ *
+ * The device does the two passes over the 10^8-pixel float32 image that cost seconds on the host:
+ *   sid_stage_order_stats  - exact order statistics of the non-NaN pixels (what nanpercentile interpolates
+ *                            between; the float32 interpolation itself is three scalar operations and stays
+ *                            with the caller, sea_ice_drift_amd/lib.py, in NumPy's own arithmetic);
+ *   sid_stage_scale_u8     - the element-wise map, float32 operation for operation as NumPy evaluates it.
+ * All pointers are device pointers unless stated; `hip_stream` is a hipStream_t (may be NULL).
+ * 0 on success, a negative SID_PM_ERR_* code otherwise (sid_pm.h); sid_stage_last_error() has the message.
+ */
+#ifndef SID_STAGE_H
+#define SID_STAGE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Number of non-NaN pixels of a float32 image [rows][cols] with row stride `stride` (in elements) -> *n_valid (host). */
+int sid_stage_count_valid(const float *d_img, int64_t rows, int64_t cols, int64_t stride, int64_t *n_valid,
+                          void *hip_stream);
+
+/* values[k] (host) = the ranks[k]-th smallest (0-based) non-NaN pixel, ranks ascending not required,
+ * 0 <= ranks[k] < n_valid; +-inf take part in the order like any value (as in np.sort). */
+int sid_stage_order_stats(const float *d_img, int64_t rows, int64_t cols, int64_t stride,
+                          const int64_t *ranks, int n_ranks, float *values, void *hip_stream);
+
+/* out[r][c] = uint8(clip(1 + (254 * (img[r][c] - vmin)) / denom, 1, 255)), 0 where img is not finite (or the
+ * result is NaN); every operation rounded to float32 (lib.py:54 with float32 operands). */
+int sid_stage_scale_u8(const float *d_img, int64_t rows, int64_t cols, int64_t stride, float vmin, float denom,
+                       uint8_t *d_out, int64_t out_stride, void *hip_stream);
+
+const char *sid_stage_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

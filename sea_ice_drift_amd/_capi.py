@@ -29,6 +29,9 @@ SYMBOLS = (
 # every symbol include/sid_ft.h declares (feature-tracking matcher, same library)
 FT_SYMBOLS = ('sid_ft_knn2', 'sid_ft_knn2_device', 'sid_ft_workspace_bytes', 'sid_ft_last_error')
 
+# every symbol include/sid_stage.h declares (uint8 staging, same library)
+STAGE_SYMBOLS = ('sid_stage_count_valid', 'sid_stage_order_stats', 'sid_stage_scale_u8', 'sid_stage_last_error')
+
 _u8p = C.POINTER(C.c_uint8)
 _f64p = C.POINTER(C.c_double)
 _f32p = C.POINTER(C.c_float)
@@ -86,6 +89,12 @@ def lib():
     L.sid_ft_workspace_bytes.argtypes = [C.c_int64, C.c_int64]
     L.sid_ft_workspace_bytes.restype = C.c_int64
     L.sid_ft_last_error.restype = C.c_char_p
+    L.sid_stage_count_valid.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.POINTER(C.c_int64), C.c_void_p]
+    L.sid_stage_order_stats.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.POINTER(C.c_int64), C.c_int,
+                                        _f32p, C.c_void_p]
+    L.sid_stage_scale_u8.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_float, C.c_float, C.c_void_p,
+                                     C.c_int64, C.c_void_p]
+    L.sid_stage_last_error.restype = C.c_char_p
     for name in SYMBOLS:
         getattr(L, name)                      # AttributeError here = header/library mismatch
     if L.sid_pm_abi_version() != ABI_VERSION:
@@ -291,3 +300,29 @@ def ft_knn2(desc1, desc2, device=0):
     if rc != 0:
         raise SidPmError(rc, L.sid_ft_last_error().decode())
     return idx, dist
+
+
+def _stage_check(rc):
+    if rc != 0:
+        raise SidPmError(rc, lib().sid_stage_last_error().decode())
+
+
+def stage_count_valid(ptr, rows, cols, stride, stream=0):
+    """Non-NaN pixels of a device float32 image (include/sid_stage.h)."""
+    n = C.c_int64(0)
+    _stage_check(lib().sid_stage_count_valid(C.c_void_p(int(ptr)), rows, cols, stride, C.byref(n), C.c_void_p(int(stream))))
+    return int(n.value)
+
+
+def stage_order_stats(ptr, rows, cols, stride, ranks, stream=0):
+    """Exact order statistics (0-based ranks among the non-NaN pixels) of a device float32 image."""
+    r = np.ascontiguousarray(ranks, dtype=np.int64)
+    out = np.empty(len(r), dtype=np.float32)
+    _stage_check(lib().sid_stage_order_stats(C.c_void_p(int(ptr)), rows, cols, stride, r.ctypes.data_as(C.POINTER(C.c_int64)),
+                                             len(r), out.ctypes.data_as(_f32p), C.c_void_p(int(stream))))
+    return out
+
+
+def stage_scale_u8(ptr, rows, cols, stride, vmin, denom, out_ptr, out_stride, stream=0):
+    _stage_check(lib().sid_stage_scale_u8(C.c_void_p(int(ptr)), rows, cols, stride, float(vmin), float(denom),
+                                          C.c_void_p(int(out_ptr)), out_stride, C.c_void_p(int(stream))))

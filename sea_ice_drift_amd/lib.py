@@ -1,9 +1,9 @@
 """Host-side helpers the PM path needs from the reference's lib.py.
 
-Only what ``pattern_matching`` touches: the two first-guess interpolators
-(reference lib.py:139-177 and :179-201), the grid scatter (lib.py:408-412) and a
-stand-in for ``nansat.NSR``.  Image staging from files (lib.py:27-59, 256-340) and the
-geo/Haversine helpers are outside the hot path.
+What ``pattern_matching`` touches: the two first-guess interpolators (reference lib.py:139-177 and
+:179-201), the grid scatter (lib.py:408-412) and a stand-in for ``nansat.NSR``; plus the uint8 staging step
+``get_uint8_image`` (lib.py:27-59), whose two full-image passes run on the GPU (include/sid_stage.h).
+Reading files (lib.py:256-340) and the geo/Haversine helpers are outside the hot path.
 """
 import numpy as np
 from scipy.interpolate import griddata
@@ -54,3 +54,72 @@ def _fill_gpi(shape, gpi, data):
     y = np.zeros(shape).flatten() + np.nan
     y[gpi] = data
     return y.reshape(shape)
+
+
+def _percentile_ranks(n, p, ftype):
+    """Neighbour ranks and weight of np.nanpercentile's 'linear' interpolation for a float32 image:
+    q = p / float32(100), virtual index (n - 1) * q in float32 (numpy/lib/_function_base_impl.py)."""
+    q = np.true_divide(p, ftype(100))
+    vi = (n - 1) * q
+    prev = np.floor(vi)
+    lo = min(max(int(prev), 0), n - 1)
+    return lo, min(lo + 1, n - 1), vi - prev
+
+
+def _lerp(a, b, t):
+    with np.errstate(all='ignore'):
+        d = np.subtract(b, a)
+        r = np.add(a, d * t)
+        if t >= 0.5:
+            r = np.subtract(b, d * (1 - t))
+    return r
+
+
+def get_uint8_image(image, vmin, vmax, pmin, pmax, device=0):
+    """Scale a float32 image to uint8 on the GPU: signature and results of the reference's
+    ``get_uint8_image`` (lib.py:27-59): ``1 + 254 * (image - vmin) / (vmax - vmin)`` clipped to [1, 255],
+    0 for pixels that are not finite; ``vmin`` / ``vmax`` default to ``np.nanpercentile(image, pmin / pmax)``.
+
+    ``image``: 2-D float32 NumPy array (uploaded) or a CUDA/HIP torch tensor (used in place); the result is of
+    the same kind.  The device selects the order statistics and maps the pixels (include/sid_stage.h); the
+    three-operation float32 interpolation between the two neighbouring order statistics is NumPy's own
+    arithmetic, so the percentiles - and the image - equal the reference's bit for bit.  No CPU fallback."""
+    import torch
+    from . import _capi
+    is_tensor = isinstance(image, torch.Tensor)
+    if is_tensor:
+        t = image
+        if not t.is_cuda:
+            raise ValueError('a torch input must live on the GPU (pass NumPy arrays for host data)')
+    else:
+        a = np.asarray(image)
+        if a.dtype != np.float32:
+            raise NotImplementedError('get_uint8_image on the device takes float32 images (got %s)' % a.dtype)
+        t = torch.from_numpy(np.ascontiguousarray(a)).to(torch.device('cuda', device))
+    if t.dtype != torch.float32 or t.dim() != 2 or t.stride(1) != 1:
+        raise NotImplementedError('2-D float32 image with unit inner stride expected')
+    rows, cols, stride = int(t.shape[0]), int(t.shape[1]), int(t.stride(0))
+    stream = torch.cuda.current_stream(t.device).cuda_stream
+    ftype = np.float32
+    if vmin is None or vmax is None:
+        n = _capi.stage_count_valid(t.data_ptr(), rows, cols, stride, stream)
+        want = [p for p, v in ((pmin, vmin), (pmax, vmax)) if v is None]
+        if n == 0:
+            vals = {p: ftype(np.nan) for p in want}
+        else:
+            rk = {p: _percentile_ranks(n, p, ftype) for p in want}
+            ranks = sorted({r for p in want for r in rk[p][:2]})
+            stat = dict(zip(ranks, _capi.stage_order_stats(t.data_ptr(), rows, cols, stride, ranks, stream)))
+            vals = {p: _lerp(stat[rk[p][0]], stat[rk[p][1]], rk[p][2]) for p in want}
+        if vmin is None:
+            vmin = vals[pmin]
+            print('VMIN: ', vmin)
+        if vmax is None:
+            vmax = vals[pmax]
+            print('VMAX: ', vmax)
+    with np.errstate(all='ignore'):
+        denom = ftype(vmax - vmin)                    # NumPy scalar rules: float32 when either is a percentile
+        vmin32 = ftype(vmin)
+    out = torch.empty((rows, cols), dtype=torch.uint8, device=t.device)
+    _capi.stage_scale_u8(t.data_ptr(), rows, cols, stride, vmin32, denom, out.data_ptr(), int(out.stride(0)), stream)
+    return out if is_tensor else out.cpu().numpy()

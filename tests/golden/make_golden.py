@@ -14,6 +14,8 @@ them, with a sha256) and the outputs the reference's functions returned:
                      affine stand-in for Nansat, incl. the kernel-input vectors it built
   g5_fullsize.npz    sha256 of the 10000x10000 benchmark pair + C-oracle results on a 1 %
                      subsample of the 200x200 grid (regression pin, not reference output)
+  g6_uint8_image.npz lib.get_uint8_image             (lib.py:27-59) on seeded float32 images with NaN / inf
+                     pixels, percentile-driven and explicit vmin / vmax
 
     python tests/golden/make_golden.py [g1 g2 g3 g4 g5]
 """
@@ -181,9 +183,49 @@ def make_g5():
                         sel=sel, out=out, ij=ij)
 
 
+def g6_cases():
+    """Inputs of the staging fixture: float32 'sigma0 in dB'-like images with NaN / inf pixels."""
+    rng = np.random.default_rng(606)
+    cases = []
+    for k, shape in enumerate([(64, 80), (301, 257), (1, 37), (500, 500)]):
+        img = rng.normal(-22.0, 4.0, shape).astype(np.float32)
+        img[rng.random(shape) < 0.07] = np.nan
+        if k == 1:
+            img[5, 7] = np.inf; img[9, 11] = -np.inf
+        if k == 3:
+            img[100:140, 200:260] = np.nan                  # a masked block (land)
+            img[::17, ::13] = np.float32(-22.0)              # many exact ties
+        cases.append(img)
+    return cases
+
+
+G6_PARAMS = [(None, None, 10, 99), (None, None, 1, 99.9), (-30.0, -12.5, 10, 99), (None, -10.0, 5, 99), (-35.0, None, 10, 95)]
+
+
+def make_g6(reflib):
+    """lib.get_uint8_image (lib.py:27-59) run as the reference wrote it (numpy %s)."""
+    import contextlib, io
+    d = {'numpy_version': np.__version__}
+    for ci, img in enumerate(g6_cases()):
+        for pi, (vmin, vmax, pmin, pmax) in enumerate(G6_PARAMS):
+            if ci == 1 and (vmin is None or vmax is None) and pi == 1:
+                pass
+            with contextlib.redirect_stdout(io.StringIO()), np.errstate(all='ignore'):
+                out = reflib.get_uint8_image(img.copy(), vmin, vmax, pmin, pmax)
+            d['out_%d_%d' % (ci, pi)] = out
+            with np.errstate(all='ignore'):
+                d['vmin_%d_%d' % (ci, pi)] = np.float64(np.nanpercentile(img, pmin) if vmin is None else vmin)
+                d['vmax_%d_%d' % (ci, pi)] = np.float64(np.nanpercentile(img, pmax) if vmax is None else vmax)
+    np.savez_compressed(os.path.join(HERE, 'g6_uint8_image.npz'), **d)
+
+
 def main():
-    which = sys.argv[1:] or ['g1', 'g2', 'g3', 'g4', 'g5']
-    pmlib, _ = ref_harness.load()
+    which = sys.argv[1:] or ['g1', 'g2', 'g3', 'g4', 'g5', 'g6']
+    pmlib, reflib = ref_harness.load()
+    if 'g6' in which:
+        t = time.time()
+        make_g6(reflib)
+        print('g6 done in %.1f s' % (time.time() - t))
     c_oracle.build()
     for name, fn in (('g1', make_g1), ('g2', make_g2), ('g3', make_g3), ('g4', make_g4)):
         if name in which:
