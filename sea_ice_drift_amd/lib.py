@@ -46,6 +46,14 @@ def interpolation_near(x1, y1, x2, y2, x1grd, y1grd, method='linear', **kwargs):
     convex hull (reference lib.py:179-201; note the (row, col) point order)."""
     src = np.array([y1, x1]).T
     dst = np.array([y1grd, x1grd]).T
+    if method == 'linear' and src.shape[1] == 2:
+        # The reference calls griddata twice, i.e. triangulates the same keypoints twice - the slowest
+        # step of the whole prelude.  One Delaunay triangulation serves both components; every component
+        # is the same barycentric sum, so the values are bit-identical to the two separate calls.
+        from scipy.interpolate import LinearNDInterpolator
+        from scipy.spatial import Delaunay
+        both = LinearNDInterpolator(Delaunay(src), np.array([x2, y2], dtype=np.float64).T)(dst)
+        return both[..., 0].T, both[..., 1].T
     return griddata(src, x2, dst, method=method).T, griddata(src, y2, dst, method=method).T
 
 
