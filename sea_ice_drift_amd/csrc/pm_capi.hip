@@ -438,6 +438,32 @@ SID_EXPORT int sid_pm_set_points(sid_pm_ctx *ctx, const double *c1, const double
         if (a.work != b.work) return a.work > b.work;             // then longest first
         return a.idx < b.idx;
     });
+    // XCD-aware launch order.  Workgroup j of a launch runs on XCD j mod 8 and every XCD has its own L2, so
+    // within a run of points of equal class and work (= equal border: the order there is the caller's, i.e.
+    // spatial for a grid) the run is cut into 8 contiguous chunks and chunk c goes to the XCD of slot
+    // (start + c) mod 8: neighbouring points - whose search windows overlap - meet in the same L2.
+    // Runs keep their place in the launch (long first), so the load balance across XCDs is unchanged.
+    static const bool no_xcd = getenv("SID_PM_NO_XCD_ORDER") != nullptr;                         // A/B runs
+    if (!no_xcd) {
+        constexpr int kXcd = 8;
+        std::vector<P> tmp;
+        for (int64_t a = 0; a < n;) {
+            int64_t b = a + 1;
+            while (b < n && pts[(size_t)b].cls == pts[(size_t)a].cls && pts[(size_t)b].band == pts[(size_t)a].band &&
+                   pts[(size_t)b].work == pts[(size_t)a].work) ++b;
+            const int64_t L = b - a, m = (L + kXcd - 1) / kXcd;
+            if (L >= 4 * kXcd) {
+                tmp.assign(pts.begin() + a, pts.begin() + b);
+                int64_t w = a;
+                for (int64_t p = 0; p < m; ++p)                       // slot t = p * 8 + c takes element c * m + p
+                    for (int c = 0; c < kXcd; ++c) {
+                        const int64_t e = (int64_t)c * m + p;
+                        if (e < L) pts[(size_t)w++] = tmp[(size_t)e];
+                    }
+            }
+            a = b;
+        }
+    }
     std::vector<int32_t> order((size_t)n);
     ctx->buckets.clear();
     for (int64_t i = 0; i < n; ++i) {
