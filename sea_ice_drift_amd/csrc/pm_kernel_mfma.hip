@@ -158,7 +158,7 @@ __device__ __forceinline__ float key2f(u32 k) { u32 b = (k & 0x80000000u) ? (k &
 // k-th smallest (0-based) of v[0..n) by 4 x 8-bit radix select.  The four histograms are zeroed
 // up front (hist4: 4 x 256 counters, 16-byte aligned scratch); per pass: all threads bin their elements (LDS atomics), barrier, wavefront 0 scans the
 // 256 bins (4 per lane + a wavefront prefix sum) and publishes the digit, barrier.
-__device__ u32 block_select(const float *v, int n, u32 k, MiscM *m, u32 *hist4, u32 *count_le) {
+__device__ __forceinline__ u32 block_select(const float *v, int n, u32 k, MiscM *m, u32 *hist4, u32 *count_le) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     __syncthreads();
     for (int i = threadIdx.x; i < 1024; i += kBlockM) hist4[i] = 0;
@@ -198,7 +198,7 @@ __device__ u32 block_select(const float *v, int n, u32 k, MiscM *m, u32 *hist4, 
 }
 
 // np.median of a float32 LDS array (mean of the two middle values for even n, float32).
-__device__ float block_median(const float *v, int n, MiscM *m, u32 *hist4) {
+__device__ __forceinline__ float block_median(const float *v, int n, MiscM *m, u32 *hist4) {
     u32 cle;
     if (n & 1) return key2f(block_select(v, n, (u32)(n / 2), m, hist4, &cle));
     const u32 k1 = (u32)(n / 2 - 1);
@@ -218,7 +218,7 @@ __device__ float block_median(const float *v, int n, MiscM *m, u32 *hist4) {
 // radix select when the bucket holds more than kMedList elements (massive ties).
 // hist: 1024 counters, list: kMedList keys (LDS scratch); tmin / tmax: this thread's min / max key of v.
 constexpr int kMedList = 256;
-__device__ float block_median_fast(const float *v, int n, MiscM *m, u32 *hist, u32 *list, u32 tmin, u32 tmax)
+__device__ __forceinline__ float block_median_fast(const float *v, int n, MiscM *m, u32 *hist, u32 *list, u32 tmin, u32 tmax)
 {
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
     u32 *red_max = reinterpret_cast<u32 *>(m->red_f);
