@@ -200,7 +200,8 @@ def main():
                 # the sweep runs on v_mfma_i32_16x16x64_i8: the matrix cores are the roofline that bounds it
                 'bound': 'mfma', 'achieved': mfma_achieved, 'peak': MFMA_I8_PEAK_TOPS, 'unit': 'TFLOP/s',
                 'frac': mfma_achieved / MFMA_I8_PEAK_TOPS, 'traffic': traffic, 'traffic_note': traffic_note,
-                'kernel': 'sid::pm_kernel_mfma<%d>' % (s if s in (34, 35) else 0), 'launches_per_step': launches,
+                # one template, two band heights: <S,4> for the one- and three-per-CU classes, <S,8> for two per CU
+                'kernel': 'sid::pm_kernel_mfma<%d,4> + <%d,8>' % ((s, s) if s in (34, 35) else (0, 0)), 'launches_per_step': launches,
                 'kernel_ms_per_step': kern_ms, 'avg_launch_ms': kern_ms / launches,
                 'algorithmic_macs_per_step': info['macs'], 'algorithmic_bytes_per_step': info['hbm_bytes'],
                 'note': 'achieved = 2 x algorithmic MACs (sum K*Rh*Rw*s*s, integer ops) / kernel time measured with HIP '
