@@ -66,3 +66,10 @@ def load():
     pmlib = importlib.import_module('sea_ice_drift.pmlib')
     lib = importlib.import_module('sea_ice_drift.lib')
     return pmlib, lib
+
+
+def load_ftlib():
+    """The reference's ftlib module (ORB itself needs the real cv2: inject key points, see make_golden g7)."""
+    load()
+    import importlib
+    return importlib.import_module('sea_ice_drift.ftlib')

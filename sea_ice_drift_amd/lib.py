@@ -21,6 +21,55 @@ except Exception:                         # noqa: BLE001
             return 'NSR(%r)' % (self.srs,)
 
 
+AVG_EARTH_RADIUS = 6371  # in km (reference lib.py:25)
+
+
+def get_displacement_km(n1, x1, y1, n2, x2, y2):
+    """Haversine displacement in km between pixels of two images (reference lib.py:61-85)."""
+    lon1, lat1 = n1.transform_points(x1, y1)
+    lon2, lat2 = n2.transform_points(x2, y2)
+    lt1, ln1, lt2, ln2 = map(np.radians, (lat1, lon1, lat2, lon2))
+    dlat = lt2 - lt1
+    dlon = ln2 - ln1
+    d = (np.sin(dlat * 0.5) ** 2 +
+         np.cos(lt1) * np.cos(lt2) * np.sin(dlon * 0.5) ** 2)
+    return 2 * AVG_EARTH_RADIUS * np.arcsin(np.sqrt(d))
+
+
+def get_speed_ms(n1, x1, y1, n2, x2, y2):
+    """Drift speed in m/s from the images' time stamps (reference lib.py:87-102)."""
+    dt = (n2.time_coverage_start - n1.time_coverage_start).total_seconds()
+    return 1000. * get_displacement_km(n1, x1, y1, n2, x2, y2) / abs(dt)
+
+
+def get_displacement_pix(n1, x1, y1, n2, x2, y2):
+    """Displacement in pixels of the first image (reference lib.py:104-121)."""
+    lon2, lat2 = n2.transform_points(x2, y2)
+    x2n1, y2n1 = n1.transform_points(lon2, lat2, 1)
+    return x2n1 - x1, y2n1 - y1
+
+
+def get_drift_vectors(n1, x1, y1, n2, x2, y2, nsr=None, **kwargs):
+    """u, v, lon1, lat1, lon2, lat2 of matched points (reference lib.py:375-406).  The reference projects
+    through ``nansat.Domain(nsr, '-te -10 -10 10 10 -tr 1 1')``; for the default ``nsr`` (lon/lat WGS84)
+    that domain maps (lon, lat) to (lon + 10, 10 - lat), so u = lon2 - lon1 and v = lat2 - lat1 in degrees.
+    Any other projection needs the real nansat and is delegated to it."""
+    lon1, lat1 = n1.transform_points(x1, y1)
+    lon2, lat2 = n2.transform_points(x2, y2)
+    if nsr is not None and getattr(nsr, 'srs', None) not in (None, ''):
+        try:
+            from nansat import Domain            # pragma: no cover - not installed in this image
+        except Exception:                        # noqa: BLE001
+            raise NotImplementedError('a projected nsr needs nansat; only the default lon/lat is built in')
+        d = Domain(nsr, '-te -10 -10 10 10 -tr 1 1')                      # pragma: no cover
+        x1, y1 = d.transform_points(lon1, lat1, 1)                         # pragma: no cover
+        x2, y2 = d.transform_points(lon2, lat2, 1)                         # pragma: no cover
+        return x2 - x1, y1 - y2, lon1, lat1, lon2, lat2                    # pragma: no cover
+    px1, py1 = lon1 - (-10.0), 10.0 - lat1                                  # Domain('-te -10 -10 10 10 -tr 1 1')
+    px2, py2 = lon2 - (-10.0), 10.0 - lat2
+    return px2 - px1, py1 - py2, lon1, lat1, lon2, lat2
+
+
 def _design_matrix(x, y, order):
     cols = [np.ones(len(x)), x, y]
     if order > 1:

@@ -1,12 +1,13 @@
 """``SeaIceDrift`` with the reference's public methods (reference seaicedrift.py:23-88).
 
-Only ``get_drift_PM`` is backed by this package (it is the hot path).  The constructor
-takes two Nansat-like objects (``sea_ice_drift_amd.domain.ArrayNansat`` or real
-``nansat.Nansat``); opening Sentinel-1 files (reference lib.get_n, lib.py:256-340) needs
-nansat/GDAL and is outside the scope of this package, as is feature tracking
-(``get_drift_FT``: OpenCV ORB + BFMatcher, reference ftlib.py) - both raise with a pointer
-to what to pass instead.
+``get_drift_PM`` is the hot path; ``get_drift_FT`` runs the matcher on the GPU and the reference's
+filters on the host, with ORB detection left to OpenCV (or a ``find_key_points=`` callable).  The
+constructor takes two Nansat-like objects (``sea_ice_drift_amd.domain.ArrayNansat`` or real
+``nansat.Nansat``); opening Sentinel-1 files (reference lib.get_n, lib.py:256-340) needs nansat/GDAL and
+is outside the scope of this package - passing file names raises with a pointer to what to pass instead.
 """
+from sea_ice_drift_amd.ftlib import feature_tracking
+from sea_ice_drift_amd.lib import get_drift_vectors
 from sea_ice_drift_amd.pmlib import pattern_matching
 
 
@@ -24,9 +25,12 @@ class SeaIceDrift(object):
         self.n2 = n2
 
     def get_drift_FT(self, **kwargs):
-        raise NotImplementedError(
-            'feature tracking (ORB + BFMatcher, reference ftlib.py) is not part of the PM hot path; '
-            'run sea_ice_drift.ftlib.feature_tracking (OpenCV) and pass its keypoints to get_drift_PM')
+        """Same returns as the reference (seaicedrift.py:42-60): u, v, lon1, lat1, lon2, lat2 of the matched
+        key points.  Matching and filtering run here (GPU matcher); ORB detection needs OpenCV or a
+        ``find_key_points=`` callable (see ``sea_ice_drift_amd.ftlib.feature_tracking``)."""
+        x1, y1, x2, y2 = feature_tracking(self.n1, self.n2, **kwargs)
+        kwargs.pop('find_key_points', None)
+        return get_drift_vectors(self.n1, x1, y1, self.n2, x2, y2, **kwargs)
 
     def get_drift_PM(self, lons, lats, lon1, lat1, lon2, lat2, **kwargs):
         """Same arguments and returns as the reference (seaicedrift.py:62-88):

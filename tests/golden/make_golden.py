@@ -16,6 +16,8 @@ them, with a sha256) and the outputs the reference's functions returned:
                      subsample of the 200x200 grid (regression pin, not reference output)
   g6_uint8_image.npz lib.get_uint8_image             (lib.py:27-59) on seeded float32 images with NaN / inf
                      pixels, percentile-driven and explicit vmin / vmax
+  g7_feature_tracking.npz  ftlib.feature_tracking    (ftlib.py:241-285: domain, Lowe, drift and least-squares
+                     filters) on synthetic key points / descriptors, brute-force matcher injected
 
     python tests/golden/make_golden.py [g1 g2 g3 g4 g5]
 """
@@ -219,8 +221,102 @@ def make_g6(reflib):
     np.savez_compressed(os.path.join(HERE, 'g6_uint8_image.npz'), **d)
 
 
+class G7KeyPoint(object):
+    """What the reference reads of a cv2.KeyPoint."""
+    def __init__(self, x, y):
+        self.pt = (float(x), float(y))
+
+
+class G7Match(object):
+    def __init__(self, q, t, d):
+        self.queryIdx, self.trainIdx, self.distance = int(q), int(t), float(d)
+
+
+class G7BruteForce(object):
+    """Stands in for cv2.BFMatcher(cv2.NORM_HAMMING) through the reference's own ``matcher=`` argument
+    (ftlib.py:66,95): brute-force Hamming k-nearest neighbours, equal distances by the smaller index."""
+    def __init__(self, norm):
+        self.norm = norm
+
+    def knnMatch(self, d1, d2, k=2):
+        from oracle import ft_oracle
+        idx, dist = ft_oracle.knn2(d1, d2)
+        return [tuple(G7Match(q, idx[q, j], dist[q, j]) for j in range(k)) for q in range(len(d1))]
+
+
+class G7Nansat(ArrayNansat):
+    """ArrayNansat with nansat's behaviour for the time stamp: ValueError when the data has none."""
+    def __init__(self, image, start=None, **kw):
+        ArrayNansat.__init__(self, image, **kw)
+        self._start = start
+
+    @property
+    def time_coverage_start(self):
+        if self._start is None:
+            raise ValueError('no time_coverage_start')
+        return self._start
+
+
+def g7_inputs(timed):
+    """Two 3000x3000 'images' (only their shape and georeference matter), 6000 / 5500 synthetic key points
+    with 256-bit descriptors: 3500 true correspondences (few flipped bits, ~1 % gross outliers), the rest noise."""
+    import datetime
+    rng = np.random.default_rng(707)
+    shape = (3000, 3000)
+    img = np.ones(shape, dtype=np.uint8)
+    t0 = datetime.datetime(2020, 1, 1)
+    scale = 4e-4                                           # degrees per pixel (~44 m)
+    n1 = G7Nansat(img, start=t0 if timed else None, origin=(10.0, 78.0), matrix=((scale, 0.0), (0.0, -scale)))
+    n2 = G7Nansat(img, start=t0 + datetime.timedelta(hours=24) if timed else None,
+                  origin=(10.0 + 150 * scale, 78.0 - 90 * scale), matrix=((scale, 0.0), (0.0, -scale)))
+    ncommon, na, nb = 3500, 2500, 2000
+    xy1 = rng.uniform(40, 2960, (ncommon + na, 2))
+    d1 = rng.integers(0, 256, (ncommon + na, 32), dtype=np.uint8)
+    # image 2 sees the common points shifted by the georeference offset plus a smooth drift, with noisy descriptors
+    drift = np.stack([8 + 6 * np.sin(xy1[:ncommon, 1] / 700.0), -5 + 4 * np.cos(xy1[:ncommon, 0] / 900.0)], axis=1)
+    xy2c = xy1[:ncommon] - np.array([150.0, 90.0]) + drift + rng.normal(0, 0.4, (ncommon, 2))
+    flips = np.zeros((ncommon, 256), dtype=np.uint8)
+    for r in range(ncommon):
+        flips[r, rng.permutation(256)[:rng.integers(0, 45)]] = 1
+    d2c = d1[:ncommon] ^ np.packbits(flips, axis=1)
+    bad = rng.permutation(ncommon)[:35]                    # gross outliers: right descriptor, wrong place
+    xy2c[bad] += rng.uniform(-900, 900, (len(bad), 2))
+    xy2 = np.concatenate([xy2c, rng.uniform(40, 2960, (nb, 2))])
+    d2 = np.concatenate([d2c, rng.integers(0, 256, (nb, 32), dtype=np.uint8)])
+    p2 = rng.permutation(len(xy2))
+    return n1, n2, xy1, d1, xy2[p2], d2[p2]
+
+
+def make_g7():
+    """ftlib.feature_tracking (ftlib.py:241-285) as the reference wrote it, fed with synthetic key points
+    (its find_key_points is OpenCV's ORB) and a brute-force matcher through its own ``matcher=`` argument."""
+    ftlib = ref_harness.load_ftlib()
+    d = {}
+    for timed in (False, True):
+        n1, n2, xy1, d1, xy2, d2 = g7_inputs(timed)
+        table = {id(n1[1]): (xy1, d1), id(n2[1]): (xy2, d2)}
+        calls = []
+
+        def fake_find_key_points(image, **kwargs):
+            xy, desc = (xy1, d1) if not calls else (xy2, d2)
+            calls.append(1)
+            return [G7KeyPoint(x, y) for x, y in xy], desc
+        ftlib.find_key_points = fake_find_key_points
+        kw = dict(matcher=G7BruteForce, max_drift=25000.0) if not timed else dict(matcher=G7BruteForce, max_speed=0.3)
+        x1, y1, x2, y2 = ftlib.feature_tracking(n1, n2, domainMargin=10, ratio_test=0.75, psi=150, **kw)
+        tag = 'timed' if timed else 'untimed'
+        for name, v in (('x1', x1), ('y1', y1), ('x2', x2), ('y2', y2)):
+            d['%s_%s' % (name, tag)] = np.asarray(v, dtype=np.float64)
+        assert len(x1) > 2000, len(x1)
+    np.savez_compressed(os.path.join(HERE, 'g7_feature_tracking.npz'), **d)
+
+
 def main():
-    which = sys.argv[1:] or ['g1', 'g2', 'g3', 'g4', 'g5', 'g6']
+    which = sys.argv[1:] or ['g1', 'g2', 'g3', 'g4', 'g5', 'g6', 'g7']
+    if 'g7' in which:
+        t = time.time()
+        make_g7()
+        print('g7 done in %.1f s' % (time.time() - t))
     pmlib, reflib = ref_harness.load()
     if 'g6' in which:
         t = time.time()
