@@ -12,8 +12,11 @@
 //       N = 16 adjacent placements x0..x0+15 of one output row y
 //       K = 64 window columns c of window row rho = y + i ; A[slot][c] = T'_slot[i][c] (0 for c >= s)
 //     B[c][x] = W'[rho][x0 + x + c] is the same for every (y, i) with y + i = rho, so a wavefront
-//     keeps a band of 8 output rows in accumulators and a ring of 8 template-row fragments in
-//     registers: one window fragment built from LDS (5 ds_read_b32 + 4 v_alignbyte_b32) feeds 8 MFMAs.
+//     keeps a band of BAND output rows in accumulators and a ring of BAND template-row fragments in
+//     registers: one window fragment built from LDS (5 ds_read_b32 + 4 v_alignbyte_b32) feeds BAND
+//     MFMAs.  BAND = 4 with three wavefronts per SIMD (168 VGPRs), BAND = 8 in the instantiation for the
+//     LDS class that fits two workgroups per CU (256 VGPRs): the sweep is LDS-bandwidth-bound, and the
+//     taller band halves the LDS bytes per MFMA.
 //
 //   winner ("row-major"):   the NCC matrix of the best angle is recomputed with M = 16 output rows
 //     (A[m][c] = T'_best[rho - y0 - m][c]) and a second all-ones operand for S_I'.
@@ -22,7 +25,14 @@
 //   The double-precision normalisation of the spec is evaluated only for arg-max candidates picked
 //   by a float32 pre-filter (|r~ - r| <= 4e-7 << margin 1e-5) and for the winner's matrix.
 //
-// One workgroup per grid point; 256 or 768 threads by LDS-footprint class (see kMaxBlockM).
+//   templates: for an integral template centre (what the reference's driver always passes) the rotated
+//   nearest-neighbour sample positions depend only on the angle; the host precomputes them once per
+//   set_points as LDS patch offsets (pm_capi.hip make_samp) and the kernel gathers through that table;
+//   any other centre, and templates at the image border, are sampled on the fly.
+//
+// One workgroup per grid point; 256 or 768 threads by LDS-footprint class (see kMaxBlockM).  The phases
+// other than the sweep are separate non-inlined functions sharing a geometry block in LDS, so each has its
+// own register allocation; throughput is set by the latency of a workgroup's phase chain.
 // Compile with -ffp-contract=off.
 #include <hip/hip_runtime.h>
 #include <math.h>
