@@ -205,9 +205,17 @@ bool size_supported(int kernel, int s)
     return kernel == KERNEL_DOT4 ? sid::img_size_supported(s) : sid::mfma_img_size_supported(s);
 }
 
+// paired: the MFMA kernel's two-row-phase sweep for angle sets of at most kPairedMaxAngles (pm_kernel.h)
+bool use_paired(int kernel, int K)
+{
+    static const bool off = getenv("SID_PM_NO_PAIRED") != nullptr;                            // A/B runs
+    return kernel == KERNEL_MFMA && K <= sid::kPairedMaxAngles && !off;
+}
+
 int lds_need(int kernel, int wh, int ww, int s, int K, int band = 4)
 {
-    return kernel == KERNEL_DOT4 ? sid::lds_layout(wh, ww, s, K).total : sid::mfma_lds_layout(wh, ww, s, band).total;
+    return kernel == KERNEL_DOT4 ? sid::lds_layout(wh, ww, s, K).total
+                                 : sid::mfma_lds_layout(wh, ww, s, band, use_paired(kernel, K) && band == 4).total;
 }
 
 int check_sweep(int kernel, int img_size, const double *angles, int n_angles, uint32_t flags)
@@ -395,7 +403,7 @@ SID_EXPORT int sid_pm_set_points(sid_pm_ctx *ctx, const double *c1, const double
     // classify: LDS footprint -> residency class (blocks per CU), work for ordering
     struct P { int idx; int lds; int cls; double work; int band = 4; bool force1 = false, force2 = false; };
     static const bool no_band8 = getenv("SID_PM_NO_BAND8") != nullptr;                      // A/B runs
-    const bool band8_ok = ctx->kernel == KERNEL_MFMA && sid::mfma_band8_supported(s) && !no_band8;
+    const bool band8_ok = ctx->kernel == KERNEL_MFMA && sid::mfma_band8_supported(s) && !no_band8 && !use_paired(ctx->kernel, K);
     std::vector<P> pts((size_t)n);
     const int lds_min = lds_need(ctx->kernel, s + 1, s + 1, s, K);
     double macs = 0, bytes = 0, valid = 0;
@@ -544,7 +552,8 @@ SID_EXPORT int sid_pm_run(sid_pm_ctx *ctx)
         static const int nt2 = getenv("SID_PM_THREADS2") ? atoi(getenv("SID_PM_THREADS2")) : 256;   // A/B: two-per-CU class
         const int nthreads = force_nt ? force_nt : (per_cu == 1 ? 768 : (per_cu == 2 ? nt2 : 256));
         const int e = ctx->kernel == KERNEL_DOT4 ? sid::launch_pm(A, b.lds, ctx->stream)
-                                                 : sid::launch_pm_mfma(A, b.lds, b.band == 8 ? (per_cu == 1 ? 512 : 256) : nthreads, b.band, ctx->stream);
+                                                 : sid::launch_pm_mfma(A, b.lds, b.band == 8 ? (per_cu == 1 ? 512 : 256) : nthreads, b.band,
+                                                                       use_paired(ctx->kernel, ctx->n_angles), ctx->stream);
         if (e != 0) return fail(SID_PM_ERR_HIP, "kernel launch failed: %s", hipGetErrorString((hipError_t)e));
     }
     if (ctx->cur_slot >= 0) {
@@ -681,7 +690,7 @@ SID_EXPORT int sid_pm_debug_point(sid_pm_ctx *ctx, double c1, double r1, double 
         A.dbg_cycles = dcyc.p;
         A.samp = sampv.empty() ? nullptr : dsamp.p; A.samp_nflag = nflag;
         step((hipError_t)(ctx->kernel == KERNEL_DOT4 ? sid::launch_pm(A, lds, ctx->stream)
-                                                     : sid::launch_pm_mfma(A, lds, getenv("SID_PM_THREADS") ? atoi(getenv("SID_PM_THREADS")) : 256, 4, ctx->stream)));
+                                                     : sid::launch_pm_mfma(A, lds, getenv("SID_PM_THREADS") ? atoi(getenv("SID_PM_THREADS")) : 256, 4, use_paired(ctx->kernel, K), ctx->stream)));
         step(hipStreamSynchronize(ctx->stream));
         if (templates) step(hipMemcpy(templates, dt.p, tcount, hipMemcpyDeviceToHost));
         if (ccm && cap > 0) step(hipMemcpy(ccm, dccm.p, sizeof(float) * cap, hipMemcpyDeviceToHost));

@@ -72,16 +72,22 @@ struct MfmaLdsLayout {
     int win_off;       // window
     int sii_off;       // sum w'^2 per placement (u32); later the Hessian (f32)
     int u_off;         // union: column sums | sweep operands + patch + queue | winner operands + NCC matrix
-    int arow;          // bytes per template row in the sweep operand table (48 or 64 lanes x 16 B)
+    int arow;          // bytes per template row in the sweep operand table (48 or 64 lanes x 16 B; half in paired mode)
+    int gpitch;        // bytes between the k-groups of a table row: 16 slots x 16 B, or 8 x 16 B in paired mode
+    int arow0;         // byte offset of template row 0 in the table (paired mode: 4 zero rows precede it)
+    int tab_rows;      // rows of the table incl. its zero rows; 16 scratch bytes follow at tab_rows * arow
     int patch_off, ppitch, pdim, pradius;   // image-1 patch the templates are sampled from
     int queue_off;
     int trow_bytes;    // one winner operand block: 4 k-groups x (s+kTrowPad) rows x 16 B
     int total;
 };
 
-// band = output rows per sweep work item (4, or 8 in the two-workgroups-per-CU kernel): band-1 zero rows follow
-// the window so that the sweep steps past it without clamping
-__host__ __device__ inline MfmaLdsLayout mfma_lds_layout(int wh, int ww, int s, int band = 4)
+// band = accumulator rows per sweep work item (4, or 8 in the two-workgroups-per-CU kernel).
+// paired (at most 7 angles): the 16 MFMA slots carry the <= 7 angles + the all-ones template twice, slots 8..15
+// working four output rows below slots 0..7, so an item covers 2 * band rows; the table stores 8 slots per
+// k-group and the lanes of slots 8..15 read it four rows earlier (zero rows at both ends).
+// Zero rows follow the window so that the sweep steps past it without clamping.
+__host__ __device__ inline MfmaLdsLayout mfma_lds_layout(int wh, int ww, int s, int band = 4, bool paired = false)
 {
     MfmaLdsLayout L;
     const int rh = wh - s + 1, rw = ww - s + 1;
@@ -91,9 +97,12 @@ __host__ __device__ inline MfmaLdsLayout mfma_lds_layout(int wh, int ww, int s, 
     L.wpitch = 16 * ntx + (s <= 48 ? 52 : 68);
     if (L.wpitch < round_up(ww, 4)) L.wpitch = round_up(ww, 4);
     L.win_off = kMiscMfmaBytes;
-    L.sii_off = round_up(L.win_off + (wh + band - 1) * L.wpitch, 16);
+    L.sii_off = round_up(L.win_off + (wh + (paired ? 2 * band : band) - 1) * L.wpitch, 16);
     L.u_off = round_up(L.sii_off + rh * rw * 4, 16);
-    L.arow = s <= 48 ? 768 : 1024;                  // columns >= 48 of a template row are zero unless s = 49
+    L.gpitch = paired ? 128 : 256;
+    L.arow = (s <= 48 ? 3 : 4) * L.gpitch;          // columns >= 48 of a template row are zero unless s = 49
+    L.arow0 = paired ? 4 * L.arow : 0;
+    L.tab_rows = paired ? s + 9 : s + 1;            // unpaired: one all-zero row behind the template
     // rotated template samples stay within hypot(tc, tc) of the centre, tc = int(s/2)+1 (pmlib.py:105)
     const int tc = s / 2 + 1;
     int r = 0;
@@ -101,7 +110,7 @@ __host__ __device__ inline MfmaLdsLayout mfma_lds_layout(int wh, int ww, int s, 
     L.pradius = r + 1;
     L.pdim = 2 * L.pradius + 2;
     L.ppitch = round_up(L.pdim, 4);
-    L.patch_off = L.u_off + round_up((s + 1) * L.arow + 16, 16);  // + one all-zero row + 16 scratch bytes
+    L.patch_off = L.u_off + round_up(L.tab_rows * L.arow + 16, 16);   // + 16 scratch bytes
     L.queue_off = round_up(L.patch_off + L.pdim * L.ppitch + 1, 16);  // + one byte = 128 behind the patch (flagged table entries)
     L.trow_bytes = 4 * (s + kTrowPad) * 16;
     int u = rh * ww * 4;                                          // column sums
@@ -115,7 +124,8 @@ __host__ __device__ inline MfmaLdsLayout mfma_lds_layout(int wh, int ww, int s, 
 __host__ __device__ inline int samp_pitch(int s) { return round_up(s, 4); }
 constexpr double kSampGuard = 1e-5;   // table entries whose coordinate is this close to k + 1/2 are flagged
 
-int launch_pm_mfma(const PMArgs &args, int lds_bytes, int nthreads, int band, void *stream);
+int launch_pm_mfma(const PMArgs &args, int lds_bytes, int nthreads, int band, bool paired, void *stream);
+constexpr int kPairedMaxAngles = 7;   // angle sets this small run the paired sweep
 bool mfma_band8_supported(int s);
 bool mfma_img_size_supported(int s);
 

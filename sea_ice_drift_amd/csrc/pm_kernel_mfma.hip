@@ -78,6 +78,7 @@ struct MiscM {                       // LDS offset 0, kMiscMfmaBytes reserved
 // non-inlined functions so that each gets its own register allocation; their shared state is here).
 struct Geo {
     int wh, ww, rh, rw, npos, wpitch, arow, s, K;
+    int gpitch, arow0, tab_rows, ones_slot;   // operand-table geometry (mfma_lds_layout) and the all-ones slot: 15, or 7 paired
     int win_off, sii_off, u_off, patch_off, ppitch, pdim, pradius, queue_off, trow_bytes;
     int pr0, pc0;                    // patch origin on image 1
     u32 win_magic;                   // floor(2^32 / (wpitch/4)) + 1: idx / (wpitch/4) == umulhi(idx, win_magic) for idx < 2^16
@@ -638,9 +639,9 @@ __device__ __noinline__ void ph_tpl_begin(const double *rot, int a0, int Kg, lon
 {
     SID_PHASE_LOCALS;
     uint8_t *afrag = smem + G.u_off;
-    const int s = S > 0 ? S : G.s, arow = G.arow;
+    const int arow = G.arow;
     if (tid < 4 * Kg) (&m->rot[0][0])[tid] = rot[4 * a0 + tid];        // one global round trip for the whole group
-    for (int idx = tid; idx < (s + 1) * arow / 16; idx += kBlockM) reinterpret_cast<uint4 *>(afrag)[idx] = make_uint4(0, 0, 0, 0);
+    for (int idx = tid; idx < G.tab_rows * arow / 16; idx += kBlockM) reinterpret_cast<uint4 *>(afrag)[idx] = make_uint4(0, 0, 0, 0);
     if (tid < kSlots) { m->isT[tid] = 0; m->isTT[tid] = 0; }
     __syncthreads();                                                   // also: patch complete
     if (dbg_cycles && tid == 0) dbg_cycles[8] = (long long)clock64();
@@ -655,9 +656,9 @@ __device__ __noinline__ void ph_tpl_general(int a0, int Kg, long long rows1, lon
     const uint8_t *patch = smem + G.patch_off;
     const int s = S > 0 ? S : G.s, arow = G.arow;                      // compile-time s: divisions by s become multiplies
     const SampleGeom g = sample_geom(G, s, rows1, cols1, patch);
-    const int dump = (s + 1) * arow;                                   // 16 scratch bytes behind the operand table
+    const int dump = G.tab_rows * arow;                                // 16 scratch bytes behind the operand table
     // byte offset of (row ig + k*ngrp, column j, slot a) = wbase + k*wstep + 16 a
-    const int wbase = g.ig * arow + (g.j >> 4) * 256 + (g.j & 15), wstep = g.ngrp * arow;
+    const int wbase = G.arow0 + g.ig * arow + (g.j >> 4) * G.gpitch + (g.j & 15), wstep = g.ngrp * arow;
     int sawzero = 0;
     auto run = [&](auto inside_tag) {
         constexpr bool INSIDE = decltype(inside_tag)::value;
@@ -759,7 +760,7 @@ __device__ __noinline__ void ph_tpl_table(const uint16_t *samp, int a0, int Kg, 
                         zero |= (z - 0x01010101u) & ~z & 0x80808080u;  // some valid byte == 0
                         sv = __builtin_amdgcn_udot4(raw, 0x01010101u, sv, false);
                         svv = __builtin_amdgcn_udot4(raw, raw, svv, false);
-                        *reinterpret_cast<u32 *>(afrag + i * arow + (jq >> 2) * 256 + a * 16 + (jq & 3) * 4) = (raw ^ 0x80808080u) & vm;
+                        *reinterpret_cast<u32 *>(afrag + G.arow0 + i * arow + (jq >> 2) * G.gpitch + a * 16 + (jq & 3) * 4) = (raw ^ 0x80808080u) & vm;
                     }
                 }
 #pragma unroll
@@ -793,7 +794,7 @@ __device__ __noinline__ void ph_tpl_fix(const uint16_t *samp, int a0, int Kg, lo
         const double *rot4 = winner_ka < 0 ? m->rot[a] : m->rot[0];
         const int v = sample_exact(g, rot4, i, j);
         if (winner_ka < 0) {
-            (smem + G.u_off)[i * arow + ((j >> 4) * 16 + a) * 16 + (j & 15)] = (uint8_t)(v ^ 0x80);
+            (smem + G.u_off)[G.arow0 + i * arow + (j >> 4) * G.gpitch + a * 16 + (j & 15)] = (uint8_t)(v ^ 0x80);
             atomicAdd(&m->isT[a], v - 128); atomicAdd(&m->isTT[a], (v - 128) * (v - 128));
             if (v == 0) m->zero_flag = 1;
         } else {
@@ -813,7 +814,7 @@ __device__ __noinline__ void ph_tpl_end(int a0, int Kg, uint8_t *dbg_templates, 
     if (dbg_cycles && tid == 0) dbg_cycles[15] = (long long)clock64();
     for (int idx = tid; idx < s * s; idx += kBlockM) {                  // slot 15: all-ones template
         const int i = idx / s, j = idx - i * s;
-        afrag[i * arow + ((j >> 4) * 16 + 15) * 16 + (j & 15)] = 1;
+        afrag[G.arow0 + i * arow + (j >> 4) * G.gpitch + G.ones_slot * 16 + (j & 15)] = 1;
     }
     __syncthreads();
     if (dbg_cycles && tid == 0) dbg_cycles[9] = (long long)clock64();
@@ -821,7 +822,7 @@ __device__ __noinline__ void ph_tpl_end(int a0, int Kg, uint8_t *dbg_templates, 
         for (int idx = tid; idx < Kg * s * s; idx += kBlockM) {
             const int a = idx / (s * s), rem = idx - a * s * s;
             const int i = rem / s, j = rem - i * s;
-            dbg_templates[(a0 + a) * s * s + rem] = afrag[i * arow + ((j >> 4) * 16 + a) * 16 + (j & 15)] ^ 0x80;
+            dbg_templates[(a0 + a) * s * s + rem] = afrag[G.arow0 + i * arow + (j >> 4) * G.gpitch + a * 16 + (j & 15)] ^ 0x80;
         }
     }
     if (tid < Kg) {                                                    // per-angle terms (signed domain)
@@ -934,9 +935,14 @@ __device__ __forceinline__ void sweep_item(v4i (&acc)[kBand], const uint8_t *ap,
 //   of the running maximum are queued for exact evaluation.  |estimate - value| <= 4e-7, so the
 //   true arg-max is always queued.
 // ---------------------------------------------------------------------------------------------
-template <int S, int kBand>
+// PAIRED (at most 7 angles, one group): the 16 MFMA slots hold the angles + the all-ones template twice;
+// the lanes of slots 8..15 read the operand table four rows earlier, so their accumulators belong to the
+// output rows kBand below those of slots 0..7 - an item covers 2 * kBand rows with the same kBand
+// accumulators, i.e. nearly half the MFMAs, window fragments and LDS traffic per output row.
+template <int S, int kBand, bool PAIRED>
 __device__ __forceinline__ Score ph_sweep(Score sc, int a0, int Kg, long long *dbg_cycles)
 {
+    static_assert(!PAIRED || kBand == 4, "the operand table of the paired mode is shifted by four rows");
     SID_PHASE_LOCALS;
     const uint8_t *afrag = smem + G.u_off;
     const uint8_t *win = smem + G.win_off;
@@ -945,35 +951,41 @@ __device__ __forceinline__ Score ph_sweep(Score sc, int a0, int Kg, long long *d
     const int s = S > 0 ? S : G.s, rh = G.rh, rw = G.rw, wpitch = G.wpitch, arow = G.arow;
     const double nd = G.nd;
     const bool zero_a = (s <= 48) && q_l == 3;
-    // lanes of k-group 3 sit on the zero row with stride 0
-    const uint8_t *abase = zero_a ? afrag + s * arow : afrag + lane * 16;
+    // lanes of k-group 3 sit on a zero row with stride 0
+    const uint8_t *abase = PAIRED ? (zero_a ? afrag : afrag + (n_l >= 8 ? 0 : 4) * arow + q_l * 128 + (n_l & 7) * 16)
+                                  : (zero_a ? afrag + s * arow : afrag + lane * 16);
     const int arow_l = zero_a ? 0 : arow;
+    constexpr int kRows = PAIRED ? 2 * kBand : kBand;                  // output rows per work item
+    const int yq = PAIRED ? kBand * (q_l >> 1) : 0;                    // this lane's accumulators: rows y0 + yq + t
+    // accumulator register r of this lane belongs to slot 4 q + r: angle index (the ones slot never is < Kg)
+    auto angle_of = [&](int r) { return PAIRED ? ((4 * q_l + r) & 7) : 4 * q_l + r; };
 
     // estimate of slot r at a placement: float(acc * A4[r] - Sw' * B4[r]) * rsq(dI), with the template's
     // 1/sqrt(dT) folded into both per-slot factors (NaN for a constant template => always a candidate)
     double A4[4], B4[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        const int a = 4 * q_l + r;
+        const int a = angle_of(r);
         const double rTa = a < Kg ? (m->constT[a0 + a] ? (double)NAN : m->rTd[a0 + a]) : 0.0;
         A4[r] = nd * rTa;
         B4[r] = (a < Kg ? m->sTd[a0 + a] : 0.0) * rTa;
     }
-    const u32 livebits = (4 * q_l + 0 < Kg ? 1u : 0u) | (4 * q_l + 1 < Kg ? 2u : 0u) |
-                         (4 * q_l + 2 < Kg ? 4u : 0u) | (4 * q_l + 3 < Kg ? 8u : 0u);
+    const u32 livebits = (angle_of(0) < Kg ? 1u : 0u) | (angle_of(1) < Kg ? 2u : 0u) |
+                         (angle_of(2) < Kg ? 4u : 0u) | (angle_of(3) < Kg ? 8u : 0u);
 #define STAMP2(k) do { if (dbg_cycles && tid == 0) dbg_cycles[k] = (long long)clock64(); } while (0)
 
-    const int nbands = (rh + kBand - 1) / kBand, ntx = (rw + 15) / 16;
+    const int nbands = (rh + kRows - 1) / kRows, ntx = (rw + 15) / 16;
     for (int item = wv; item < nbands * ntx; item += kWavesM) {
         const int band = item / ntx, xt = item - band * ntx;
-        const int y0 = band * kBand, x0 = xt * 16;
+        const int y0 = band * kRows, x0 = xt * 16;
         // k-group 3 multiplies the all-zero template columns (s <= 48): its lanes read the window bytes of
         // k-group 0 (same addresses = LDS broadcast, and the window pitch needs no room for columns 48..63)
         const u32 sbyte = (u32)(x0 + n_l + 16 * (zero_a ? 0 : q_l));
         const u32 sh = sbyte & 3u;
         if (item == wv) STAMP2(10);
         v4i acc[kBand];
-        sweep_item<S, kBand>(acc, abase, arow_l, win + y0 * wpitch + (sbyte & ~3u), wpitch, s, sh);
+        sweep_item<(PAIRED && S > 0) ? S + 4 : S, kBand>(acc, abase, arow_l, win + y0 * wpitch + (sbyte & ~3u), wpitch,
+                                                         PAIRED ? s + 4 : s, sh);
         if (item == wv) STAMP2(11);
 
         {
@@ -987,8 +999,9 @@ __device__ __forceinline__ Score ph_sweep(Score sc, int a0, int Kg, long long *d
         u32 siiv[kBand];
 #pragma unroll
         for (int t = 0; t < kBand; ++t) {
-            swp[t] = __builtin_amdgcn_ds_bpermute((n_l + 48) << 2, acc[t][3]);   // slot 15 = sum of w'
-            const int y = y0 + t;
+            // the ones slot = sum of w': slot 15 (lanes 48..63, register 3), or slots 7 / 15 in paired mode
+            swp[t] = __builtin_amdgcn_ds_bpermute((PAIRED ? n_l + 16 + 32 * (q_l >> 1) : n_l + 48) << 2, acc[t][3]);
+            const int y = y0 + yq + t;
             siiv[t] = sii[(xok & (y < rh)) ? y * rw + x : 0];
         }
         auto estimate_row = [&](int t, float (&e)[4]) {
@@ -996,7 +1009,7 @@ __device__ __forceinline__ Score ph_sweep(Score sc, int a0, int Kg, long long *d
             const double dI = nd * siid - swd * swd;                  // exact
             float rIf = __builtin_amdgcn_rsqf((float)dI);
             rIf = (2.0 * dI <= nd) ? NAN : rIf;                       // (nearly) flat window: the exact path decides
-            const u32 lv = (xok & (y0 + t < rh)) ? livebits : 0u;
+            const u32 lv = (xok & (y0 + yq + t < rh)) ? livebits : 0u;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float v = (float)__builtin_fma((double)acc[t][r], A4[r], -(swd * B4[r])) * rIf;
@@ -1025,8 +1038,8 @@ __device__ __forceinline__ Score ph_sweep(Score sc, int a0, int Kg, long long *d
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     if (e[r] != -INFINITY && !(e[r] < thr)) {         // live, and true for NaN
-                        const int a = 4 * q_l + r;
-                        const int key = ((a0 + a) * rh + y0 + t) * rw + x;
+                        const int a = angle_of(r);
+                        const int key = ((a0 + a) * rh + y0 + yq + t) * rw + x;
                         const u32 slot = atomicAdd(&m->qcount, 1u);
                         if (slot < (u32)kQueueCap) queue[slot] = make_uint4((u32)acc[t][r], (u32)swp[t], siiv[t], (u32)key);
                         else ovf |= 1u << (4 * t + r);
@@ -1050,8 +1063,8 @@ __device__ __forceinline__ Score ph_sweep(Score sc, int a0, int Kg, long long *d
 #pragma unroll
                         for (int rr = 0; rr < 4; ++rr) pv = b == 4 * tt + rr ? acc[tt][rr] : pv;
                     }
-                    const int a = 4 * q_l + r;
-                    const int key = ((a0 + a) * rh + y0 + t) * rw + x;
+                    const int a = angle_of(r);
+                    const int key = ((a0 + a) * rh + y0 + yq + t) * rw + x;
                     take_better(sc, exact_from_sums(pv, sw, si, nd, m->sTd[a0 + a], m->rTd[a0 + a], m->constT[a0 + a] != 0), key);
                 }
             }
@@ -1300,7 +1313,7 @@ __device__ __noinline__ void ph_hessian(unsigned flags, int iy, int ix, float be
 
 // BAND = 4: up to 768 threads, three wavefronts per SIMD (168 VGPRs).  BAND = 8: 256 threads, two per SIMD (the
 // class whose LDS footprint admits two workgroups per CU anyway): an 8-row band halves the LDS bytes per MFMA.
-template <int S, int BAND>
+template <int S, int BAND, bool PAIRED>
 __global__ __launch_bounds__(BAND == 8 ? 512 : kMaxBlockM, BAND == 8 ? 2 : kOccM) void pm_kernel_mfma(const PMArgs A)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1333,10 +1346,11 @@ __global__ __launch_bounds__(BAND == 8 ? 512 : kMaxBlockM, BAND == 8 ? 2 : kOccM
     const int wh = (int)(r1e - r0), ww = (int)(c1e - c0);
     const int rh = wh - s + 1, rw = ww - s + 1, npos = rh * rw;
     if (tid == 0) {
-        const MfmaLdsLayout L = mfma_lds_layout(wh, ww, s, BAND);
+        const MfmaLdsLayout L = mfma_lds_layout(wh, ww, s, BAND, PAIRED);
         const double c1 = A.c1[pt], r1 = A.r1[pt];
-        G->band = BAND;
+        G->band = PAIRED ? 2 * BAND : BAND;
         G->wh = wh; G->ww = ww; G->rh = rh; G->rw = rw; G->npos = npos; G->wpitch = L.wpitch; G->arow = L.arow;
+        G->gpitch = L.gpitch; G->arow0 = L.arow0; G->tab_rows = L.tab_rows; G->ones_slot = PAIRED ? 7 : 15;
         G->s = s; G->K = K;
         G->win_off = L.win_off; G->sii_off = L.sii_off; G->u_off = L.u_off; G->patch_off = L.patch_off;
         G->ppitch = L.ppitch; G->pdim = L.pdim; G->pradius = L.pradius; G->queue_off = L.queue_off;
@@ -1376,7 +1390,7 @@ __global__ __launch_bounds__(BAND == 8 ? 512 : kMaxBlockM, BAND == 8 ? 2 : kOccM
         }
         SID_STAMP(3);
 #ifndef SID_ABLATE_SWEEP
-        sc = ph_sweep<S, BAND>(sc, a0, Kg, A.dbg_cycles);
+        sc = ph_sweep<S, BAND, PAIRED>(sc, a0, Kg, A.dbg_cycles);
 #else
         sc.bestv = 0.5f; sc.bestkey = 17;
 #endif
@@ -1434,17 +1448,22 @@ bool mfma_img_size_supported(int s) { return s >= 2 && s + 15 <= 64; }
 
 bool mfma_band8_supported(int s) { return s == 34 || s == 35; }
 
-int launch_pm_mfma(const PMArgs &args, int lds_bytes, int nthreads, int band, void *stream)
+int launch_pm_mfma(const PMArgs &args, int lds_bytes, int nthreads, int band, bool paired, void *stream)
 {
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (args.n_launch <= 0) return (int)hipSuccess;
-    void (*kern)(const PMArgs) = pm_kernel_mfma<0, 4>;
-    if (band == 8) {
+    void (*kern)(const PMArgs) = nullptr;
+    if (paired) {                                                      // at most 7 angles: one group, paired slots
+        if (band != 4 || args.n_angles > kPairedMaxAngles) return (int)hipErrorInvalidValue;
+        kern = args.img_size == 34 ? pm_kernel_mfma<34, 4, true> : args.img_size == 35 ? pm_kernel_mfma<35, 4, true>
+                                                                                        : pm_kernel_mfma<0, 4, true>;
+    } else if (band == 8) {
         if (!mfma_band8_supported(args.img_size) || (nthreads != 256 && nthreads != 512)) return (int)hipErrorInvalidValue;
-        kern = args.img_size == 34 ? pm_kernel_mfma<34, 8> : pm_kernel_mfma<35, 8>;
-    } else if (band != 4) return (int)hipErrorInvalidValue;
-    else if (args.img_size == 34) kern = pm_kernel_mfma<34, 4>;
-    else if (args.img_size == 35) kern = pm_kernel_mfma<35, 4>;
+        kern = args.img_size == 34 ? pm_kernel_mfma<34, 8, false> : pm_kernel_mfma<35, 8, false>;
+    } else if (band == 4) {
+        kern = args.img_size == 34 ? pm_kernel_mfma<34, 4, false> : args.img_size == 35 ? pm_kernel_mfma<35, 4, false>
+                                                                                         : pm_kernel_mfma<0, 4, false>;
+    } else return (int)hipErrorInvalidValue;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
     if (e != hipSuccess) return (int)e;
