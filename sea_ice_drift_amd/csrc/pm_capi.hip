@@ -227,14 +227,26 @@ int check_sweep(int kernel, int img_size, const double *angles, int n_angles, ui
     if (!size_supported(kernel, img_size))
         return fail(SID_PM_ERR_UNSUPPORTED, "img_size=%d: the %s kernel supports %s", img_size,
                     kernel == KERNEL_DOT4 ? "dot4" : "MFMA", kernel == KERNEL_DOT4 ? "33..36" : "2..49");
-    if (flags & SID_PM_HES_SMTH) return fail(SID_PM_ERR_UNSUPPORTED, "hes_smth=True is not implemented on the device");
+    if ((flags & SID_PM_HES_SMTH) && kernel == KERNEL_DOT4)
+        return fail(SID_PM_ERR_UNSUPPORTED, "hes_smth=True is implemented by the MFMA kernel only");
     if (flags & ~(SID_PM_HES_NORM | SID_PM_HES_SMTH | SID_PM_MCC_NORM)) return fail(SID_PM_ERR_ARG, "unknown flag bits");
     return SID_PM_OK;
+}
+
+// scipy.ndimage.gaussian_filter(ccm, 1) taps (pmlib.py:46-47): exp(-k^2 / 2), k = -4..4, divided by their sum in
+// NumPy's pairwise order for nine terms; host libm, as in the oracle
+void gauss_taps(double w5[5])
+{
+    double w[9];
+    for (int k = -4; k <= 4; ++k) w[k + 4] = exp(-0.5 * (double)(k * k));
+    const double sum = (((w[0] + w[1]) + (w[2] + w[3])) + ((w[4] + w[5]) + (w[6] + w[7]))) + w[8];
+    for (int k = 0; k < 5; ++k) w5[k] = w[k] / sum;
 }
 
 int fill_args(sid_pm_ctx *ctx, sid::PMArgs &A)
 {
     memset(&A, 0, sizeof A);
+    gauss_taps(A.gauss_w);
     A.img1 = ctx->cur[0].ptr; A.rows1 = ctx->cur[0].rows; A.cols1 = ctx->cur[0].cols; A.stride1 = ctx->cur[0].stride;
     A.img2 = ctx->cur[1].ptr; A.rows2 = ctx->cur[1].rows; A.cols2 = ctx->cur[1].cols; A.stride2 = ctx->cur[1].stride;
     const int64_t n = ctx->n;
@@ -688,6 +700,7 @@ SID_EXPORT int sid_pm_debug_point(sid_pm_ctx *ctx, double c1, double r1, double 
         A.angles = dang.p; A.rot = drot.p; A.out = dout.p; A.out_ij = dij.p;
         A.dbg_templates = dt.p; A.dbg_ccm = dccm.p; A.dbg_hes = dhes.p; A.dbg_shape = dshape.p; A.dbg_cap = cap;
         A.dbg_cycles = dcyc.p;
+        gauss_taps(A.gauss_w);
         A.samp = sampv.empty() ? nullptr : dsamp.p; A.samp_nflag = nflag;
         step((hipError_t)(ctx->kernel == KERNEL_DOT4 ? sid::launch_pm(A, lds, ctx->stream)
                                                      : sid::launch_pm_mfma(A, lds, getenv("SID_PM_THREADS") ? atoi(getenv("SID_PM_THREADS")) : 256, 4, use_paired(ctx->kernel, K), ctx->stream)));

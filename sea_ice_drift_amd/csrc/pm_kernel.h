@@ -27,6 +27,7 @@ struct PMArgs {
     // null = always sample on the fly
     const uint16_t *samp;
     int32_t samp_nflag;                             // number of flagged entries in samp (0 almost always)
+    double gauss_w[5];                              // hes_smth: normalised sigma-1 Gaussian taps w[0] (|k| = 4) .. w[4] (centre), host-computed
     double *out;                                    // [n_total][5]
     int32_t *out_ij;                                // [n_total][3]
     // diagnostics (debug_point only; null in production launches)

@@ -66,6 +66,7 @@ struct MiscM {                       // LDS offset 0, kMiscMfmaBytes reserved
     u32 gmax_key;                    // block-wide running max of the float32 estimates (ordered key)
     u32 qcount;                      // candidate queue fill
     int pad_;
+    double gw[5];                    // hes_smth: Gaussian taps (PMArgs::gauss_w)
     int isT[kSlots], isTT[kSlots];   // integer template sums of the current group
     double rot[kSlots][4];           // cos, sin, tcT0, tcT1 of the current group's angles
     double rTd[kMaxAngles];          // 1/sqrt(dT) per angle
@@ -1235,6 +1236,48 @@ __device__ __noinline__ void ph_hessian(unsigned flags, int iy, int ix, float be
     u32 *hist4 = reinterpret_cast<u32 *>(smem + G.u_off);             // winner operands are dead: 4 KB of histograms
     u32 *medlist = hist4 + 1024;                                       // + 1 KB of keys (2 * trow_bytes >= 5 KB for every s)
     const int rh = G.rh, rw = G.rw, npos = G.npos;
+    float rr = best_r;
+    if (flags & 4u) {                                                  // mcc_norm (pmlib.py:171-172): on the unsmoothed matrix
+        double cx = 0.0, cxx = 0.0;
+        float cmin = INFINITY, cmax = -INFINITY;
+        for (int idx = tid; idx < npos; idx += kBlockM) {
+            const float c = ccm[idx];
+            const double v = (double)c;
+            cx += v; cxx += v * v;
+            cmin = fminf(cmin, c); cmax = fmaxf(cmax, c);
+        }
+        block_sum2(cx, cxx, m);
+        const float sd = std_from_sums(cx, cxx, npos);
+        const float med = block_median_fast(ccm, npos, m, hist4, medlist, f2key(cmin), f2key(cmax));
+        rr = (best_r - med) / sd;
+    }
+    if (flags & 2u) {
+        // hes_smth (pmlib.py:46-47): scipy.ndimage.gaussian_filter(ccm, 1) in place - per axis a radius-4
+        // kernel in double ('reflect' boundary; centre tap first, then the pairs from the outermost inwards,
+        // as scipy's correlate1d does for a symmetric kernel), rounded to float32 after each axis
+        float *tmp = hes;                                              // the Hessian buffer is free until the gradient pass
+        float *cw = reinterpret_cast<float *>(smem + G.u_off + 2 * G.trow_bytes);
+        const double w4 = m->gw[4], w3 = m->gw[3], w2 = m->gw[2], w1 = m->gw[1], w0 = m->gw[0];
+        auto refl = [](int q, int n) { while (q < 0 || q >= n) { if (q < 0) q = -q - 1; if (q >= n) q = 2 * n - 1 - q; } return q; };
+        __syncthreads();
+        for (int pass = 0; pass < 2; ++pass) {
+            const float *src = pass == 0 ? ccm : tmp;
+            float *dst = pass == 0 ? tmp : cw;
+            const int n = pass == 0 ? rh : rw, stride = pass == 0 ? rw : 1;
+            for (int idx = tid; idx < npos; idx += kBlockM) {
+                const int y = idx / rw, x = idx - y * rw;
+                const int p = pass == 0 ? y : x;
+                const float *line = src + (pass == 0 ? x : y * rw);
+                double acc = (double)line[p * stride] * w4;
+                acc += ((double)line[refl(p - 4, n) * stride] + (double)line[refl(p + 4, n) * stride]) * w0;
+                acc += ((double)line[refl(p - 3, n) * stride] + (double)line[refl(p + 3, n) * stride]) * w1;
+                acc += ((double)line[refl(p - 2, n) * stride] + (double)line[refl(p + 2, n) * stride]) * w2;
+                acc += ((double)line[refl(p - 1, n) * stride] + (double)line[refl(p + 1, n) * stride]) * w3;
+                dst[idx] = (float)acc;
+            }
+            __syncthreads();
+        }
+    }
     double sx = 0.0, sxx = 0.0;
     float hmin = INFINITY, hmax = -INFINITY;
     {
@@ -1291,21 +1334,6 @@ __device__ __noinline__ void ph_hessian(unsigned flags, int iy, int ix, float be
         const float med = block_median_fast(hes, npos, m, hist4, medlist, f2key(hmin), f2key(hmax));
         h = (h - med) / sd;
     }
-    float rr = best_r;
-    if (flags & 4u) {
-        double cx = 0.0, cxx = 0.0;
-        float cmin = INFINITY, cmax = -INFINITY;
-        for (int idx = tid; idx < npos; idx += kBlockM) {
-            const float c = ccm[idx];
-            const double v = (double)c;
-            cx += v; cxx += v * v;
-            cmin = fminf(cmin, c); cmax = fmaxf(cmax, c);
-        }
-        block_sum2(cx, cxx, m);
-        const float sd = std_from_sums(cx, cxx, npos);
-        const float med = block_median_fast(ccm, npos, m, hist4, medlist, f2key(cmin), f2key(cmax));
-        rr = (best_r - med) / sd;
-    }
     __syncthreads();
     if (tid == 0) { m->red_f[0] = h; m->red_f[1] = rr; }
     __syncthreads();
@@ -1360,6 +1388,7 @@ __global__ __launch_bounds__(BAND == 8 ? 512 : kMaxBlockM, BAND == 8 ? 2 : kOccM
         G->rw_magic = 0xffffffffu / (u32)rw + 1u;
         G->r0 = r0; G->c0 = c0; G->c1 = c1; G->r1 = r1; G->nd = (double)(s * s);
         m->zero_flag = 0; m->gmax_key = 0x007fffffu /* f2key(-inf) */; m->qcount = 0;
+        for (int k = 0; k < 5; ++k) m->gw[k] = A.gauss_w[k];
     }
     __syncthreads();
 

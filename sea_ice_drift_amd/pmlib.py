@@ -12,7 +12,7 @@ The structure is  prelude (host, NumPy)  ->  dispatch (GPU)  ->  postlude (host,
 * the dispatch replaces the ``multiprocessing.Pool.map`` of pmlib.py:436-448 with the HIP
   kernel behind the C ABI (``_capi``).  ``threads`` is accepted for signature compatibility
   and ignored.  There is no CPU fallback: without the HIP library / a gfx950 device this
-  raises.  Options the kernel does not implement (``hes_smth=True``, ``rot_order != 0``, a
+  raises.  Options the kernel does not implement (``rot_order != 0``, a
   user ``template_matcher``, ``img_size`` outside 2..49) raise ``NotImplementedError``;
 * ``pm_postlude``  turns the (N,5) result block into the seven output grids as
                    pmlib.py:451-497 does.
@@ -168,8 +168,6 @@ def _sweep_options(kwargs):
     angles = list(kwargs.get('angles', [-3, 0, 3]))
     flags = _capi.flags_from_kwargs(hes_norm=kwargs.get('hes_norm', True), hes_smth=kwargs.get('hes_smth', False),
                                     mcc_norm=kwargs.get('mcc_norm', False))
-    if flags & _capi.HES_SMTH:
-        raise NotImplementedError('hes_smth=True is not implemented on the device')
     return angles, flags
 
 

@@ -166,3 +166,22 @@ def test_pair_streaming_through_two_slots(pm_ctx, c_oracle):
                                         ANGLES7, rot=rot, nthreads=8)
         assert_parity(results[k][0], results[k][1], exp, exp_ij)
     assert not np.array_equal(results[0][1], results[1][1])            # the pairs really differ
+
+
+@pytest.mark.parametrize('flags', [2, 3, 7, 6])
+def test_hessian_options_incl_gaussian_smoothing(pm_ctx, c_oracle, flags):
+    """hes_smth (scipy gaussian_filter sigma 1 before the Hessian, pmlib.py:46-47) alone and combined with
+    hes_norm / mcc_norm: flags bit 0 = hes_norm, bit 1 = hes_smth, bit 2 = mcc_norm."""
+    img1, img2 = syn.make_pair(600, 600, seed=55)
+    g = syn.make_grid(600, 600, 9, margin=90)
+    rot = rot_for(ANGLES7, 0.0, 34)
+    exp, exp_ij = c_oracle.pm_batch(img1, img2, g['c1'], g['r1'], g['c2fg'], g['r2fg'], g['border'], 34, 0.0,
+                                    ANGLES7, rot=rot, flags=flags, nthreads=8)
+    pm_ctx.upload_pair(img1, img2)
+    pm_ctx.set_points(g['c1'], g['r1'], g['c2fg'], g['r2fg'], g['border'], 34, 0.0, ANGLES7, rot=rot, flags=flags)
+    pm_ctx.run()
+    got, got_ij = pm_ctx.fetch()
+    np.testing.assert_array_equal(got_ij, exp_ij)
+    np.testing.assert_array_equal(got[:, :3], exp[:, :3])
+    np.testing.assert_allclose(got[:, 3], exp[:, 3], rtol=1e-5, atol=1e-5)      # r: exact unless mcc_norm
+    np.testing.assert_allclose(got[:, 4], exp[:, 4], rtol=1e-5, atol=1e-5)      # h

@@ -104,8 +104,6 @@ def test_unsupported_options_raise_instead_of_falling_back():
     img = np.ones((200, 200), dtype=np.uint8)
     args = ([100.0], [100.0], [100.0], [100.0], [20.0], 34, 0.0)
     with pytest.raises(NotImplementedError):
-        my.pm_dispatch(img, img, *args, hes_smth=True)
-    with pytest.raises(NotImplementedError):
         my.pm_dispatch(img, img, *args, rot_order=1)
     with pytest.raises(NotImplementedError):
         my.pm_dispatch(img, img, *args, template_matcher=lambda *a: None)

@@ -48,8 +48,8 @@ def test_g2_hessian(c_oracle, n):
     np.testing.assert_array_equal(po.get_hessian(m), g['norm%d' % n])
     np.testing.assert_array_equal(c_oracle.hessian(m, 0), g['raw%d' % n])
     np.testing.assert_array_equal(c_oracle.hessian(m, 1), g['norm%d' % n])
-    # hes_smth: the C form restates scipy's gaussian_filter; float32 round-off level agreement
-    np.testing.assert_allclose(c_oracle.hessian(m, 3), g['smth%d' % n], rtol=2e-4, atol=2e-4)
+    # hes_smth: the C form restates scipy's gaussian_filter (taps, 'reflect', accumulation order) bit for bit
+    np.testing.assert_array_equal(c_oracle.hessian(m, 3), g['smth%d' % n])
 
 
 # ---------------------------------------------------------------- matcher
