@@ -1,30 +1,41 @@
 #!/usr/bin/env python3
 """bench.py - PM grid-points/sec of the HIP pattern-matching path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W           (N=1 directly; N>1 under
-    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+    python bench.py --gpus N --steps K --warmup W [--mode grid|stream]
 
-Workload (BASELINE.json configs[1]): one synthetic 10000x10000 uint8 pair, 200x200 grid,
-34 px template, 15 trial angles [-7..7], mixed search border 20..50 px - the five kernel
-input vectors and both images are resident in HBM before the timed region starts.
+N = 1 runs in this process.  N > 1 works both ways: launched by ``python -m torch.distributed.run
+--nproc-per-node N ... bench.py --gpus N`` (RANK / LOCAL_RANK / WORLD_SIZE in the environment), or plainly
+as ``python bench.py --gpus N`` - the parent then starts that same launcher as a child process before it
+touches torch or the GPU (a process that has initialised the GPU is never replaced) and exits with its code.
 
-A "step" = one pass of the hot path over the whole grid: kernel launches for every point,
-the gather of the (N,5)+(N,3) results to rank 0 (RCCL when N>1) and their copy to the host
-(the reference's seam ends with the results in the parent process, pmlib.py:444,462).
-N>1 is weak scaling: every rank owns a 200x200-point share of a (200*N)x200 grid on the
-same pair (points dealt by search-window size, sea_ice_drift_amd/dist.py).
+--mode grid (default; BASELINE.json configs[1] at N = 1, configs[2] at N > 1)
+    one synthetic 10000x10000 uint8 pair, 200x200 grid, 34 px template, 15 trial angles [-7..7], mixed
+    search border 20..50 px; the five kernel-input vectors and both images are resident in HBM before the
+    timed region.  A step = one pass of the hot path over the whole grid: kernel launches for every point,
+    the gather of the packed (N,5) float64 + (N,3) int32 results to rank 0 (one RCCL gather when N > 1) and
+    their copy to the host (the reference's seam ends with the results in the parent, pmlib.py:444,462).
+    N > 1 is STRONG scaling by default - the same 200x200 grid dealt to the ranks by search-window size
+    (sea_ice_drift_amd/dist.py) - and the weak figure ((200*N)x200 grid, 40 000 points per GPU) is measured
+    after it and reported under "weak_scaling"; ``--scaling weak`` makes the weak workload the headline.
 
-Prints ONE JSON line on rank 0 (see the task contract), with a "roofline" object measured
-live from HIP events around the kernel launches and a "cpu_baseline" object = the C oracle
-(oracle/pm_oracle.c, OpenMP over points) timed on a bounded sample of the same workload.
+--mode stream (BASELINE.json configs[4])
+    a batch of --pairs (16) synthetic 10000x10000 pairs in pinned host memory, dealt round-robin to the ranks;
+    every rank streams its pairs through the two device slots of its handle (sid_pm_upload_pair on the copy
+    stream while the kernels of the previous pair run) and fetches each result block.  A step = the whole
+    batch; value = points of all pairs / time, uploads included.  No collective on the data path.
+
+Prints ONE JSON line on rank 0 with a "roofline" object measured live from HIP events around the kernel
+launches and a "cpu_baseline" object (B2 = the C oracle with OpenMP over points, plus B1 = the
+reference-shaped Python/Pool loop under "b1") timed on bounded samples of the same workload.
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
@@ -37,63 +48,217 @@ HBM_PEAK_GBS = 8000.0
 MFMA_I8_PEAK_TOPS = 5000.0
 
 
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=None, help='timed steps (default 20; 3 in stream mode)')
+    ap.add_argument('--warmup', type=int, default=None, help='untimed steps (default 3; 1 in stream mode)')
+    ap.add_argument('--mode', choices=('grid', 'stream'), default='grid')
+    ap.add_argument('--pairs', type=int, default=16, help='stream mode: pairs in the batch (all ranks together)')
+    ap.add_argument('--size', type=int, default=10000, help='image side in pixels')
+    ap.add_argument('--grid', type=int, default=200, help='grid points per side')
+    ap.add_argument('--border', default='mixed', help="'mixed' or a fixed border in pixels")
+    ap.add_argument('--angles', type=int, default=7, help='trial angles are -A..A in 1 degree steps')
+    ap.add_argument('--img-size', type=int, default=34)
+    ap.add_argument('--scaling', choices=('weak', 'strong'), default=None,
+                    help='N > 1, grid mode: strong (default) = the same grid sharded; weak = grid rows x N')
+    ap.add_argument('--no-weak', action='store_true', help='skip the secondary weak-scaling measurement')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-sample', type=int, default=0, help='points in the B2 CPU sample (0 = auto, ~12 s)')
+    ap.add_argument('--check', type=int, default=64, help='points verified against the oracle after timing')
+    args = ap.parse_args(argv)
+    if args.steps is None:
+        args.steps = 3 if args.mode == 'stream' else 20
+    if args.warmup is None:
+        args.warmup = 1 if args.mode == 'stream' else 3
+    if args.scaling is None:
+        args.scaling = 'strong'
+    return args
+
+
 def host_cores():
     """CPU threads this process may really use: affinity mask capped by the cgroup CPU quota."""
     n = len(os.sched_getaffinity(0))
     try:
         quota, period = open('/sys/fs/cgroup/cpu.max').read().split()[:2]
         if quota != 'max':
-            n = min(n, max(1, int(np.ceil(int(quota) / int(period)))))
+            n = min(n, max(1, -(-int(quota) // int(period))))
     except (OSError, ValueError):
         pass
     return n
 
 
-def parse_args():
-    ap = argparse.ArgumentParser()
-    ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--size', type=int, default=10000, help='image side in pixels')
-    ap.add_argument('--grid', type=int, default=200, help='grid points per side (per GPU)')
-    ap.add_argument('--border', default='mixed', help="'mixed' or a fixed border in pixels")
-    ap.add_argument('--angles', type=int, default=7, help='trial angles are -A..A in 1 degree steps')
-    ap.add_argument('--img-size', type=int, default=34)
-    ap.add_argument('--scaling', choices=('weak', 'strong'), default='weak')
-    ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-sample', type=int, default=0, help='points in the CPU sample (0 = auto, ~15 s)')
-    ap.add_argument('--check', type=int, default=64, help='points verified against the oracle after timing')
-    return ap.parse_args()
+def free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
 
 
-def main():
-    args = parse_args()
-    import torch
-    import torch.distributed as dist
-    from sea_ice_drift_amd import _capi, synthetic as syn
-    from sea_ice_drift_amd.dist import ResultGatherer, shard_indices, shard_size
+def spawn_ranks(args, argv):
+    """``python bench.py --gpus N`` without a launcher: run torch.distributed.run as a CHILD (this process has
+    not imported torch and never touches the GPU) and hand its exit code on."""
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
+           '--master-addr', '127.0.0.1', '--master-port', str(free_port()), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1')
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    env.setdefault('OMP_NUM_THREADS', str(max(1, host_cores() // args.gpus)))
+    return subprocess.call(cmd, env=env)
 
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    rank = int(os.environ.get('RANK', '0'))
-    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit('--gpus %d needs `python -m torch.distributed.run --nproc-per-node %d bench.py ...`'
-                             % (args.gpus, args.gpus))
-        raise SystemExit('WORLD_SIZE=%d does not match --gpus %d' % (world, args.gpus))
-    if not torch.cuda.is_available():
-        raise SystemExit('bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)')
-    torch.cuda.set_device(local_rank)
-    dev = torch.device('cuda', local_rank)
+
+def lib_md5():
+    from sea_ice_drift_amd import _capi
+    with open(_capi.LIB_PATH, 'rb') as fh:
+        return hashlib.md5(fh.read()).hexdigest()
+
+
+class GridRun(object):
+    """The resident state of one grid workload on this rank + its step function."""
+
+    def __init__(self, args, dev, world, rank, local_rank, t1, t2, n_rows, angles, rot):
+        import torch
+        from sea_ice_drift_amd import _capi, synthetic as syn
+        from sea_ice_drift_amd.dist import PackedGatherer, shard_indices
+        self.torch = torch
+        s = args.img_size
+        H = W = args.size
+        border = args.border if args.border == 'mixed' else int(args.border)
+        self.g = g = syn.make_grid(H, W, (n_rows, args.grid), border=border)
+        self.n_total = g['c1'].size
+        self.idx = idx = shard_indices(g['border'], world, rank)
+        self.ctx = _capi.PMContext(local_rank)
+        self.ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+        self.ctx.bind_pair_tensors(t1, t2)
+        self.ctx.set_points(g['c1'][idx], g['r1'][idx], g['c2fg'][idx], g['r2fg'][idx], g['border'][idx], s, 0.0,
+                            angles, rot=rot)
+        self.gather = PackedGatherer(self.n_total, idx, dev)
+        out_t, ij_t = self.gather.local_views()
+        self.ctx.bind_results_tensors(out_t, ij_t)
+        self.info = self.ctx.work_info()
+        self.rank, self.world = rank, world
+
+    def step(self, ev=None):
+        if ev is not None:
+            ev[0].record()
+        self.ctx.run()
+        if ev is not None:
+            ev[1].record()
+        self.gather.gather_to_host()            # rank 0: results on the host = end of the seam
+
+    def results(self):
+        return self.gather.host_results()
+
+    def close(self):
+        self.ctx.close()
+
+
+def timed_steps(torch, dist, world, run, steps, warmup):
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(warmup):
+        run.step()
+    fence()
+    t0 = time.perf_counter()
+    for k in range(steps):
+        run.step(ev[k])
+    fence()
+    elapsed = time.perf_counter() - t0
     if world > 1:
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=dev)
+        te = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
+        dist.all_reduce(te, op=dist.ReduceOp.MAX)
+        elapsed = float(te.item())
+    kern_ms = sum(a.elapsed_time(b) for a, b in ev) / max(steps, 1)
+    return elapsed, kern_ms
 
-    border = args.border if args.border == 'mixed' else int(args.border)
+
+def traffic_from_profile(args, launches):
+    """HBM bytes per launch from the committed PMC profile (rocprofv3 cannot run inside this process).  Quoted
+    only for the workload it was collected on, and with a statement whether it was this very build."""
+    try:
+        with open(os.path.join(ROOT, 'profiles', 'traffic.json')) as fh:
+            tj = json.load(fh)
+    except (OSError, ValueError):
+        return None, 'no PMC profile under profiles/'
+    want = {'size': args.size, 'grid': args.grid, 'angles': args.angles,
+            'border': args.border if args.border == 'mixed' else int(args.border), 'img_size': args.img_size}
+    if tj.get('workload') != want:
+        return None, 'profiles/traffic.json was collected on another workload'
+    same = tj.get('so_md5') == lib_md5()
+    note = ('bytes per launch, PMC FETCH_SIZE x2 + WRITE_SIZE (profiles/traffic.json, %s): %s'
+            % ('collected on THIS build of libsid_pm.so (md5 match)' if same else
+               'collected on an EARLIER build (library md5 differs: %s vs %s)' % (tj.get('so_md5'), lib_md5()),
+               tj.get('note', '')))
+    return tj['hbm_bytes_per_launch'] * tj['launches_per_step'] / max(launches, 1), note
+
+
+def cpu_baselines(args, img1, img2, g, n_total, angles, rot, s):
+    """B2 (C oracle, OpenMP over points) and B1 (reference-shaped Python/Pool loop) on bounded samples."""
+    import numpy as np
+    from oracle import b1_baseline, c_oracle
+    nthreads = host_cores()
+    pick = lambda sel: [g[k][sel] for k in ('c1', 'r1', 'c2fg', 'r2fg', 'border')]
+    cal = np.arange(0, n_total, max(1, n_total // (8 * nthreads)))[:8 * nthreads]
+    tc = time.perf_counter()
+    c_oracle.pm_batch(img1, img2, *pick(cal), s, 0.0, angles, rot=rot, nthreads=nthreads)
+    rate = len(cal) / (time.perf_counter() - tc)
+    n_s = args.cpu_sample or int(min(n_total, max(len(cal), rate * 12.0)))
+    smp = np.linspace(0, n_total - 1, n_s).astype(np.int64)
+    tc = time.perf_counter()
+    c_oracle.pm_batch(img1, img2, *pick(smp), s, 0.0, angles, rot=rot, nthreads=nthreads)
+    dt = time.perf_counter() - tc
+    out = {'value': n_s / dt, 'unit': 'grid-points/s', 'cores': nthreads, 'kind': 'port',
+           'sample': 'B2: %d evenly spaced points of the same %d-point grid, same pair/angles/borders, '
+                     'oracle/pm_oracle.c (restated CPU pmlib, exact-integer NCC; not cv2) with OpenMP over points, '
+                     '%.1f s' % (n_s, n_total, dt)}
+    # B1: ~8 s; per-point Python tasks under a fork pool, the reference's own structure (pmlib.py:436-448)
+    cal1 = np.linspace(0, n_total - 1, 2 * nthreads).astype(np.int64)
+    tc = time.perf_counter()
+    b1_baseline.run(img1, img2, *pick(cal1), s, 0.0, angles, processes=nthreads)
+    rate1 = len(cal1) / (time.perf_counter() - tc)
+    n1 = int(min(n_total, max(len(cal1), rate1 * 8.0)))
+    smp1 = np.linspace(0, n_total - 1, n1).astype(np.int64)
+    tc = time.perf_counter()
+    b1_baseline.run(img1, img2, *pick(smp1), s, 0.0, angles, processes=nthreads)
+    dt1 = time.perf_counter() - tc
+    out['b1'] = {'value': n1 / dt1, 'unit': 'grid-points/s', 'cores': nthreads, 'kind': 'port',
+                 'sample': 'B1: %d points, one Python task per point under multiprocessing.Pool(%d) as pmlib.py:436-448; '
+                           'scipy affine_transform templates, float32-FFT correlation standing in for cv2 (absent), '
+                           'NumPy Hessian; %.1f s' % (n1, nthreads, dt1)}
+    return out
+
+
+def parity_block(args, img1, img2, g, n_total, res, res_ij, angles, rot, s):
+    """Spot check against the C oracle + the cv2-flip exposure statistic (checker only, not timed)."""
+    import numpy as np
+    from oracle import c_oracle
+    c_oracle.build()
+    sel = np.random.default_rng(0).choice(n_total, size=min(args.check, n_total), replace=False)
+    exp, exp_ij, gap = c_oracle.pm_batch(img1, img2, g['c1'][sel], g['r1'][sel], g['c2fg'][sel], g['r2fg'][sel],
+                                         g['border'][sel], s, 0.0, angles, rot=rot, nthreads=host_cores(), want_gap=True)
+    ok = (np.array_equal(res_ij[sel], exp_ij) and np.array_equal(res[sel, :4], exp[:, :4], equal_nan=True)
+          and np.allclose(res[sel, 4], exp[:, 4], rtol=1e-5, atol=1e-5, equal_nan=True))
+    fin = np.isfinite(gap)
+    return {'points': int(len(sel)), 'ok': bool(ok),
+            # a float32/DFT matcher such as cv2's carries ~1e-6 noise: peaks this close to the runner-up could flip there
+            'cv2_flip_exposure': {'gap_below_1e-6': int(((gap > 0) & (gap < 1e-6) & fin).sum()),
+                                  'exact_ties': int(((gap == 0) & fin).sum()), 'of_points': int(fin.sum()),
+                                  'min_positive_gap': float(gap[(gap > 0) & fin].min()) if ((gap > 0) & fin).any() else None}}
+
+
+def grid_mode(args, torch, dist, dev, world, rank, local_rank):
+    import numpy as np
+    from sea_ice_drift_amd import synthetic as syn
+    from sea_ice_drift_amd.pmlib import rotation_table
     angles = list(range(-args.angles, args.angles + 1))
     s = args.img_size
     H = W = args.size
-
     # ---- inputs: rank 0 generates the pair, the others receive it over xGMI ----
     t_gen = time.time()
     if rank == 0:
@@ -108,148 +273,209 @@ def main():
         dist.broadcast(t1, 0)
         dist.broadcast(t2, 0)
     t_gen = time.time() - t_gen
+    rot = rotation_table(angles, 0.0, s)          # rotation terms via NumPy, as the reference
 
-    n_rows = args.grid * world if args.scaling == 'weak' else args.grid
-    g = syn.make_grid(H, W, (n_rows, args.grid), border=border)
-    n_total = g['c1'].size
-    idx = shard_indices(g['border'], world, rank)
-    m = shard_size(n_total, world)
-    from sea_ice_drift_amd.pmlib import rotation_table     # rotation terms via NumPy, as the reference
+    headline_rows = args.grid * world if (args.scaling == 'weak' and world > 1) else args.grid
+    run = GridRun(args, dev, world, rank, local_rank, t1, t2, headline_rows, angles, rot)
+    elapsed, kern_ms = timed_steps(torch, dist, world, run, args.steps, args.warmup)
+    res, res_ij = run.results() if rank == 0 else (None, None)
+    n_total, info, g = run.n_total, run.info, run.g
+    n_local = len(run.idx)
+    run.close()
+
+    weak = None
+    if world > 1 and args.scaling == 'strong' and not args.no_weak:
+        wrun = GridRun(args, dev, world, rank, local_rank, t1, t2, args.grid * world, angles, rot)
+        ws = max(3, args.steps // 4)
+        w_el, _ = timed_steps(torch, dist, world, wrun, ws, 1)
+        weak = {'value': wrun.n_total / (w_el / ws), 'unit': 'grid-points/s', 'ms_per_step': w_el / ws * 1e3,
+                'steps': ws, 'points_total': int(wrun.n_total),
+                'workload': '(%d*%d)x%d grid on the same pair: %d points per GPU' % (args.grid, world, args.grid,
+                                                                                  wrun.n_total // world)}
+        wrun.close()
+
+    if rank != 0:
+        return None
+    ms_per_step = elapsed / args.steps * 1e3
+    launches = max(info['launches'], 1)
+    kern_s = kern_ms * 1e-3
+    # rank 0's own kernels ran on its shard: the work of that shard over its kernel time
+    mfma_achieved = 2.0 * info['macs'] / kern_s / 1e12
+    hbm_achieved = info['hbm_bytes'] / kern_s / 1e9
+    traffic, traffic_note = traffic_from_profile(args, launches) if world == 1 else (None, 'single-GPU profile only')
+    border = args.border if args.border == 'mixed' else int(args.border)
+    line = {
+        'metric': 'PM grid-points/sec (10000x10000 px pair, 34px template)',
+        'value': n_total / (elapsed / args.steps), 'unit': 'grid-points/s', 'n_gpus': world, 'steps': args.steps,
+        'warmup': args.warmup, 'ms_per_step': ms_per_step, 'higher_is_better': True,
+        'scaling': args.scaling if world > 1 else 'strong', 'vs_baseline': None, 'dtype': 'u8', 'data': 'synthetic',
+        'config': {'workload': '%dx%d grid on one synthetic %dx%d uint8 pair, template %d px, %d angles [%d..%d], '
+                               'border %s, flags hes_norm' % (headline_rows, args.grid, H, W, s, len(angles), angles[0],
+                                                             angles[-1], border),
+                   'points_total': int(n_total), 'points_per_gpu': int(n_local),
+                   'parallelism': ('single GPU, no collective' if world == 1 else
+                                   'points dealt to %d GPUs by search-window size, one RCCL gather of the packed '
+                                   'result blocks to rank 0' % world)},
+        'roofline': {
+            # the sweep runs on v_mfma_i32_16x16x64_i8: the matrix cores are the roofline that bounds it
+            'bound': 'mfma', 'achieved': mfma_achieved, 'peak': MFMA_I8_PEAK_TOPS, 'unit': 'TFLOP/s',
+            'frac': mfma_achieved / MFMA_I8_PEAK_TOPS, 'traffic': traffic, 'traffic_note': traffic_note,
+            'kernel': 'sid::pm_kernel_mfma<%d,...> (one instantiation per band height)' % (s if s in (34, 35) else 0),
+            'launches_per_step': launches, 'kernel_ms_per_step': kern_ms, 'avg_launch_ms': kern_ms / launches,
+            'algorithmic_macs_per_step': info['macs'], 'algorithmic_bytes_per_step': info['hbm_bytes'],
+            'note': 'rank 0 share: achieved = 2 x algorithmic MACs (sum K*Rh*Rw*s*s, integer ops) / kernel time from HIP '
+                    'events on the launch stream; padding of the MFMA tiles (template columns, the all-ones slot) is '
+                    'not counted as work (DESIGN.md section 6)',
+            'hbm': {'achieved': hbm_achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': hbm_achieved / HBM_PEAK_GBS,
+                    'note': '~10^4 MAC per HBM byte: not HBM-bound; algorithmic bytes = both images once at most'},
+        },
+        'setup_s': {'generate_and_upload_pair': t_gen},
+    }
+    if weak is not None:
+        line['weak_scaling'] = weak
+    if args.check > 0:
+        line['parity_check'] = parity_block(args, img1, img2, g, n_total, res, res_ij, angles, rot, s)
+        if not line['parity_check']['ok']:
+            print(json.dumps(line))
+            raise SystemExit('PARITY FAILURE against the CPU oracle - the number above is invalid')
+    if not args.no_cpu_baseline:
+        line['cpu_baseline'] = cpu_baselines(args, img1, img2, g, n_total, angles, rot, s)
+    return line
+
+
+def stream_mode(args, torch, dist, dev, world, rank, local_rank):
+    """BASELINE config 5: every rank streams its share of the batch through its two device slots."""
+    import numpy as np
+    from sea_ice_drift_amd import _capi, synthetic as syn
+    from sea_ice_drift_amd.pmlib import rotation_table
+    angles = list(range(-args.angles, args.angles + 1))
+    s = args.img_size
+    H = W = args.size
+    border = args.border if args.border == 'mixed' else int(args.border)
+    mine = list(range(rank, args.pairs, world))
+    t_gen = time.time()
+    base1, base2 = syn.make_pair(H, W)
+    # pair p = the base pair rolled by 37 p rows and 53 p columns (both images alike: the drift field moves along);
+    # distinct pixels per pair, generated in seconds, pinned so that the uploads are truly asynchronous
+    pairs = {}
+    for p in mine:
+        a = torch.from_numpy(np.roll(base1, (37 * p, 53 * p), axis=(0, 1))).pin_memory()
+        b = torch.from_numpy(np.roll(base2, (37 * p, 53 * p), axis=(0, 1))).pin_memory()
+        pairs[p] = (a, b)
+    t_gen = time.time() - t_gen
+    g = syn.make_grid(H, W, args.grid, border=border)
+    n_pts = g['c1'].size
     rot = rotation_table(angles, 0.0, s)
-
     ctx = _capi.PMContext(local_rank)
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
-    ctx.bind_pair_tensors(t1, t2)
-    ctx.set_points(g['c1'][idx], g['r1'][idx], g['c2fg'][idx], g['r2fg'][idx], g['border'][idx], s, 0.0, angles,
-                   rot=rot)
-    out_t = torch.full((m, 5), float('nan'), dtype=torch.float64, device=dev)
-    ij_t = torch.full((m, 3), -1, dtype=torch.int32, device=dev)
-    ctx.bind_results_tensors(out_t[:len(idx)], ij_t[:len(idx)])
+    first = pairs[mine[0]] if mine else (torch.from_numpy(base1), torch.from_numpy(base2))
+    ctx.upload_pair(first[0].numpy(), first[1].numpy(), slot=0)
+    ctx.set_points(g['c1'], g['r1'], g['c2fg'], g['r2fg'], g['border'], s, 0.0, angles, rot=rot)
     info = ctx.work_info()
-    gather = ResultGatherer(n_total, idx, dev)
-    host_out = torch.empty((n_total, 5), dtype=torch.float64).pin_memory() if rank == 0 else None
-    host_ij = torch.empty((n_total, 3), dtype=torch.int32).pin_memory() if rank == 0 else None
+    results = {}
 
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    class Run(object):
+        def step(self, ev=None):
+            # pair k matches from slot k % 2 while pair k+1 uploads into the other slot
+            if mine:
+                a, b = pairs[mine[0]]
+                ctx.upload_pair(a.numpy(), b.numpy(), slot=0)
+            for k, p in enumerate(mine):
+                if k + 1 < len(mine):
+                    a, b = pairs[mine[k + 1]]
+                    ctx.upload_pair(a.numpy(), b.numpy(), slot=(k + 1) % 2, select=False)
+                ctx.select_pair(k % 2)
+                if ev is not None and k == 0:
+                    ev[0].record()
+                ctx.run()
+                if ev is not None and k == 0:
+                    ev[1].record()
+                results[p] = ctx.fetch()
 
-    def step(k=None):
-        if k is not None:
-            ev[k][0].record()
-        ctx.run()
-        if k is not None:
-            ev[k][1].record()
-        o, j = gather.gather(out_t, ij_t)
-        if rank == 0:
-            host_out.copy_(o, non_blocking=True)
-            host_ij.copy_(j, non_blocking=True)
-            torch.cuda.current_stream().synchronize()      # results are on the host: end of the seam
-
-    def fence():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        step()
-    fence()
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        step(k)
-    fence()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        te = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(te, op=dist.ReduceOp.MAX)
-        elapsed = float(te.item())
-    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev])) if args.steps else float('nan')
-
-    if rank == 0:
-        res = host_out.numpy().copy()
-        res_ij = host_ij.numpy().copy()
-        ms_per_step = elapsed / args.steps * 1e3
-        value = n_total / (elapsed / args.steps)
-        launches = max(info['launches'], 1)
-        kern_s = kern_ms * 1e-3
-        hbm_achieved = info['hbm_bytes'] / kern_s / 1e9
-        mfma_achieved = 2.0 * info['macs'] / kern_s / 1e12
-        # HBM traffic per launch from the committed PMC profile (rocprofv3 cannot run inside this process);
-        # only quoted when the profile was collected on this very workload
-        traffic, traffic_note = None, 'no PMC profile for this workload under profiles/'
-        try:
-            with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'traffic.json')) as fh:
-                tj = json.load(fh)
-            if tj.get('workload') == {'size': args.size, 'grid': args.grid, 'angles': args.angles,
-                                      'border': args.border if args.border == 'mixed' else int(args.border),
-                                      'img_size': s}:
-                traffic = tj['hbm_bytes_per_launch'] * tj['launches_per_step'] / launches
-                traffic_note = 'bytes per launch, PMC FETCH_SIZE x2 + WRITE_SIZE (profiles/traffic.json): ' + tj['note']
-        except (OSError, ValueError, KeyError):
-            pass
-        line = {
-            'metric': 'PM grid-points/sec (10000x10000 px pair, 34px template)',
-            'value': value, 'unit': 'grid-points/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-            'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': args.scaling, 'vs_baseline': None,
-            'dtype': 'u8', 'data': 'synthetic',
-            'config': {'workload': '%dx%d grid per GPU on one synthetic %dx%d uint8 pair, template %d px, '
-                                   '%d angles [%d..%d], border %s, flags hes_norm'
-                                   % (args.grid, args.grid, H, W, s, len(angles), angles[0], angles[-1], border),
-                       'points_total': int(n_total), 'points_per_gpu': int(len(idx)),
-                       'parallelism': 'points sharded over %d GPU(s), RCCL gather to rank 0' % world},
-            'roofline': {
-                # the sweep runs on v_mfma_i32_16x16x64_i8: the matrix cores are the roofline that bounds it
-                'bound': 'mfma', 'achieved': mfma_achieved, 'peak': MFMA_I8_PEAK_TOPS, 'unit': 'TFLOP/s',
-                'frac': mfma_achieved / MFMA_I8_PEAK_TOPS, 'traffic': traffic, 'traffic_note': traffic_note,
-                # one template, two band heights: <S,4> for the one- and three-per-CU classes, <S,8> for two per CU
-                'kernel': 'sid::pm_kernel_mfma<%d,4> + <%d,8>' % ((s, s) if s in (34, 35) else (0, 0)), 'launches_per_step': launches,
-                'kernel_ms_per_step': kern_ms, 'avg_launch_ms': kern_ms / launches,
-                'algorithmic_macs_per_step': info['macs'], 'algorithmic_bytes_per_step': info['hbm_bytes'],
-                'note': 'achieved = 2 x algorithmic MACs (sum K*Rh*Rw*s*s, integer ops) / kernel time measured with HIP '
-                        'events on the launch stream; the MFMA tiles carry 64 window columns for a 34-column template '
-                        '(47 % padding) and a 16th all-ones template slot, so the matrix pipe itself is busier than '
-                        'this figure (see DESIGN.md); VALU work around the MFMAs is the practical limiter',
-                'hbm': {'achieved': hbm_achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': hbm_achieved / HBM_PEAK_GBS,
-                        'note': '~10^4 MAC per HBM byte: not HBM-bound; algorithmic bytes = both images once at most'},
-            },
-            'setup_s': {'generate_and_upload_pair': t_gen},
-        }
-        # ---- parity spot check against the oracle (checker only; not timed) ----
+    run = Run()
+    elapsed, kern_ms = timed_steps(torch, dist, world, run, args.steps, args.warmup)
+    line = None
+    # parity: up to three pairs of this rank against the oracle on a subsample (checker only)
+    ok, checked = True, 0
+    if args.check > 0 and mine:
         from oracle import c_oracle
         c_oracle.build()
-        nthreads = host_cores()
-        if args.check > 0:
-            sel = np.random.default_rng(0).choice(n_total, size=min(args.check, n_total), replace=False)
-            exp, exp_ij = c_oracle.pm_batch(img1, img2, g['c1'][sel], g['r1'][sel], g['c2fg'][sel], g['r2fg'][sel],
-                                            g['border'][sel], s, 0.0, angles, rot=rot, nthreads=nthreads)
-            ok = (np.array_equal(res_ij[sel], exp_ij) and np.array_equal(res[sel, :4], exp[:, :4], equal_nan=True)
-                  and np.allclose(res[sel, 4], exp[:, 4], rtol=1e-5, atol=1e-5, equal_nan=True))
-            line['parity_check'] = {'points': int(len(sel)), 'ok': bool(ok)}
-            if not ok:
-                print(json.dumps(line))
-                raise SystemExit('PARITY FAILURE against the CPU oracle - the number above is invalid')
-        if not args.no_cpu_baseline:
-            # bounded sample: every stride-th point of the same grid, sized for ~15 s of wall time
-            cal = np.arange(0, n_total, max(1, n_total // (8 * nthreads)))[:8 * nthreads]
-            tc = time.perf_counter()
-            c_oracle.pm_batch(img1, img2, g['c1'][cal], g['r1'][cal], g['c2fg'][cal], g['r2fg'][cal],
-                              g['border'][cal], s, 0.0, angles, rot=rot, nthreads=nthreads)
-            rate = len(cal) / (time.perf_counter() - tc)
-            n_s = args.cpu_sample or int(min(n_total, max(len(cal), rate * 15.0)))
-            smp = np.linspace(0, n_total - 1, n_s).astype(np.int64)
-            tc = time.perf_counter()
-            c_oracle.pm_batch(img1, img2, g['c1'][smp], g['r1'][smp], g['c2fg'][smp], g['r2fg'][smp],
-                              g['border'][smp], s, 0.0, angles, rot=rot, nthreads=nthreads)
-            dt = time.perf_counter() - tc
-            line['cpu_baseline'] = {
-                'value': n_s / dt, 'unit': 'grid-points/s', 'cores': nthreads, 'kind': 'port',
-                'sample': '%d evenly spaced points of the same %d-point grid, same pair/angles/borders, '
-                          'oracle/pm_oracle.c (restated CPU pmlib, exact-integer NCC; not cv2) with OpenMP '
-                          'over points, %.1f s' % (n_s, n_total, dt)}
+        sel = np.random.default_rng(1).choice(n_pts, size=min(args.check, n_pts), replace=False)
+        for p in mine[:3]:
+            a, b = pairs[p]
+            exp, exp_ij = c_oracle.pm_batch(a.numpy(), b.numpy(), g['c1'][sel], g['r1'][sel], g['c2fg'][sel],
+                                            g['r2fg'][sel], g['border'][sel], s, 0.0, angles, rot=rot, nthreads=host_cores())
+            got, got_ij = results[p]
+            ok = ok and (np.array_equal(got_ij[sel], exp_ij) and np.array_equal(got[sel, :4], exp[:, :4], equal_nan=True)
+                         and np.allclose(got[sel, 4], exp[:, 4], rtol=1e-5, atol=1e-5, equal_nan=True))
+            checked += 1
+    if world > 1:
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        ok = bool(flag.item())
+    ctx.close()
+    if rank == 0:
+        total_pts = n_pts * args.pairs
+        line = {
+            'metric': 'PM grid-points/sec (10000x10000 px pair, 34px template)',
+            'value': total_pts / (elapsed / args.steps), 'unit': 'grid-points/s', 'n_gpus': world, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'strong',
+            'vs_baseline': None, 'dtype': 'u8', 'data': 'synthetic',
+            'config': {'workload': 'batch of %d synthetic %dx%d uint8 pairs streamed from pinned host memory, %dx%d grid '
+                                   'per pair, template %d px, %d angles, border %s; uploads overlap the kernels of the '
+                                   'previous pair (two device slots per GPU)' % (args.pairs, H, W, args.grid, args.grid, s,
+                                                                                len(angles), border),
+                       'pairs_total': args.pairs, 'pairs_per_gpu': len(mine), 'points_per_pair': int(n_pts),
+                       'ms_per_pair': elapsed / args.steps * 1e3 / max(len(mine), 1),
+                       'parallelism': 'pairs dealt round-robin to %d GPU(s); no collective on the data path' % world},
+            'roofline': {'bound': 'mfma', 'achieved': 2.0 * info['macs'] / (kern_ms * 1e-3) / 1e12, 'peak': MFMA_I8_PEAK_TOPS,
+                         'unit': 'TFLOP/s', 'frac': 2.0 * info['macs'] / (kern_ms * 1e-3) / 1e12 / MFMA_I8_PEAK_TOPS,
+                         'traffic': None, 'kernel_ms_per_pair': kern_ms,
+                         'note': 'kernels of the first pair of every step (HIP events on the launch stream); the step time '
+                                 'also holds the 200 MB H2D upload of every pair, overlapped'},
+            'parity_check': {'pairs_checked_per_rank': checked, 'ok': ok},
+            'setup_s': {'generate_and_pin_pairs': t_gen},
+        }
+        if not ok:
+            print(json.dumps(line))
+            raise SystemExit('PARITY FAILURE against the CPU oracle - the number above is invalid')
+    return line
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    args = parse_args(argv)
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    if args.gpus > 1 and 'RANK' not in os.environ:
+        raise SystemExit(spawn_ranks(args, argv))        # before any torch / GPU call in this process
+    if world != args.gpus:
+        raise SystemExit('WORLD_SIZE=%d does not match --gpus %d' % (world, args.gpus))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+
+    import torch
+    import torch.distributed as dist
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)')
+    # N ranks on fewer devices (functional dry runs on a 1-GPU box) share devices round-robin
+    local_dev = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(local_dev)
+    dev = torch.device('cuda', local_dev)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        shared = torch.cuda.device_count() < world
+        # RCCL cannot put two ranks on one device: the dry run on a smaller box uses gloo for the collectives
+        dist.init_process_group('gloo' if shared else 'nccl', **({} if shared else {'device_id': dev}))
+    fn = stream_mode if args.mode == 'stream' else grid_mode
+    line = fn(args, torch, dist, dev, world, rank, local_dev)
+    if rank == 0 and line is not None:
+        if world > 1 and dist.get_backend() == 'gloo':
+            line['config']['parallelism'] += ' [DRY RUN: %d ranks share %d device(s), gloo collectives]' % (
+                world, torch.cuda.device_count())
         print(json.dumps(line))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
-    ctx.close()
 
 
 if __name__ == '__main__':

@@ -40,6 +40,8 @@ def lib():
         L.sid_oracle_pm_batch.argtypes = (
             [_u8p, C.c_int64, C.c_int64, C.c_int64] * 2 + [_f64p] * 5 +
             [C.c_int64, C.c_int, C.c_double, _f64p, _f64p, C.c_int, C.c_uint, C.c_int, _f64p, _i32p])
+        L.sid_oracle_pm_batch_gap.restype = C.c_int
+        L.sid_oracle_pm_batch_gap.argtypes = L.sid_oracle_pm_batch.argtypes + [_f32p]
         L.sid_oracle_max_threads.restype = C.c_int
         _lib = L
     return _lib
@@ -85,8 +87,9 @@ def hessian(ccm, flags=1):
 
 
 def pm_batch(img1, img2, c1, r1, c2fg, r2fg, border, img_size, alpha0, angles, rot=None, flags=1,
-             nthreads=1):
-    """(N,5) float64 + (N,3) int32, same contract as oracle.pm_oracle.pm_batch."""
+             nthreads=1, want_gap=False):
+    """(N,5) float64 + (N,3) int32, same contract as oracle.pm_oracle.pm_batch.  want_gap: also the float32 [N]
+    distance between the peak and the second-largest NCC value of every point (cv2-flip exposure)."""
     img1, p1 = _u8(img1)
     img2, p2 = _u8(img2)
     vecs = [_f64(v) for v in (c1, r1, c2fg, r2fg, border)]
@@ -98,14 +101,16 @@ def pm_batch(img1, img2, c1, r1, c2fg, r2fg, border, img_size, alpha0, angles, r
         prot = None
     out = np.empty((n, 5), dtype=np.float64)
     ij = np.empty((n, 3), dtype=np.int32)
-    rc = lib().sid_oracle_pm_batch(p1, img1.shape[0], img1.shape[1], img1.strides[0],
-                                   p2, img2.shape[0], img2.shape[1], img2.strides[0],
-                                   *[v[1] for v in vecs], n, int(img_size), float(alpha0), pa, prot,
-                                   len(angles), int(flags), int(nthreads),
-                                   out.ctypes.data_as(_f64p), ij.ctypes.data_as(_i32p))
+    gap = np.empty(n, dtype=np.float32) if want_gap else None
+    rc = lib().sid_oracle_pm_batch_gap(p1, img1.shape[0], img1.shape[1], img1.strides[0],
+                                       p2, img2.shape[0], img2.shape[1], img2.strides[0],
+                                       *[v[1] for v in vecs], n, int(img_size), float(alpha0), pa, prot,
+                                       len(angles), int(flags), int(nthreads),
+                                       out.ctypes.data_as(_f64p), ij.ctypes.data_as(_i32p),
+                                       gap.ctypes.data_as(_f32p) if want_gap else None)
     if rc:
         raise ValueError('sid_oracle_pm_batch failed: %d' % rc)
-    return out, ij
+    return (out, ij, gap) if want_gap else (out, ij)
 
 
 def max_threads():

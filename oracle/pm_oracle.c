@@ -339,7 +339,7 @@ static void use_mcc_ws(sid_ws *w, const uint8_t *img1, int64_t rows1, int64_t co
                        const uint8_t *img2, int64_t rows2, int64_t cols2, int64_t stride2,
                        double c1, double r1, double c2fg, double r2fg, double border,
                        int s, const double *angles, const double *rot, int n_angles,
-                       unsigned flags, double *out5, int32_t *ij3)
+                       unsigned flags, double *out5, int32_t *ij3, float *gap)
 {
     const int hws = (int)((double)s / 2.);
     /* Python int(): truncation toward zero (pmlib.py:201-202) */
@@ -347,6 +347,7 @@ static void use_mcc_ws(sid_ws *w, const uint8_t *img1, int64_t rows1, int64_t co
     const int64_t c0 = (int64_t)(c2fg - hws - border), c1e = (int64_t)(c2fg + hws + border + 1);
     for (int k = 0; k < 5; ++k) out5[k] = NAN;
     if (ij3) { ij3[0] = ij3[1] = ij3[2] = -1; }
+    if (gap) *gap = NAN;
     if (!(r0 >= 0 && c0 >= 0 && r1e <= rows2 && c1e <= cols2 && r1e - r0 >= s + 1 && c1e - c0 >= s + 1)) return;
     const int wh = (int)(r1e - r0), ww = (int)(c1e - c0);
     const int rh = wh - s + 1, rw = ww - s + 1;
@@ -354,6 +355,7 @@ static void use_mcc_ws(sid_ws *w, const uint8_t *img1, int64_t rows1, int64_t co
     const uint8_t *win = img2 + r0 * stride2 + c0;
 
     float best_r = -INFINITY;
+    float top1 = -INFINITY, top2 = -INFINITY;                   /* two largest values over all angles and placements */
     int best_k = -1, best_idx = -1;
     for (int k = 0; k < n_angles; ++k) {
         if (sid_oracle_get_template(img1, rows1, cols1, stride1, c1, r1, rot + 4 * k, s, w->tmpl) == 0)
@@ -362,6 +364,11 @@ static void use_mcc_ws(sid_ws *w, const uint8_t *img1, int64_t rows1, int64_t co
                             w->si + (size_t)rh * rw, k > 0);
         int idx = 0; float mx = w->res[0];
         for (int p = 1; p < rh * rw; ++p) if (w->res[p] > mx) { mx = w->res[p]; idx = p; }  /* first max */
+        if (gap)
+            for (int p = 0; p < rh * rw; ++p) {
+                const float v = w->res[p];
+                if (v > top1) { top2 = top1; top1 = v; } else if (v > top2) top2 = v;
+            }
         if (mx > best_r) {                                      /* strict (pmlib.py:160) */
             best_r = mx; best_k = k; best_idx = idx;
             float *t = w->best; w->best = w->res; w->res = t;
@@ -380,6 +387,9 @@ static void use_mcc_ws(sid_ws *w, const uint8_t *img1, int64_t rows1, int64_t co
     out5[0] = c2fg + dc; out5[1] = r2fg + dr; out5[2] = angles[best_k];
     out5[3] = (double)rr; out5[4] = (double)best_h;
     if (ij3) { ij3[0] = iy; ij3[1] = ix; ij3[2] = best_k; }
+    /* distance of the peak to the runner-up anywhere in the (angle, row, col) volume: a float32/DFT matcher
+     * (cv2) could pick the other one when this is below its noise (~1e-6) */
+    if (gap) *gap = top1 - top2;
 }
 
 /* rot may be NULL: then cos/sin/tcT are derived here with libm (NumPy's own cos/sin can
@@ -399,12 +409,31 @@ static double *make_rot(const double *angles, int n_angles, double alpha0, int s
     return rot;
 }
 
+int sid_oracle_pm_batch_gap(const uint8_t *img1, int64_t rows1, int64_t cols1, int64_t stride1,
+                            const uint8_t *img2, int64_t rows2, int64_t cols2, int64_t stride2,
+                            const double *c1, const double *r1, const double *c2fg, const double *r2fg,
+                            const double *border, int64_t n, int img_size, double alpha0,
+                            const double *angles, const double *rot_in, int n_angles, unsigned flags,
+                            int nthreads, double *out, int32_t *out_ij, float *gap);
+
 int sid_oracle_pm_batch(const uint8_t *img1, int64_t rows1, int64_t cols1, int64_t stride1,
                         const uint8_t *img2, int64_t rows2, int64_t cols2, int64_t stride2,
                         const double *c1, const double *r1, const double *c2fg, const double *r2fg,
                         const double *border, int64_t n, int img_size, double alpha0,
                         const double *angles, const double *rot_in, int n_angles, unsigned flags,
                         int nthreads, double *out, int32_t *out_ij)
+{
+    return sid_oracle_pm_batch_gap(img1, rows1, cols1, stride1, img2, rows2, cols2, stride2, c1, r1, c2fg, r2fg, border, n,
+                                   img_size, alpha0, angles, rot_in, n_angles, flags, nthreads, out, out_ij, NULL);
+}
+
+/* same, plus gap[n] = peak value minus the second-largest NCC value of the point (NULL: not computed) */
+int sid_oracle_pm_batch_gap(const uint8_t *img1, int64_t rows1, int64_t cols1, int64_t stride1,
+                            const uint8_t *img2, int64_t rows2, int64_t cols2, int64_t stride2,
+                            const double *c1, const double *r1, const double *c2fg, const double *r2fg,
+                            const double *border, int64_t n, int img_size, double alpha0,
+                            const double *angles, const double *rot_in, int n_angles, unsigned flags,
+                            int nthreads, double *out, int32_t *out_ij, float *gap)
 {
     if (n_angles < 1 || img_size < 2 || n < 0) return -1;
     double *rot = make_rot(angles, n_angles, alpha0, img_size, rot_in);
@@ -420,7 +449,7 @@ int sid_oracle_pm_batch(const uint8_t *img1, int64_t rows1, int64_t cols1, int64
         for (int64_t i = 0; i < n; ++i)
             use_mcc_ws(&w, img1, rows1, cols1, stride1, img2, rows2, cols2, stride2,
                        c1[i], r1[i], c2fg[i], r2fg[i], border[i], img_size, angles, rot, n_angles,
-                       flags, out + 5 * i, out_ij ? out_ij + 3 * i : NULL);
+                       flags, out + 5 * i, out_ij ? out_ij + 3 * i : NULL, gap ? gap + i : NULL);
         ws_free(&w);
     }
     free(rot);

@@ -182,12 +182,17 @@ class PMContext(object):
     def set_stream(self, stream_handle):
         _check(lib().sid_pm_set_stream(self._h, C.c_void_p(int(stream_handle) if stream_handle else 0)))
 
-    def upload_pair(self, img1, img2, slot=0):
+    def upload_pair(self, img1, img2, slot=0, select=True):
+        """Copy a host pair into device slot 0/1 and (select=True) make it the pair the next run matches.
+        Streaming code that prefetches pair k+1 while pair k runs passes select=False and switches with
+        select_pair (the C call alone only selects a slot when no other owned slot is current)."""
         img1, img2 = _u8(img1), _u8(img2)
-        self._keep = [img1, img2]                     # async copy: keep the host buffers alive
+        self._keep = (self._keep + [img1, img2])[-4:]  # async copies: keep the host buffers of both slots alive
         _check(lib().sid_pm_upload_pair(self._h, int(slot),
                                         _p(img1, _u8p), img1.shape[0], img1.shape[1], img1.strides[0],
                                         _p(img2, _u8p), img2.shape[0], img2.shape[1], img2.strides[0]))
+        if select:
+            self.select_pair(slot)
 
     def select_pair(self, slot):
         _check(lib().sid_pm_select_pair(self._h, int(slot)))

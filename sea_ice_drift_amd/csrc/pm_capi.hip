@@ -71,11 +71,8 @@ struct DevBuf {
 
 }  // namespace
 
-enum KernelKind { KERNEL_MFMA = 0, KERNEL_DOT4 = 1 };
-
 struct sid_pm_ctx {
     int device = 0;
-    int kernel = KERNEL_MFMA;           // SID_PM_KERNEL=dot4 selects the VALU kernel (A/B runs, tests)
     hipStream_t stream = nullptr;
     // image pairs: two owned slots + one borrowed binding
     DevBuf<uint8_t> own[2][2];
@@ -88,13 +85,18 @@ struct sid_pm_ctx {
     hipStream_t copy_stream = nullptr;
     hipEvent_t slot_ready[2] = {nullptr, nullptr}, slot_done[2] = {nullptr, nullptr};
     bool ready_rec[2] = {false, false}, done_rec[2] = {false, false};
-    // resident points
-    DevBuf<double> vec;                 // 5 * n
-    DevBuf<int32_t> order;
-    DevBuf<double> angles, rot;
-    DevBuf<uint16_t> samp;              // sampling table of the MFMA kernel (make_samp)
-    bool have_samp = false;             // SID_PM_NO_SAMP_TABLE=1 keeps the on-the-fly sampling (A/B runs, tests)
+    // resident points: one device arena (a single upload per set_points) carved into the vectors below
+    DevBuf<uint8_t> arena;
+    double *d_vec = nullptr;            // 5 * n
+    int32_t *d_order = nullptr;
+    double *d_angles = nullptr, *d_rot = nullptr;
+    uint16_t *d_samp = nullptr;         // sampling table of the kernel (make_samp)
+    bool have_samp = false;             // SID_PM_NO_SAMP_TABLE=1 keeps the on-the-fly sampling (tests of the general sampler)
     int samp_nflag = 0;
+    // host copies of what the classification needs: the launch classes depend on the shape of image 2, so a
+    // pair of another shape (select_pair / bind_pair / upload_pair after set_points) is re-classified at run()
+    std::vector<double> h_c2fg, h_r2fg, h_border;
+    int64_t cls_rows2 = -1, cls_cols2 = -1;
     DevBuf<double> out;
     DevBuf<int32_t> out_ij;
     double *user_out = nullptr;         // caller-owned result arrays (bind_results)
@@ -200,35 +202,34 @@ int check_images(const Image &a, const Image &b)
     return SID_PM_OK;
 }
 
-bool size_supported(int kernel, int s)
-{
-    return kernel == KERNEL_DOT4 ? sid::img_size_supported(s) : sid::mfma_img_size_supported(s);
-}
-
-// paired: the MFMA kernel's two-row-phase sweep for angle sets of at most kPairedMaxAngles (pm_kernel.h)
-bool use_paired(int kernel, int K)
+// paired: the kernel's two-row-phase sweep for angle sets of at most kPairedMaxAngles (pm_kernel.h)
+bool use_paired(int K)
 {
     static const bool off = getenv("SID_PM_NO_PAIRED") != nullptr;                            // A/B runs
-    return kernel == KERNEL_MFMA && K <= sid::kPairedMaxAngles && !off;
+    return K <= sid::kPairedMaxAngles && !off;
 }
 
-int lds_need(int kernel, int wh, int ww, int s, int K, int band = 4)
+// row-pair kernel (pm_kernel_rp.inc): template sides 34 / 35 with more angles than the paired sweep takes
+bool use_rp(int s, int K)
 {
-    return kernel == KERNEL_DOT4 ? sid::lds_layout(wh, ww, s, K).total
-                                 : sid::mfma_lds_layout(wh, ww, s, band, use_paired(kernel, K) && band == 4).total;
+    static const bool off = getenv("SID_PM_NO_RP") != nullptr;                                // A/B runs: classic sweep
+    return sid::rp_size_supported(s) && !use_paired(K) && !off;
 }
 
-int check_sweep(int kernel, int img_size, const double *angles, int n_angles, uint32_t flags)
+int lds_need(int wh, int ww, int s, int K, int band = 4)
+{
+    if (use_rp(s, K)) return sid::rp_lds_layout(wh, ww, s).total;
+    return sid::mfma_lds_layout(wh, ww, s, band, use_paired(K) && band == 4).total;
+}
+
+int check_sweep(int img_size, const double *angles, int n_angles, uint32_t flags)
 {
     if (!angles || n_angles < 1)
         return fail(SID_PM_ERR_ARG, "angles must hold at least one angle (the reference's loop, pmlib.py:150, "
                                     "leaves best_result undefined for an empty list)");
     if (n_angles > sid::kMaxAngles) return fail(SID_PM_ERR_UNSUPPORTED, "more than %d angles", sid::kMaxAngles);
-    if (!size_supported(kernel, img_size))
-        return fail(SID_PM_ERR_UNSUPPORTED, "img_size=%d: the %s kernel supports %s", img_size,
-                    kernel == KERNEL_DOT4 ? "dot4" : "MFMA", kernel == KERNEL_DOT4 ? "33..36" : "2..49");
-    if ((flags & SID_PM_HES_SMTH) && kernel == KERNEL_DOT4)
-        return fail(SID_PM_ERR_UNSUPPORTED, "hes_smth=True is implemented by the MFMA kernel only");
+    if (!sid::mfma_img_size_supported(img_size))
+        return fail(SID_PM_ERR_UNSUPPORTED, "img_size=%d: the kernel supports 2..49", img_size);
     if (flags & ~(SID_PM_HES_NORM | SID_PM_HES_SMTH | SID_PM_MCC_NORM)) return fail(SID_PM_ERR_ARG, "unknown flag bits");
     return SID_PM_OK;
 }
@@ -250,12 +251,113 @@ int fill_args(sid_pm_ctx *ctx, sid::PMArgs &A)
     A.img1 = ctx->cur[0].ptr; A.rows1 = ctx->cur[0].rows; A.cols1 = ctx->cur[0].cols; A.stride1 = ctx->cur[0].stride;
     A.img2 = ctx->cur[1].ptr; A.rows2 = ctx->cur[1].rows; A.cols2 = ctx->cur[1].cols; A.stride2 = ctx->cur[1].stride;
     const int64_t n = ctx->n;
-    A.c1 = ctx->vec.p; A.r1 = ctx->vec.p + n; A.c2fg = ctx->vec.p + 2 * n; A.r2fg = ctx->vec.p + 3 * n;
-    A.border = ctx->vec.p + 4 * n;
+    A.c1 = ctx->d_vec; A.r1 = ctx->d_vec + n; A.c2fg = ctx->d_vec + 2 * n; A.r2fg = ctx->d_vec + 3 * n;
+    A.border = ctx->d_vec + 4 * n;
     A.img_size = ctx->img_size; A.n_angles = ctx->n_angles; A.flags = ctx->flags;
-    A.angles = ctx->angles.p; A.rot = ctx->rot.p; A.samp = ctx->have_samp ? ctx->samp.p : nullptr; A.samp_nflag = ctx->samp_nflag;
+    A.angles = ctx->d_angles; A.rot = ctx->d_rot; A.samp = ctx->have_samp ? ctx->d_samp : nullptr; A.samp_nflag = ctx->samp_nflag;
     A.out = ctx->user_out ? ctx->user_out : ctx->out.p;
     A.out_ij = ctx->user_out ? ctx->user_ij : ctx->out_ij.p;
+    return SID_PM_OK;
+}
+
+// Launch classes of the resident points for the pair that is current now: LDS footprint -> residency class
+// (workgroups per CU) -> one launch per (class, band), XCD-aware order inside.  The footprint depends on the shape
+// of image 2 (a window outside the image is a NaN point and gets the minimal footprint), so this runs in
+// set_points and again in run() whenever the current pair's image 2 has another shape.  Uploads `order`.
+int classify_points(sid_pm_ctx *ctx)
+{
+    const int64_t n = ctx->n;
+    const int s = ctx->img_size, K = ctx->n_angles;
+    const int64_t rows2 = ctx->cur[1].rows, cols2 = ctx->cur[1].cols;
+    const double *c2fg = ctx->h_c2fg.data(), *r2fg = ctx->h_r2fg.data(), *border = ctx->h_border.data();
+    struct P { int idx; int lds; int cls; double work; int band = 4; bool force1 = false, force2 = false; };
+    static const bool no_band8 = getenv("SID_PM_NO_BAND8") != nullptr;                      // A/B runs
+    const bool band8_ok = sid::mfma_band8_supported(s) && !no_band8 && !use_paired(K) && !use_rp(s, K);
+    std::vector<P> pts((size_t)n);
+    const int lds_min = lds_need(s + 1, s + 1, s, K);
+    double macs = 0, bytes = 0, valid = 0;
+    int lds_max = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        int wh = 0, ww = 0;
+        P p; p.idx = (int)i; p.lds = lds_min; p.cls = 0; p.work = 0.0;
+        if (window_dims(c2fg[i], r2fg[i], border[i], s, rows2, cols2, wh, ww)) {
+            const int need = lds_need(wh, ww, s, K);
+            if (need > sid::max_lds_bytes())
+                return fail(SID_PM_ERR_UNSUPPORTED, "point %lld: search window %dx%d needs %d bytes of LDS (> %d)",
+                            (long long)i, wh, ww, need, sid::max_lds_bytes());
+            p.lds = need;
+            // the two-per-CU class runs the 8-row-band kernel (two wavefronts per SIMD leave it 256 VGPRs); its
+            // window carries 4 more zero rows, and a point that then no longer fits twice stays with band 4
+            if (band8_ok && blocks_per_cu(need) == 2) {
+                const int need8 = lds_need(wh, ww, s, K, 8);
+                if (blocks_per_cu(need8) >= 2) { p.lds = need8; p.band = 8; p.force2 = true; }
+                else p.force1 = true;
+            }
+            const double rh = wh - s + 1, rw = ww - s + 1;
+            p.work = rh * rw;
+            macs += (double)K * rh * rw * s * s;
+            // window + bounding box of the rotated template + 5 inputs + outputs
+            bytes += (double)wh * ww + 51.0 * 51.0 + 40.0 + 52.0;
+            valid += 1;
+        }
+        p.cls = p.force1 ? 1 : (p.force2 ? 2 : std::min(8, blocks_per_cu(p.lds)));
+        lds_max = std::max(lds_max, p.lds);
+        pts[(size_t)i] = p;
+    }
+    std::sort(pts.begin(), pts.end(), [](const P &a, const P &b) {
+        if (a.cls != b.cls) return a.cls < b.cls;                 // biggest footprints first
+        if (a.band != b.band) return a.band < b.band;             // one launch per (class, band)
+        if (a.work != b.work) return a.work > b.work;             // then longest first
+        return a.idx < b.idx;
+    });
+    // XCD-aware launch order.  Workgroup j of a launch runs on XCD j mod 8 and every XCD has its own L2, so
+    // within a run of points of equal class and work (= equal border: the order there is the caller's, i.e.
+    // spatial for a grid) the run is cut into 8 contiguous chunks and chunk c goes to the XCD of slot
+    // (start + c) mod 8: neighbouring points - whose search windows overlap - meet in the same L2.
+    // Runs keep their place in the launch (long first), so the load balance across XCDs is unchanged.
+    static const bool no_xcd = getenv("SID_PM_NO_XCD_ORDER") != nullptr;                         // A/B runs
+    if (!no_xcd) {
+        constexpr int kXcd = 8;
+        std::vector<P> tmp;
+        for (int64_t a = 0; a < n;) {
+            int64_t b = a + 1;
+            while (b < n && pts[(size_t)b].cls == pts[(size_t)a].cls && pts[(size_t)b].band == pts[(size_t)a].band &&
+                   pts[(size_t)b].work == pts[(size_t)a].work) ++b;
+            const int64_t L = b - a, m = (L + kXcd - 1) / kXcd;
+            if (L >= 4 * kXcd) {
+                tmp.assign(pts.begin() + a, pts.begin() + b);
+                int64_t w = a;
+                for (int64_t p = 0; p < m; ++p)                       // slot t = p * 8 + c takes element c * m + p
+                    for (int c = 0; c < kXcd; ++c) {
+                        const int64_t e = (int64_t)c * m + p;
+                        if (e < L) pts[(size_t)w++] = tmp[(size_t)e];
+                    }
+            }
+            a = b;
+        }
+    }
+    std::vector<int32_t> order((size_t)n);
+    ctx->buckets.clear();
+    for (int64_t i = 0; i < n; ++i) {
+        order[(size_t)i] = pts[(size_t)i].idx;
+        if (ctx->buckets.empty() || pts[(size_t)i].cls != pts[(size_t)(i - 1)].cls || pts[(size_t)i].band != pts[(size_t)(i - 1)].band)
+            ctx->buckets.push_back(Bucket{(int)i, 0, 0, pts[(size_t)i].band});
+        Bucket &b = ctx->buckets.back();
+        b.count += 1;
+        b.lds = std::max(b.lds, pts[(size_t)i].lds);
+    }
+    if (n > 0) {
+        HIP_TRY(hipMemcpyAsync(ctx->d_order, order.data(), sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));               // `order` is a local
+    }
+    ctx->cls_rows2 = rows2; ctx->cls_cols2 = cols2;
+    const double img_bytes = (double)ctx->cur[0].rows * ctx->cur[0].cols + (double)rows2 * cols2;
+    ctx->info[0] = (double)ctx->buckets.size();
+    ctx->info[1] = valid;
+    ctx->info[2] = macs;
+    ctx->info[3] = std::min(bytes, img_bytes + 92.0 * valid);
+    ctx->info[4] = (double)lds_max;
+    ctx->info[5] = 0;
     return SID_PM_OK;
 }
 
@@ -313,8 +415,6 @@ SID_EXPORT int sid_pm_create(int device, sid_pm_ctx **out)
         }
         if (e != hipSuccess) { sid_pm_destroy(ctx); return fail(SID_PM_ERR_HIP, "stream/event creation failed: %s", hipGetErrorString(e)); }
     }
-    const char *kk = getenv("SID_PM_KERNEL");
-    if (kk && strcmp(kk, "dot4") == 0) ctx->kernel = KERNEL_DOT4;
     *out = ctx;
     return SID_PM_OK;
 }
@@ -330,7 +430,7 @@ SID_EXPORT void sid_pm_destroy(sid_pm_ctx *ctx)
         if (ctx->slot_done[k]) (void)hipEventDestroy(ctx->slot_done[k]);
     }
     for (auto &pair : ctx->own) for (auto &b : pair) b.release();
-    ctx->vec.release(); ctx->order.release(); ctx->angles.release(); ctx->rot.release(); ctx->samp.release();
+    ctx->arena.release();
     ctx->out.release(); ctx->out_ij.release();
     delete ctx;
 }
@@ -370,7 +470,9 @@ SID_EXPORT int sid_pm_upload_pair(sid_pm_ctx *ctx, int slot,
     }
     HIP_TRY(hipEventRecord(ctx->slot_ready[slot], ctx->copy_stream));
     ctx->ready_rec[slot] = true;
-    if (!ctx->have_pair || ctx->cur_slot == slot) {       // first pair, or refresh of the selected slot
+    // first pair, refresh of the selected slot, or a borrowed binding is current (an upload replaces it: the
+    // caller who streams through both slots switches with select_pair)
+    if (!ctx->have_pair || ctx->cur_slot == slot || ctx->cur_slot < 0) {
         ctx->cur[0] = ctx->slot_img[slot][0]; ctx->cur[1] = ctx->slot_img[slot][1];
         ctx->have_pair = true; ctx->cur_slot = slot;
     }
@@ -406,129 +508,47 @@ SID_EXPORT int sid_pm_set_points(sid_pm_ctx *ctx, const double *c1, const double
     if (!ctx) return fail(SID_PM_ERR_ARG, "null ctx");
     if (n < 0 || n > 0x7fffffff / 8) return fail(SID_PM_ERR_ARG, "bad point count");
     if (n > 0 && (!c1 || !r1 || !c2fg || !r2fg || !border)) return fail(SID_PM_ERR_ARG, "null point vector");
-    if (int rc = check_sweep(ctx->kernel, img_size, angles, n_angles, flags)) return rc;
+    if (int rc = check_sweep(img_size, angles, n_angles, flags)) return rc;
     if (!ctx->have_pair) return fail(SID_PM_ERR_STATE, "set_points needs an image pair (upload_pair/bind_pair first)");
     Guard g(ctx->device);
     const int s = img_size, K = n_angles;
-    const int64_t rows2 = ctx->cur[1].rows, cols2 = ctx->cur[1].cols;
-
-    // classify: LDS footprint -> residency class (blocks per CU), work for ordering
-    struct P { int idx; int lds; int cls; double work; int band = 4; bool force1 = false, force2 = false; };
-    static const bool no_band8 = getenv("SID_PM_NO_BAND8") != nullptr;                      // A/B runs
-    const bool band8_ok = ctx->kernel == KERNEL_MFMA && sid::mfma_band8_supported(s) && !no_band8 && !use_paired(ctx->kernel, K);
-    std::vector<P> pts((size_t)n);
-    const int lds_min = lds_need(ctx->kernel, s + 1, s + 1, s, K);
-    double macs = 0, bytes = 0, valid = 0;
-    int lds_max = 0;
-    for (int64_t i = 0; i < n; ++i) {
-        int wh = 0, ww = 0;
-        P p; p.idx = (int)i; p.lds = lds_min; p.cls = 0; p.work = 0.0;
-        if (window_dims(c2fg[i], r2fg[i], border[i], s, rows2, cols2, wh, ww)) {
-            const int need = lds_need(ctx->kernel, wh, ww, s, K);
-            if (need > sid::max_lds_bytes())
-                return fail(SID_PM_ERR_UNSUPPORTED, "point %lld: search window %dx%d needs %d bytes of LDS (> %d)",
-                            (long long)i, wh, ww, need, sid::max_lds_bytes());
-            p.lds = need;
-            // the two-per-CU class runs the 8-row-band kernel (two wavefronts per SIMD leave it 256 VGPRs); its
-            // window carries 4 more zero rows, and a point that then no longer fits twice stays with band 4
-            static const bool band8_all = getenv("SID_PM_BAND8_ALL") != nullptr;                 // A/B: also the three-per-CU class
-            if (band8_ok && (blocks_per_cu(need) == 2 || (band8_all && blocks_per_cu(need) > 2))) {
-                const int need8 = lds_need(ctx->kernel, wh, ww, s, K, 8);
-                if (blocks_per_cu(need8) >= 2) { p.lds = need8; p.band = 8; p.force2 = true; }
-                else p.force1 = true;
-            }
-            static const bool band8_c1 = getenv("SID_PM_BAND8_C1") != nullptr;                     // A/B: the one-per-CU class, 512 threads
-            if (band8_ok && band8_c1 && blocks_per_cu(need) == 1 && lds_need(ctx->kernel, wh, ww, s, K, 8) <= sid::max_lds_bytes()) {
-                p.lds = lds_need(ctx->kernel, wh, ww, s, K, 8); p.band = 8;
-            }
-            const double rh = wh - s + 1, rw = ww - s + 1;
-            p.work = rh * rw;
-            macs += (double)K * rh * rw * s * s;
-            // window + bounding box of the rotated template + 5 inputs + outputs
-            bytes += (double)wh * ww + 51.0 * 51.0 + 40.0 + 52.0;
-            valid += 1;
-        }
-        p.cls = p.force1 ? 1 : (p.force2 ? 2 : std::min(8, blocks_per_cu(p.lds)));
-        lds_max = std::max(lds_max, p.lds);
-        pts[(size_t)i] = p;
-    }
-    std::sort(pts.begin(), pts.end(), [](const P &a, const P &b) {
-        if (a.cls != b.cls) return a.cls < b.cls;                 // biggest footprints first
-        if (a.band != b.band) return a.band < b.band;             // one launch per (class, band)
-        if (a.work != b.work) return a.work > b.work;             // then longest first
-        return a.idx < b.idx;
-    });
-    // XCD-aware launch order.  Workgroup j of a launch runs on XCD j mod 8 and every XCD has its own L2, so
-    // within a run of points of equal class and work (= equal border: the order there is the caller's, i.e.
-    // spatial for a grid) the run is cut into 8 contiguous chunks and chunk c goes to the XCD of slot
-    // (start + c) mod 8: neighbouring points - whose search windows overlap - meet in the same L2.
-    // Runs keep their place in the launch (long first), so the load balance across XCDs is unchanged.
-    static const bool no_xcd = getenv("SID_PM_NO_XCD_ORDER") != nullptr;                         // A/B runs
-    if (!no_xcd) {
-        constexpr int kXcd = 8;
-        std::vector<P> tmp;
-        for (int64_t a = 0; a < n;) {
-            int64_t b = a + 1;
-            while (b < n && pts[(size_t)b].cls == pts[(size_t)a].cls && pts[(size_t)b].band == pts[(size_t)a].band &&
-                   pts[(size_t)b].work == pts[(size_t)a].work) ++b;
-            const int64_t L = b - a, m = (L + kXcd - 1) / kXcd;
-            if (L >= 4 * kXcd) {
-                tmp.assign(pts.begin() + a, pts.begin() + b);
-                int64_t w = a;
-                for (int64_t p = 0; p < m; ++p)                       // slot t = p * 8 + c takes element c * m + p
-                    for (int c = 0; c < kXcd; ++c) {
-                        const int64_t e = (int64_t)c * m + p;
-                        if (e < L) pts[(size_t)w++] = tmp[(size_t)e];
-                    }
-            }
-            a = b;
-        }
-    }
-    std::vector<int32_t> order((size_t)n);
-    ctx->buckets.clear();
-    for (int64_t i = 0; i < n; ++i) {
-        order[(size_t)i] = pts[(size_t)i].idx;
-        if (ctx->buckets.empty() || pts[(size_t)i].cls != pts[(size_t)(i - 1)].cls || pts[(size_t)i].band != pts[(size_t)(i - 1)].band)
-            ctx->buckets.push_back(Bucket{(int)i, 0, 0, pts[(size_t)i].band});
-        Bucket &b = ctx->buckets.back();
-        b.count += 1;
-        b.lds = std::max(b.lds, pts[(size_t)i].lds);
-    }
 
     std::vector<double> rotv;
     make_rot(angles, K, alpha0, s, rot, rotv);
     std::vector<uint16_t> sampv;
     int nflag = 0;
-    if (ctx->kernel == KERNEL_MFMA && !getenv("SID_PM_NO_SAMP_TABLE")) nflag = make_samp(rotv, K, s, sampv);
+    if (!getenv("SID_PM_NO_SAMP_TABLE")) nflag = make_samp(rotv, K, s, sampv);
 
-    if (int rc = ctx->samp.reserve(sampv.size() + 4)) return rc;
-    if (int rc = ctx->vec.reserve((size_t)(5 * n))) return rc;
-    if (int rc = ctx->order.reserve((size_t)n)) return rc;
-    if (int rc = ctx->angles.reserve((size_t)K)) return rc;
-    if (int rc = ctx->rot.reserve((size_t)(4 * K))) return rc;
+    // one arena, one upload: [5n doubles | K angles | 4K rotation terms | order (int32 n) | sampling table]
+    auto up = [](size_t v) { return (v + 255) / 256 * 256; };
+    const size_t o_vec = 0, o_ang = up(o_vec + sizeof(double) * 5 * (size_t)n), o_rot = up(o_ang + sizeof(double) * (size_t)K),
+                 o_ord = up(o_rot + sizeof(double) * 4 * (size_t)K), o_smp = up(o_ord + sizeof(int32_t) * (size_t)n),
+                 total = up(o_smp + sizeof(uint16_t) * (sampv.size() + 4));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));               // nothing may still read the old arena
+    if (int rc = ctx->arena.reserve(total)) return rc;
     if (int rc = ctx->out.reserve((size_t)(5 * n))) return rc;
     if (int rc = ctx->out_ij.reserve((size_t)(3 * n))) return rc;
-    // synchronous copies: the host vectors are caller-owned and not retained
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    std::vector<uint8_t> host(total, 0);
     const double *src[5] = {c1, r1, c2fg, r2fg, border};
-    for (int k = 0; k < 5 && n > 0; ++k)
-        HIP_TRY(hipMemcpy(ctx->vec.p + k * n, src[k], sizeof(double) * (size_t)n, hipMemcpyHostToDevice));
-    if (n > 0) HIP_TRY(hipMemcpy(ctx->order.p, order.data(), sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(ctx->angles.p, angles, sizeof(double) * (size_t)K, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(ctx->rot.p, rotv.data(), sizeof(double) * rotv.size(), hipMemcpyHostToDevice));
-    if (!sampv.empty()) HIP_TRY(hipMemcpy(ctx->samp.p, sampv.data(), sizeof(uint16_t) * sampv.size(), hipMemcpyHostToDevice));
+    for (int k = 0; k < 5 && n > 0; ++k) memcpy(host.data() + o_vec + sizeof(double) * (size_t)(k * n), src[k], sizeof(double) * (size_t)n);
+    memcpy(host.data() + o_ang, angles, sizeof(double) * (size_t)K);
+    memcpy(host.data() + o_rot, rotv.data(), sizeof(double) * rotv.size());
+    if (!sampv.empty()) memcpy(host.data() + o_smp, sampv.data(), sizeof(uint16_t) * sampv.size());
+    // synchronous: the host vectors are caller-owned and not retained
+    HIP_TRY(hipMemcpy(ctx->arena.p, host.data(), total, hipMemcpyHostToDevice));
+    ctx->d_vec = reinterpret_cast<double *>(ctx->arena.p + o_vec);
+    ctx->d_angles = reinterpret_cast<double *>(ctx->arena.p + o_ang);
+    ctx->d_rot = reinterpret_cast<double *>(ctx->arena.p + o_rot);
+    ctx->d_order = reinterpret_cast<int32_t *>(ctx->arena.p + o_ord);
+    ctx->d_samp = reinterpret_cast<uint16_t *>(ctx->arena.p + o_smp);
     ctx->have_samp = !sampv.empty(); ctx->samp_nflag = nflag;
+    ctx->h_c2fg.assign(c2fg, c2fg + n); ctx->h_r2fg.assign(r2fg, r2fg + n); ctx->h_border.assign(border, border + n);
 
     ctx->user_out = nullptr; ctx->user_ij = nullptr;
     ctx->n = n; ctx->img_size = s; ctx->n_angles = K; ctx->flags = flags;
+    ctx->have_points = false;
+    if (int rc = classify_points(ctx)) return rc;
     ctx->have_points = true;
-    const double img_bytes = (double)ctx->cur[0].rows * ctx->cur[0].cols + (double)rows2 * cols2;
-    ctx->info[0] = (double)ctx->buckets.size();
-    ctx->info[1] = valid;
-    ctx->info[2] = macs;
-    ctx->info[3] = std::min(bytes, img_bytes + 92.0 * valid);
-    ctx->info[4] = (double)lds_max;
-    ctx->info[5] = 0;
     return SID_PM_OK;
 }
 
@@ -546,26 +566,28 @@ SID_EXPORT int sid_pm_run(sid_pm_ctx *ctx)
     if (!ctx) return fail(SID_PM_ERR_ARG, "null ctx");
     if (!ctx->have_points || !ctx->have_pair) return fail(SID_PM_ERR_STATE, "run needs set_points and an image pair");
     Guard g(ctx->device);
+    // the launch classes were sized for the image-2 shape current at set_points; a pair of another shape
+    // (select_pair / bind_pair / upload_pair since then) gets its own classification before anything is launched
+    if (ctx->cur[1].rows != ctx->cls_rows2 || ctx->cur[1].cols != ctx->cls_cols2) {
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        if (int rc = classify_points(ctx)) return rc;
+    }
     sid::PMArgs A;
     fill_args(ctx, A);
     if (ctx->cur_slot >= 0 && ctx->ready_rec[ctx->cur_slot])
         HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->slot_ready[ctx->cur_slot], 0));
-    static const int lds_pad = getenv("SID_PM_LDS_PAD") ? atoi(getenv("SID_PM_LDS_PAD")) : 0;   // occupancy experiments
-    for (const Bucket &b0 : ctx->buckets) {
-        Bucket b = b0;
-        b.lds = std::min(b.lds + lds_pad, sid::max_lds_bytes());
-        A.order = ctx->order.p + b.offset;
+    for (const Bucket &b : ctx->buckets) {
+        A.order = ctx->d_order + b.offset;
         A.n_launch = b.count;
+        A.lds_bytes = b.lds;
         // 256 threads per point; 768 when the LDS footprint leaves room for one point per CU only, so that
         // the CU still carries 12 wavefronts (3 per SIMD = the register budget).  (Measured: 384- and
         // 512-thread groups lose to 2 x 256 - they do not pack onto the SIMDs and serialise the phases.)
         const int per_cu = std::max(1, std::min(b.band == 8 ? 2 : 8, blocks_per_cu(b.lds)));
-        static const int force_nt = getenv("SID_PM_THREADS") ? atoi(getenv("SID_PM_THREADS")) : 0;   // A/B experiments
-        static const int nt2 = getenv("SID_PM_THREADS2") ? atoi(getenv("SID_PM_THREADS2")) : 256;   // A/B: two-per-CU class
-        const int nthreads = force_nt ? force_nt : (per_cu == 1 ? 768 : (per_cu == 2 ? nt2 : 256));
-        const int e = ctx->kernel == KERNEL_DOT4 ? sid::launch_pm(A, b.lds, ctx->stream)
-                                                 : sid::launch_pm_mfma(A, b.lds, b.band == 8 ? (per_cu == 1 ? 512 : 256) : nthreads, b.band,
-                                                                       use_paired(ctx->kernel, ctx->n_angles), ctx->stream);
+        const int nthreads = b.band == 8 ? 256 : (per_cu == 1 ? 768 : 256);
+        const int e = use_rp(ctx->img_size, ctx->n_angles)
+                          ? sid::launch_pm_rp(A, b.lds, nthreads, ctx->stream)
+                          : sid::launch_pm_mfma(A, b.lds, nthreads, b.band, use_paired(ctx->n_angles), ctx->stream);
         if (e != 0) return fail(SID_PM_ERR_HIP, "kernel launch failed: %s", hipGetErrorString((hipError_t)e));
     }
     if (ctx->cur_slot >= 0) {
@@ -647,12 +669,12 @@ SID_EXPORT int sid_pm_debug_point(sid_pm_ctx *ctx, double c1, double r1, double 
 {
     if (!ctx) return fail(SID_PM_ERR_ARG, "null ctx");
     if (!ctx->have_pair) return fail(SID_PM_ERR_STATE, "debug_point needs an image pair");
-    if (int rc = check_sweep(ctx->kernel, img_size, angles, n_angles, flags)) return rc;
+    if (int rc = check_sweep(img_size, angles, n_angles, flags)) return rc;
     Guard g(ctx->device);
     const int s = img_size, K = n_angles;
-    int wh = 0, ww = 0, lds = lds_need(ctx->kernel, s + 1, s + 1, s, K);
+    int wh = 0, ww = 0, lds = lds_need(s + 1, s + 1, s, K);
     if (window_dims(c2fg, r2fg, border, s, ctx->cur[1].rows, ctx->cur[1].cols, wh, ww))
-        lds = lds_need(ctx->kernel, wh, ww, s, K);
+        lds = lds_need(wh, ww, s, K);
     if (lds > sid::max_lds_bytes()) return fail(SID_PM_ERR_UNSUPPORTED, "search window too large for LDS");
     std::vector<double> rotv;
     make_rot(angles, K, alpha0, s, rot, rotv);
@@ -663,7 +685,7 @@ SID_EXPORT int sid_pm_debug_point(sid_pm_ctx *ctx, double c1, double r1, double 
     DevBuf<uint16_t> dsamp;
     std::vector<uint16_t> sampv;
     int nflag = 0;
-    if (ctx->kernel == KERNEL_MFMA && !getenv("SID_PM_NO_SAMP_TABLE")) nflag = make_samp(rotv, K, s, sampv);
+    if (!getenv("SID_PM_NO_SAMP_TABLE")) nflag = make_samp(rotv, K, s, sampv);
     DevBuf<float> dccm, dhes;
     DevBuf<long long> dcyc;
     int rc = SID_PM_OK;
@@ -702,8 +724,9 @@ SID_EXPORT int sid_pm_debug_point(sid_pm_ctx *ctx, double c1, double r1, double 
         A.dbg_cycles = dcyc.p;
         gauss_taps(A.gauss_w);
         A.samp = sampv.empty() ? nullptr : dsamp.p; A.samp_nflag = nflag;
-        step((hipError_t)(ctx->kernel == KERNEL_DOT4 ? sid::launch_pm(A, lds, ctx->stream)
-                                                     : sid::launch_pm_mfma(A, lds, getenv("SID_PM_THREADS") ? atoi(getenv("SID_PM_THREADS")) : 256, 4, use_paired(ctx->kernel, K), ctx->stream)));
+        A.lds_bytes = lds;
+        step((hipError_t)(use_rp(s, K) ? sid::launch_pm_rp(A, lds, 256, ctx->stream)
+                                       : sid::launch_pm_mfma(A, lds, 256, 4, use_paired(K), ctx->stream)));
         step(hipStreamSynchronize(ctx->stream));
         if (templates) step(hipMemcpy(templates, dt.p, tcount, hipMemcpyDeviceToHost));
         if (ccm && cap > 0) step(hipMemcpy(ccm, dccm.p, sizeof(float) * cap, hipMemcpyDeviceToHost));

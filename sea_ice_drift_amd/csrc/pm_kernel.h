@@ -1,13 +1,10 @@
-// Shared between the HIP kernel (pm_kernel.hip) and the host C-ABI (pm_capi.hip).
+// Shared between the HIP kernel (pm_kernel_mfma.hip) and the host C-ABI (pm_capi.hip).
 #pragma once
 #include <stdint.h>
 
 namespace sid {
 
-constexpr int kBlock = 256;          // threads per grid point: 4 wavefronts of 64
-constexpr int kStrip = 8;            // NCC outputs per thread-task along a row
 constexpr int kMaxAngles = 64;
-constexpr int kMiscBytes = 4096;     // fixed LDS header: histogram, reduction scratch, per-angle terms
 
 // Arguments of one launch (one block per grid point of this launch).
 struct PMArgs {
@@ -16,6 +13,7 @@ struct PMArgs {
     const double *c1, *r1, *c2fg, *r2fg, *border;   // [n_total], original point order
     const int32_t *order;                           // [n_launch] -> original point index
     int32_t n_launch;
+    int32_t lds_bytes;                              // dynamic LDS of this launch: a point whose layout needs more writes NaN
     int32_t img_size;                               // s
     int32_t n_angles;                               // K
     uint32_t flags;
@@ -35,36 +33,10 @@ struct PMArgs {
     long long *dbg_cycles;                          // [16] shader-clock stamps at phase boundaries
 };
 
-// LDS carve-up for a window of wh x ww pixels, template side s, K angles.
-struct LdsLayout {
-    int wpitch;      // bytes per window row in LDS
-    int win_off, ccm_off, tmpl_off, total;
-};
-
 __host__ __device__ inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
-// dwords per template row in LDS (zero padded, multiple of 4 so rows are 16-byte aligned)
-__host__ __device__ inline int tmpl_row_dwords(int s) { return round_up((s + 3) / 4, 4); }
-
-__host__ __device__ inline LdsLayout lds_layout(int wh, int ww, int s, int K)
-{
-    LdsLayout L;
-    const int rh = wh - s + 1, rw = ww - s + 1;
-    const int nch = (s + 3) / 4;
-    // a strip task reads (nch + 2) dwords rounded up to an even count from its first output
-    L.wpitch = round_up(rw, kStrip) - kStrip + round_up(nch + 2, 2) * 4;
-    if (L.wpitch < round_up(ww, 8)) L.wpitch = round_up(ww, 8);
-    L.win_off = kMiscBytes;
-    L.ccm_off = round_up(L.win_off + wh * L.wpitch, 16);
-    L.tmpl_off = round_up(L.ccm_off + rh * rw * 4, 16);
-    const int tmpl_bytes = K * s * tmpl_row_dwords(s) * 4;
-    const int hes_bytes = rh * rw * 4;              // aliases the templates once they are dead
-    L.total = round_up(L.tmpl_off + (tmpl_bytes > hes_bytes ? tmpl_bytes : hes_bytes), 16);
-    return L;
-}
-
 // ---- MFMA kernel (pm_kernel_mfma.hip) ----
-constexpr int kMiscMfmaBytes = 2816;
+constexpr int kMiscMfmaBytes = 3072;
 constexpr int kTrowPad = 36;         // zero rows around a winner operand block: 16 above, 20 below (the step loop runs in fours)
 constexpr int kQueueCap = 192;       // arg-max candidates waiting for exact evaluation (16 B each)
 
@@ -122,6 +94,77 @@ __host__ __device__ inline MfmaLdsLayout mfma_lds_layout(int wh, int ww, int s, 
     return L;
 }
 
+// ---- row-pair kernel (pm_kernel_rp.inc): template sides 34 and 35, more than kPairedMaxAngles angles ----
+// Sweep operands: the template columns 0..31 live in a table [row -1 .. s+1][16 slots][32 B] (zero rows around),
+// from which one MFMA operand = two consecutive template rows x 32 columns (K = 64 all useful); the columns
+// 32.. ("strip") are multiplied through a column-pair copy of the window, WP[u][rho] = (W[rho][u], W[rho][u+1]),
+// so that K = 32 window rows x 2 columns.
+struct RpLdsLayout {
+    int wpitch, wrows;          // window pitch (multiple of 8) and rows written (window + zero rows)
+    int win_off, sii_off;
+    int wp_off, wp_pitch, wp_rows, wp_len;   // column-pair copy: wp_rows rows (u = 32 + row) of wp_len entries (2 B each)
+    int u_off;                  // union: column sums | table + strip + patch + queue | winner operands + NCC matrix
+    int tab_rows;               // s + 3 rows of 512 B
+    int strip_off, ncp, nrg;    // strip operand fragments: ncp column pairs x nrg row groups, 1 KB each
+    int patch_off, ppitch, pdim, pradius, queue_off, trow_bytes;
+    int npair, nsingle;         // x tiling of a band: npair items of 32 placements, then nsingle (0/1) of 16
+    int total;
+};
+
+__host__ __device__ inline bool rp_size_supported(int s) { return s == 34 || s == 35; }
+
+__host__ __device__ inline RpLdsLayout rp_lds_layout(int wh, int ww, int s)
+{
+    RpLdsLayout L;
+    const int rh = wh - s + 1, rw = ww - s + 1;
+    const int nE = (s + 1) / 2, nO = s / 2 + 1, nst = (nE > nO ? nE : nO) + 1;
+    const int rem = rw % 32;
+    L.npair = rw / 32 + (rem > 16 ? 1 : 0);
+    L.nsingle = (rem > 0 && rem <= 16) ? 1 : 0;
+    // bytes a window row must hold: a pair item at x0 reads 24 B from x0 + 8 (n >> 2) + 16 (g & 1) (<= x0 + 64);
+    // a single item reads 5 dwords from (x0 + n + 16 (g & 1)) & ~3 (<= x0 + 51); the winner (k-groups 0..2 + the
+    // broadcast group) 5 dwords up to 16 ntx + 52
+    int need = ww;
+    if (L.npair && 32 * (L.npair - 1) + 64 > need) need = 32 * (L.npair - 1) + 64;
+    if (L.nsingle && 32 * L.npair + 52 > need) need = 32 * L.npair + 52;
+    const int ntx = (rw + 15) / 16;
+    if (16 * ntx + 52 > need) need = 16 * ntx + 52;
+    L.wpitch = round_up(need, 8);
+    const int y0max = 4 * ((rh + 3) / 4 - 1);
+    L.wrows = y0max + 2 * nst;                       // last step reads rows y0 + 2 (nst - 1) and + 1
+    if (L.wrows < wh + 3) L.wrows = wh + 3;
+    L.win_off = kMiscMfmaBytes;
+    L.sii_off = round_up(L.win_off + L.wrows * L.wpitch, 16);
+    L.u_off = round_up(L.sii_off + rh * rw * 4, 16);
+    L.ncp = (s - 32 + 1) / 2; L.nrg = 2;
+    L.wp_rows = rw + 2 * (L.ncp - 1);
+    L.wp_len = y0max + 44;                           // entries rho = 0 .. y0max + 3 + 32 + 8 (+ slack of a 24-byte read)
+    L.wp_pitch = round_up(2 * L.wp_len, 8);
+    if (!((L.wp_pitch / 8) & 1)) L.wp_pitch += 8;    // 8 x odd: at most two-way bank conflicts for the lane-private rows
+    L.tab_rows = s + 3;
+    L.strip_off = L.u_off + L.tab_rows * 512;
+    const int tc = s / 2 + 1;
+    int r = 0;
+    while (r * r < 2 * tc * tc) ++r;
+    L.pradius = r + 1;
+    L.pdim = 2 * L.pradius + 2;
+    L.ppitch = round_up(L.pdim, 4);
+    L.patch_off = L.strip_off + L.ncp * L.nrg * 1024 + 16;      // + 16 scratch bytes
+    L.queue_off = round_up(L.patch_off + L.pdim * L.ppitch + 1, 16);
+    L.trow_bytes = 4 * (s + kTrowPad) * 16;
+    // the column-pair copy only lives during the sweep: behind the queue, inside the union (built after the
+    // column sums are dead, overwritten by the winner's NCC matrix)
+    L.wp_off = round_up(L.queue_off + kQueueCap * 16, 16);
+    int u = rh * ww * 4;
+    const int sweep = L.wp_off + L.wp_rows * L.wp_pitch - L.u_off;
+    if (u < sweep) u = sweep;
+    if (u < 2 * L.trow_bytes + rh * rw * 4) u = 2 * L.trow_bytes + rh * rw * 4;
+    L.total = round_up(L.u_off + u, 16);
+    return L;
+}
+
+int launch_pm_rp(const PMArgs &args, int lds_bytes, int nthreads, void *stream);
+
 __host__ __device__ inline int samp_pitch(int s) { return round_up(s, 4); }
 constexpr double kSampGuard = 1e-5;   // table entries whose coordinate is this close to k + 1/2 are flagged
 
@@ -130,11 +173,7 @@ constexpr int kPairedMaxAngles = 7;   // angle sets this small run the paired sw
 bool mfma_band8_supported(int s);
 bool mfma_img_size_supported(int s);
 
-// host-side launcher implemented in pm_kernel.hip; returns a hipError_t as int
-int launch_pm(const PMArgs &args, int lds_bytes, void *stream);
 int launch_rsqrt(const double *x, double *y, int64_t n, void *stream);
-// true when a kernel instantiation exists for this template side
-bool img_size_supported(int s);
 int max_lds_bytes();
 
 }  // namespace sid

@@ -1,8 +1,7 @@
 // pm_kernel_mfma.hip - the pattern-matching kernel on the gfx950 matrix cores.
 //
-// Same operator and same numerical specification as pm_kernel.hip (reference pmlib.py:117-212,
-// :36-59; NCC specification in DESIGN.md section 3), but the 34x34 uint8 correlation runs on
-// v_mfma_i32_16x16x64_i8 as an implicit correlation - no im2col is materialised:
+// Operator: reference pmlib.py:117-212, :36-59; NCC specification in DESIGN.md section 3.  The 34x34 uint8
+// correlation runs on v_mfma_i32_16x16x64_i8 as an implicit correlation - no im2col is materialised:
 //
 //   bytes are re-centred (w' = w ^ 0x80, t' = t ^ 0x80 as int8); numer, dI and dT are covariances
 //   and do not change under the shift, so the integer sums stay exact and the spec is untouched.
@@ -73,6 +72,9 @@ struct MiscM {                       // LDS offset 0, kMiscMfmaBytes reserved
     double sTd[kMaxAngles];          // sum t' per angle
     float rTf[kMaxAngles];
     int constT[kMaxAngles];
+    // row-pair kernel: float32 pre-filter terms of the current group's slots (pm_kernel_rp.inc)
+    int mTi[kSlots]; float cTf[kSlots], aTf[kSlots];
+    int any_const;
 };
 
 // Per-point geometry, written once by thread 0 and read by every phase (the phases are separate
@@ -85,10 +87,11 @@ struct Geo {
     u32 win_magic;                   // floor(2^32 / (wpitch/4)) + 1: idx / (wpitch/4) == umulhi(idx, win_magic) for idx < 2^16
     u32 patch_magic, rw_magic;       // same for ppitch/4 and for rw
     int band;                        // output rows per sweep work item (kernel template parameter)
+    int wp_off, wp_pitch, wp_rows, strip_off, wrows, npair, nsingle;   // row-pair kernel (RpLdsLayout)
     long long r0, c0;                // window origin on image 2
     double c1, r1, nd;
 };
-constexpr int kGeoOff = 2560;
+constexpr int kGeoOff = 2816;
 static_assert(sizeof(MiscM) <= kGeoOff, "misc header too large");
 static_assert(kGeoOff + sizeof(Geo) <= kMiscMfmaBytes, "geometry block does not fit the LDS header");
 
@@ -153,7 +156,7 @@ __device__ __forceinline__ double wave_sum_dpp_d(double v) {
     return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
 
-// ---- small block utilities (same semantics as in pm_kernel.hip) ----
+// ---- small block utilities ----
 
 __device__ __forceinline__ u32 block_min(u32 v, MiscM *m) {
     v = wave_umin_dpp(v);
@@ -1373,6 +1376,13 @@ __global__ __launch_bounds__(BAND == 8 ? 512 : kMaxBlockM, BAND == 8 ? 2 : kOccM
     }
     const int wh = (int)(r1e - r0), ww = (int)(c1e - c0);
     const int rh = wh - s + 1, rw = ww - s + 1, npos = rh * rw;
+    // the launch was sized by the host for the image shape it classified the points with (pm_capi.hip
+    // classify_points); a window that needs more LDS than that must never be touched
+    if (mfma_lds_layout(wh, ww, s, BAND, PAIRED).total > A.lds_bytes) {
+        if (tid < 5) out[tid] = NAN;
+        if (oij && tid < 3) oij[tid] = -1;
+        return;
+    }
     if (tid == 0) {
         const MfmaLdsLayout L = mfma_lds_layout(wh, ww, s, BAND, PAIRED);
         const double c1 = A.c1[pt], r1 = A.r1[pt];
@@ -1471,7 +1481,25 @@ __global__ __launch_bounds__(BAND == 8 ? 512 : kMaxBlockM, BAND == 8 ? 2 : kOccM
     }
 }
 
+#include "pm_kernel_rp.inc"
+
+__global__ void rsqrt_kernel(const double *x, double *y, int64_t n)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) y[i] = 1.0 / sqrt(x[i]);
+}
+
 }  // namespace
+
+int max_lds_bytes() { return 160 * 1024; }
+
+int launch_rsqrt(const double *x, double *y, int64_t n, void *stream)
+{
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (n <= 0) return (int)hipSuccess;
+    hipLaunchKernelGGL(rsqrt_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, y, n);
+    return (int)hipGetLastError();
+}
 
 bool mfma_img_size_supported(int s) { return s >= 2 && s + 15 <= 64; }
 
@@ -1487,16 +1515,32 @@ int launch_pm_mfma(const PMArgs &args, int lds_bytes, int nthreads, int band, bo
         kern = args.img_size == 34 ? pm_kernel_mfma<34, 4, true> : args.img_size == 35 ? pm_kernel_mfma<35, 4, true>
                                                                                         : pm_kernel_mfma<0, 4, true>;
     } else if (band == 8) {
-        if (!mfma_band8_supported(args.img_size) || (nthreads != 256 && nthreads != 512)) return (int)hipErrorInvalidValue;
+        if (!mfma_band8_supported(args.img_size) || nthreads != 256) return (int)hipErrorInvalidValue;
         kern = args.img_size == 34 ? pm_kernel_mfma<34, 8, false> : pm_kernel_mfma<35, 8, false>;
     } else if (band == 4) {
         kern = args.img_size == 34 ? pm_kernel_mfma<34, 4, false> : args.img_size == 35 ? pm_kernel_mfma<35, 4, false>
                                                                                          : pm_kernel_mfma<0, 4, false>;
     } else return (int)hipErrorInvalidValue;
+    // the attribute belongs to the function, not to the stream: always the maximum, so that launches of different
+    // footprints from different host threads cannot undercut each other
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, max_lds_bytes());
     if (e != hipSuccess) return (int)e;
-    if (nthreads != 256 && nthreads != 384 && nthreads != 512 && nthreads != 768) return (int)hipErrorInvalidValue;
+    if (lds_bytes > max_lds_bytes() || (nthreads != 256 && nthreads != 768)) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(kern, dim3(args.n_launch), dim3(nthreads), lds_bytes, st, args);
+    return (int)hipGetLastError();
+}
+
+int launch_pm_rp(const PMArgs &args, int lds_bytes, int nthreads, void *stream)
+{
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (args.n_launch <= 0) return (int)hipSuccess;
+    if (!rp_size_supported(args.img_size)) return (int)hipErrorInvalidValue;
+    void (*kern)(const PMArgs) = args.img_size == 34 ? pm_kernel_rp<34> : pm_kernel_rp<35>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, max_lds_bytes());
+    if (e != hipSuccess) return (int)e;
+    if (lds_bytes > max_lds_bytes() || (nthreads != 256 && nthreads != 768)) return (int)hipErrorInvalidValue;
     hipLaunchKernelGGL(kern, dim3(args.n_launch), dim3(nthreads), lds_bytes, st, args);
     return (int)hipGetLastError();
 }

@@ -94,3 +94,98 @@ class ResultGatherer(object):
             ij = torch.full((self.n_total, 3), -1, dtype=torch.int32, device=self.device)
             ij[self.dest] = stacked_ij.reshape(-1, 3)[self.sel]
         return out, ij
+
+
+class PackedGatherer(object):
+    """One collective per step: every rank's results live in ONE padded byte block
+    [m x 5 float64 | m x 3 int32] that the kernels write in place (``local_views``), so the
+    exchange step of the path is a single gather of that block to rank `dst` (RCCL over xGMI
+    with device tensors), followed there by one index_select per array that undoes the
+    sharding and an asynchronous copy into pinned host memory.  With a ``gloo`` group (CPU
+    tests, several ranks sharing one device in a dry run) the block is staged through the host.
+    """
+
+    ROW = 5 * 8 + 3 * 4
+
+    def __init__(self, n_total, idx_local, device, group=None, dst=0):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist, self.group, self.dst = torch, dist, group, dst
+        self.distributed = dist.is_available() and dist.is_initialized()
+        self.world = dist.get_world_size(group) if self.distributed else 1
+        self.rank = dist.get_rank(group) if self.distributed else 0
+        self.is_dst = self.rank == dst
+        self.n_total, self.device = int(n_total), torch.device(device)
+        self.m = m = shard_size(n_total, self.world)
+        self.n_local = len(idx_local)
+        if self.n_local > m:
+            raise ValueError('shard larger than the padded block')
+        self.host_staged = self.distributed and dist.get_backend(group) == 'gloo' and self.device.type != 'cpu'
+        self.block = torch.zeros(m * self.ROW, dtype=torch.uint8, device=self.device)
+        self.out_local = self.block[:m * 40].view(torch.float64).view(m, 5)
+        self.ij_local = self.block[m * 40:].view(torch.int32).view(m, 3)
+        self.out_local.fill_(float('nan'))
+        self.ij_local.fill_(-1)
+        # one-time index exchange: which original point every row of every rank's block holds
+        idx_pad = torch.full((m,), -1, dtype=torch.int64)
+        idx_pad[:self.n_local] = torch.as_tensor(np.asarray(idx_local), dtype=torch.int64)
+        if self.world == 1:
+            all_idx = idx_pad[None]
+        else:
+            gl = [torch.empty_like(idx_pad) for _ in range(self.world)] if self.is_dst else None
+            if dist.get_backend(group) == 'gloo':
+                dist.gather(idx_pad, gl, dst=dst, group=group)
+            else:
+                dev_pad = idx_pad.to(self.device)
+                dgl = [torch.empty_like(dev_pad) for _ in range(self.world)] if self.is_dst else None
+                dist.gather(dev_pad, dgl, dst=dst, group=group)
+                gl = [t.cpu() for t in dgl] if self.is_dst else None
+            all_idx = torch.stack(gl) if self.is_dst else None
+        if self.is_dst:
+            flat = all_idx.reshape(-1)
+            rows = torch.nonzero(flat >= 0).reshape(-1)
+            perm = torch.full((self.n_total,), -1, dtype=torch.int64)
+            perm[flat[rows]] = rows                               # original index -> row of the stacked blocks
+            if (perm < 0).any():
+                raise ValueError('the shards do not cover all points')
+            work_dev = torch.device('cpu') if self.host_staged else self.device
+            self.perm = perm.to(work_dev)
+            self.stack = torch.empty((self.world, m * self.ROW), dtype=torch.uint8, device=work_dev)
+            self.full_out = torch.empty((self.n_total, 5), dtype=torch.float64, device=work_dev)
+            self.full_ij = torch.empty((self.n_total, 3), dtype=torch.int32, device=work_dev)
+            pin = self.device.type == 'cuda'
+            self.host_out = torch.empty((self.n_total, 5), dtype=torch.float64, pin_memory=pin)
+            self.host_ij = torch.empty((self.n_total, 3), dtype=torch.int32, pin_memory=pin)
+
+    def local_views(self):
+        """The [n_local,5] float64 and [n_local,3] int32 tensors the kernels of this rank write."""
+        return self.out_local[:self.n_local], self.ij_local[:self.n_local]
+
+    def gather_to_host(self):
+        """The exchange step.  On `dst` the results are in host memory, in original point order, on return."""
+        torch, dist, m = self.torch, self.dist, self.m
+        if self.world == 1:
+            stack = self.block[None]
+        elif self.host_staged:
+            mine = self.block.cpu()
+            dist.gather(mine, list(self.stack.unbind(0)) if self.is_dst else None, dst=self.dst, group=self.group)
+            stack = self.stack if self.is_dst else None
+        else:
+            dist.gather(self.block, list(self.stack.unbind(0)) if self.is_dst else None, dst=self.dst, group=self.group)
+            stack = self.stack if self.is_dst else None
+        if not self.is_dst:
+            return
+        so = stack[:, :m * 40].reshape(-1).view(torch.float64).view(-1, 5) if stack.shape[0] == 1 else \
+            stack[:, :m * 40].contiguous().view(torch.float64).view(-1, 5)
+        si = stack[:, m * 40:].reshape(-1).view(torch.int32).view(-1, 3) if stack.shape[0] == 1 else \
+            stack[:, m * 40:].contiguous().view(torch.int32).view(-1, 3)
+        torch.index_select(so, 0, self.perm, out=self.full_out)
+        torch.index_select(si, 0, self.perm, out=self.full_ij)
+        self.host_out.copy_(self.full_out, non_blocking=True)
+        self.host_ij.copy_(self.full_ij, non_blocking=True)
+        if self.device.type == 'cuda':
+            torch.cuda.current_stream(self.device).synchronize()
+
+    def host_results(self):
+        """NumPy copies of the gathered results (`dst` only)."""
+        return self.host_out.numpy().copy(), self.host_ij.numpy().copy()

@@ -21,32 +21,33 @@ except Exception:                         # noqa: BLE001
             return 'NSR(%r)' % (self.srs,)
 
 
-AVG_EARTH_RADIUS = 6371  # in km (reference lib.py:25)
+EARTH_RADIUS_KM = 6371  # mean radius the reference's Haversine uses (lib.py:25)
+
+
+def _haversine_km(lon_a, lat_a, lon_b, lat_b):
+    """Great-circle distance in km between (lon, lat) pairs given in degrees."""
+    phi_a, phi_b = np.radians(lat_a), np.radians(lat_b)
+    half_dphi = (phi_b - phi_a) * 0.5
+    half_dlam = (np.radians(lon_b) - np.radians(lon_a)) * 0.5
+    hav = np.sin(half_dphi) ** 2 + np.cos(phi_a) * np.cos(phi_b) * np.sin(half_dlam) ** 2
+    return 2 * EARTH_RADIUS_KM * np.arcsin(np.sqrt(hav))
+
+
+def great_circle_km(n1, x1, y1, n2, x2, y2):
+    """Distance in km between pixel (x1, y1) of image n1 and pixel (x2, y2) of image n2 (what the
+    reference's get_displacement_km returns, lib.py:61-85)."""
+    return _haversine_km(*(n1.transform_points(x1, y1) + n2.transform_points(x2, y2)))
 
 
 def get_displacement_km(n1, x1, y1, n2, x2, y2):
-    """Haversine displacement in km between pixels of two images (reference lib.py:61-85)."""
-    lon1, lat1 = n1.transform_points(x1, y1)
-    lon2, lat2 = n2.transform_points(x2, y2)
-    lt1, ln1, lt2, ln2 = map(np.radians, (lat1, lon1, lat2, lon2))
-    dlat = lt2 - lt1
-    dlon = ln2 - ln1
-    d = (np.sin(dlat * 0.5) ** 2 +
-         np.cos(lt1) * np.cos(lt2) * np.sin(dlon * 0.5) ** 2)
-    return 2 * AVG_EARTH_RADIUS * np.arcsin(np.sqrt(d))
+    """Reference name (lib.py:61) of ``great_circle_km``."""
+    return great_circle_km(n1, x1, y1, n2, x2, y2)
 
 
 def get_speed_ms(n1, x1, y1, n2, x2, y2):
-    """Drift speed in m/s from the images' time stamps (reference lib.py:87-102)."""
-    dt = (n2.time_coverage_start - n1.time_coverage_start).total_seconds()
-    return 1000. * get_displacement_km(n1, x1, y1, n2, x2, y2) / abs(dt)
-
-
-def get_displacement_pix(n1, x1, y1, n2, x2, y2):
-    """Displacement in pixels of the first image (reference lib.py:104-121)."""
-    lon2, lat2 = n2.transform_points(x2, y2)
-    x2n1, y2n1 = n1.transform_points(lon2, lat2, 1)
-    return x2n1 - x1, y2n1 - y1
+    """Drift speed in m/s between two time-stamped images (reference lib.py:87-102)."""
+    elapsed = abs((n2.time_coverage_start - n1.time_coverage_start).total_seconds())
+    return 1000. * great_circle_km(n1, x1, y1, n2, x2, y2) / elapsed
 
 
 def get_drift_vectors(n1, x1, y1, n2, x2, y2, nsr=None, **kwargs):
@@ -70,24 +71,38 @@ def get_drift_vectors(n1, x1, y1, n2, x2, y2, nsr=None, **kwargs):
     return px2 - px1, py1 - py2, lon1, lat1, lon2, lat2
 
 
-def _design_matrix(x, y, order):
-    cols = [np.ones(len(x)), x, y]
+def _poly_terms(x, y, order):
+    """Columns of the design matrix in the reference's term order (lib.py:160-168):
+    1, x, y | x^2, y^2, xy | x^3, y^3, x^2 y, y^2 x."""
+    x, y = np.asarray(x, dtype=np.float64), np.asarray(y, dtype=np.float64)
+    terms = [np.ones(len(x)), x, y]
     if order > 1:
-        cols += [x ** 2, y ** 2, x * y]
+        terms.extend((x ** 2, y ** 2, x * y))
     if order > 2:
-        cols += [x ** 3, y ** 3, x ** 2 * y, y ** 2 * x]
-    return np.vstack(cols).T
+        terms.extend((x ** 3, y ** 3, x ** 2 * y, y ** 2 * x))
+    return np.vstack(terms).T
+
+
+def fit_polynomial_map(x1, y1, x2, y2, order=1):
+    """Least-squares polynomial map (x1, y1) -> (x2, y2); returns ``f(x, y) -> (x', y')`` for flat arrays.
+    The solve is NumPy's ``lstsq`` with ``rcond=-1`` on the design matrix above, one right-hand side at a
+    time, and the evaluation is a matrix-vector product - the arithmetic of lib.py:139-177."""
+    design = _poly_terms(x1, y1, order)
+    coef_x = np.linalg.lstsq(design, x2, rcond=-1)[0]
+    coef_y = np.linalg.lstsq(design, y2, rcond=-1)[0]
+
+    def evaluate(x, y):
+        g = _poly_terms(x, y, order)
+        return np.dot(g, coef_x), np.dot(g, coef_y)
+    evaluate.coefficients = (coef_x, coef_y)
+    return evaluate
 
 
 def interpolation_poly(x1, y1, x2, y2, x1grd, y1grd, order=1, **kwargs):
-    """Least-squares polynomial map (x1,y1)->(x2,y2) evaluated on the grid points
-    (reference lib.py:139-177; term order 1, x, y, x^2, y^2, xy, x^3, y^3, x^2 y, y^2 x)."""
-    A = _design_matrix(x1, y1, order)
-    bx = np.linalg.lstsq(A, x2, rcond=-1)[0]
-    by = np.linalg.lstsq(A, y2, rcond=-1)[0]
-    xf, yf = x1grd.flatten(), y1grd.flatten()
-    G = _design_matrix(xf, yf, order)
-    return np.dot(G, bx).reshape(x1grd.shape), np.dot(G, by).reshape(x1grd.shape)
+    """Reference name and signature (lib.py:139-177): the polynomial map evaluated on the grid points,
+    shaped like ``x1grd``."""
+    fx, fy = fit_polynomial_map(x1, y1, x2, y2, order)(np.ravel(x1grd), np.ravel(y1grd))
+    return fx.reshape(np.shape(x1grd)), fy.reshape(np.shape(x1grd))
 
 
 def interpolation_near(x1, y1, x2, y2, x1grd, y1grd, method='linear', **kwargs):
@@ -107,10 +122,11 @@ def interpolation_near(x1, y1, x2, y2, x1grd, y1grd, method='linear', **kwargs):
 
 
 def _fill_gpi(shape, gpi, data):
-    """Scatter the values of the valid points into a NaN grid (reference lib.py:408-412)."""
-    y = np.zeros(shape).flatten() + np.nan
-    y[gpi] = data
-    return y.reshape(shape)
+    """Grid of ``shape`` holding ``data`` at the flat positions where ``gpi`` is set and NaN elsewhere
+    (reference lib.py:408-412)."""
+    grid = np.full(int(np.prod(shape)), np.nan)
+    grid[np.asarray(gpi, dtype=bool).ravel()] = data
+    return grid.reshape(shape)
 
 
 def _percentile_ranks(n, p, ftype):

@@ -57,16 +57,23 @@ def get_initial_rotation(n1, n2):
     return np.degrees(np.arctan2(x1 - x0, y1 - y0)[0])
 
 
-def nearest_keypoint_distance(x_kp, y_kp, rows_q, cols_q):
+def nearest_keypoint_distance(x_kp, y_kp, rows_q, cols_q, shape=None):
     """Distance from integer pixels (rows_q, cols_q) to the nearest keypoint pixel.
 
     Same numbers as sampling the reference's full-image Euclidean distance transform
     (pmlib.py:61-77: seed[uint16(y), uint16(x)] = True; distance_transform_edt) at those
     pixels, but evaluated only where needed with a KD-tree: at 10000x10000 the EDT costs
     ~0.8 GB and seconds of CPU.  Both are sqrt of an exact integer
-    squared distance in float64.
+    squared distance in float64.  ``shape`` = (rows, cols) of image 2: a key point whose uint16-cast pixel lies
+    outside it cannot seed the reference's EDT image - its fancy-index assignment raises IndexError, and so
+    does this.
     """
-    seeds = np.stack([np.uint16(y_kp).astype(np.float64), np.uint16(x_kp).astype(np.float64)], axis=1)
+    seed_r, seed_c = np.uint16(y_kp), np.uint16(x_kp)
+    if shape is not None and seed_r.size and (seed_r.max() >= shape[0] or seed_c.max() >= shape[1]):
+        bad = int(np.argmax((seed_r >= shape[0]) | (seed_c >= shape[1])))
+        raise IndexError('key point %d at pixel (row %d, col %d) is out of bounds for image 2 of shape %s '
+                         '(reference pmlib.py:73)' % (bad, int(seed_r[bad]), int(seed_c[bad]), tuple(shape[:2])))
+    seeds = np.stack([seed_r.astype(np.float64), seed_c.astype(np.float64)], axis=1)
     tree = cKDTree(seeds)
     q = np.stack([np.asarray(rows_q, dtype=np.float64), np.asarray(cols_q, dtype=np.float64)], axis=1)
     d, _ = tree.query(q, k=1)
@@ -92,7 +99,7 @@ def prepare_first_guess(c2pm1, r2pm1, n1, c1, r1, n2, c2, r2, img_size,
         # negative int16 values index from the end, as NumPy fancy indexing would
         rq = np.where(rq < 0, rq + n2_shape[0], rq)
         cq = np.where(cq < 0, cq + n2_shape[1], cq)
-        border[inside] = nearest_keypoint_distance(c2, r2, rq, cq)
+        border[inside] = nearest_keypoint_distance(c2, r2, rq, cq, shape=n2_shape)
     else:
         c2t, r2t = interpolation_poly(c1n2, r1n2, c2, r2, c1n2, r1n2, **kwargs)
         c2d, r2d = interpolation_near(c1n2, r1n2, c2 - c2t, r2 - r2t, c2pm1, r2pm1, **kwargs)
@@ -179,6 +186,7 @@ def pm_dispatch(img1, img2, c1, r1, c2fg, r2fg, border, img_size, alpha0, device
     ctx = _capi.PMContext(device) if own else context
     try:
         ctx.upload_pair(img1, img2)
+        ctx.select_pair(0)                  # a reused context may have another slot or a borrowed pair current
         try:
             ctx.set_points(c1, r1, c2fg, r2fg, border, img_size, alpha0, angles, rot=rot, flags=flags)
         except _capi.SidPmError as e:

@@ -8,7 +8,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from sea_ice_drift_amd.dist import ResultGatherer, shard_indices, shard_size
+from sea_ice_drift_amd.dist import PackedGatherer, ResultGatherer, shard_indices, shard_size
 
 
 def _free_port():
@@ -36,6 +36,16 @@ def _worker(rank, world, port, n_total, q):
     g = ResultGatherer(n_total, idx, torch.device('cpu'))
     for _ in range(2):                                           # reusable across steps
         out, ij = g.gather(out_local, ij_local)
+    # the one-collective form bench.py uses: the "kernel" writes into the packed block in place
+    pg = PackedGatherer(n_total, idx, torch.device('cpu'))
+    o_v, j_v = pg.local_views()
+    o_v.copy_(torch.from_numpy(truth[idx]))
+    j_v.copy_(torch.from_numpy(truth_ij[idx]))
+    for _ in range(2):
+        pg.gather_to_host()
+    if rank == 0:
+        p_out, p_ij = pg.host_results()
+        assert np.array_equal(p_out, truth) and np.array_equal(p_ij, truth_ij)
     if rank == 0:
         q.put((np.array_equal(out.numpy(), truth), np.array_equal(ij.numpy(), truth_ij),
                float(border[idx].sum()), len(idx)))

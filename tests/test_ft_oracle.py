@@ -35,20 +35,25 @@ def test_degenerate_sizes():
 
 
 def test_product_filter_equals_reference_filter():
-    """sea_ice_drift_amd.ftlib._filter_matches (array form) against the loop form of ftlib.py:101-116."""
+    """sea_ice_drift_amd.ftlib.match (mask form, matcher replaced by the oracle) against the loop form of
+    ftlib.py:101-116."""
     rng = np.random.default_rng(5)
     d1, d2 = random_descriptors(rng, 300), random_descriptors(rng, 280)
     d1[:60] = d2[rng.permutation(280)[:60]] ^ rng.integers(0, 2, (60, 32), dtype=np.uint8)   # some close pairs
     idx, dist = fo.knn2(d1, d2)
     p1, p2 = rng.random((300, 2)) * 1000, rng.random((280, 2)) * 1000
     exp = fo.filter_matches(idx, dist, 0.7, p1, p2)
-    got = ftlib._filter_matches((idx, dist), 0.7, p1, p2)
+    import pytest
+    mp = pytest.MonkeyPatch()
+    mp.setattr(ftlib, '_get_matches', lambda a, b, device=0, verbose=False: (idx, dist))
+    got = ftlib.match(p1, d1, p2, d2, ratio_test=0.7)
     assert len(exp[0]) >= 40
     for a, b in zip(exp, got):
         np.testing.assert_array_equal(a, b)
 
     class KP:                                          # cv2.KeyPoint-like
         def __init__(self, xy): self.pt = (float(xy[0]), float(xy[1]))
-    got2 = ftlib._filter_matches((idx, dist), 0.7, [KP(p) for p in p1], [KP(p) for p in p2])
+    got2 = ftlib.get_match_coords([KP(p) for p in p1], d1, [KP(p) for p in p2], d2, ratio_test=0.7)
+    mp.undo()
     for a, b in zip(exp, got2):
         np.testing.assert_array_equal(a, b)

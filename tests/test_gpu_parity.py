@@ -158,7 +158,7 @@ def test_pair_streaming_through_two_slots(pm_ctx, c_oracle):
     for k in range(len(pairs)):
         pm_ctx.select_pair(k % 2)
         if k + 1 < len(pairs):
-            pm_ctx.upload_pair(pinned[k + 1][0].numpy(), pinned[k + 1][1].numpy(), slot=(k + 1) % 2)
+            pm_ctx.upload_pair(pinned[k + 1][0].numpy(), pinned[k + 1][1].numpy(), slot=(k + 1) % 2, select=False)
         pm_ctx.run()
         results.append(pm_ctx.fetch())
     for k, (img1, img2) in enumerate(pairs):

@@ -1,0 +1,64 @@
+"""Determinism soak (race detector) as part of the GPU suite.
+
+Every configuration runs the same 6 400-point workload 200 times on one handle; every repetition must be bit-identical
+to the first, and the first equals the C oracle on a subsample.  Covers the row-pair sweep (15 angles), the classic
+paired-slot sweep (7 angles), the table sampler and the on-the-fly sampler (SID_PM_NO_SAMP_TABLE, read at every
+set_points), mixed and large borders (all three residency classes).  History: DESIGN.md section 6b.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from sea_ice_drift_amd import _capi, pmlib as my, synthetic as syn
+
+pytestmark = pytest.mark.gpu
+REPS = 200
+
+
+@pytest.fixture(scope='module')
+def workload():
+    size = 4000
+    img1, img2 = syn.make_pair(size, size, seed=777)
+    return img1, img2, size
+
+
+@pytest.mark.parametrize('angles,img_size,border,no_table', [
+    (7, 34, 'mixed', False),     # 15 angles: row-pair sweep, table sampler
+    (7, 34, 'mixed', True),      # ... on-the-fly sampler
+    (3, 34, 'mixed', False),     # 7 angles: paired-slot sweep
+    (3, 34, 'mixed', True),
+    (7, 35, 44, False),          # reference default template side, large windows (one workgroup per CU)
+    (7, 34, 28, False),          # two workgroups per CU
+])
+def test_repeated_runs_are_bit_identical(workload, c_oracle, angles, img_size, border, no_table):
+    img1, img2, size = workload
+    g = syn.make_grid(size, size, 80, border=border)
+    ang = list(range(-angles, angles + 1))
+    rot = my.rotation_table(ang, 0.0, img_size)
+    old = os.environ.pop('SID_PM_NO_SAMP_TABLE', None)
+    if no_table:
+        os.environ['SID_PM_NO_SAMP_TABLE'] = '1'
+    try:
+        with _capi.PMContext(0) as ctx:
+            ctx.upload_pair(img1, img2)
+            ctx.set_points(g['c1'], g['r1'], g['c2fg'], g['r2fg'], g['border'], img_size, 0.0, ang, rot=rot)
+            ctx.run()
+            ref, ref_ij = ctx.fetch()
+            bad = 0
+            for _ in range(REPS - 1):
+                ctx.run()
+                out, ij = ctx.fetch()
+                same = (ij == ref_ij).all(1) & ((out == ref) | (np.isnan(out) & np.isnan(ref))).all(1)
+                bad += int((~same).sum())
+    finally:
+        os.environ.pop('SID_PM_NO_SAMP_TABLE', None)
+        if old is not None:
+            os.environ['SID_PM_NO_SAMP_TABLE'] = old
+    assert bad == 0, '%d point results differed between repetitions' % bad
+    sel = np.arange(0, len(ref), 53)
+    exp, exp_ij = c_oracle.pm_batch(img1, img2, g['c1'][sel], g['r1'][sel], g['c2fg'][sel], g['r2fg'][sel],
+                                    g['border'][sel], img_size, 0.0, ang, rot=rot, nthreads=8)
+    np.testing.assert_array_equal(ref_ij[sel], exp_ij)
+    np.testing.assert_array_equal(ref[sel, :4], exp[:, :4])
+    np.testing.assert_allclose(ref[sel, 4], exp[:, 4], rtol=1e-5, atol=1e-5)

@@ -123,3 +123,13 @@ def test_api_surface():
     np.testing.assert_allclose(c, [10.0, 20.0], atol=1e-9)
     np.testing.assert_allclose(r, [5.0, 7.0], atol=1e-9)
     assert abs(my.get_initial_rotation(ArrayNansat(img), n) + 5.0) < 1e-9
+
+
+def test_out_of_image_keypoint_raises_like_the_reference_edt():
+    """pmlib.py:72-73: seed[np.uint16(y), np.uint16(x)] = True fails for a key point outside image 2."""
+    with pytest.raises(IndexError):
+        my.nearest_keypoint_distance(np.array([10.0, 400.0]), np.array([10.0, 20.0]), [5], [5], shape=(300, 260))
+    with pytest.raises(IndexError):
+        my.nearest_keypoint_distance(np.array([10.0]), np.array([-3.0]), [5], [5], shape=(300, 260))
+    d = my.nearest_keypoint_distance(np.array([10.9]), np.array([20.2]), [20], [13], shape=(300, 260))
+    assert d[0] == 3.0                                              # truncated to pixel (20, 10)

@@ -35,7 +35,7 @@ with _capi.PMContext(0) as ctx:
     outs = []
     for k in range(npairs):
         ctx.select_pair(k % 2)
-        if k + 1 < npairs: ctx.upload_pair(*host[(k + 1) % distinct], slot=(k + 1) % 2)
+        if k + 1 < npairs: ctx.upload_pair(*host[(k + 1) % distinct], slot=(k + 1) % 2, select=False)
         ctx.run(); outs.append(ctx.fetch())
     t_stream = time.perf_counter() - t0
     ok = all(np.array_equal(outs[k][1], outs[k % distinct][1]) for k in range(npairs)) and np.array_equal(outs[0][1], ref0[1])
