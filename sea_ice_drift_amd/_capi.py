@@ -32,6 +32,9 @@ FT_SYMBOLS = ('sid_ft_knn2', 'sid_ft_knn2_device', 'sid_ft_workspace_bytes', 'si
 # every symbol include/sid_stage.h declares (uint8 staging, same library)
 STAGE_SYMBOLS = ('sid_stage_count_valid', 'sid_stage_order_stats', 'sid_stage_scale_u8', 'sid_stage_last_error')
 
+# every symbol include/sid_orb.h declares (key-point detector, same library)
+ORB_SYMBOLS = ('sid_orb_detect', 'sid_orb_last_error')
+
 _u8p = C.POINTER(C.c_uint8)
 _f64p = C.POINTER(C.c_double)
 _f32p = C.POINTER(C.c_float)
@@ -55,6 +58,12 @@ def lib():
             '%s not found: build it with `make -C %s` (hipcc --offload-arch=gfx950) or '
             '`python -c "import __graft_entry__ as g; g.build()"`. There is no CPU fallback.'
             % (LIB_PATH, os.path.join(_HERE, 'csrc')))
+    try:                                      # torch first: its wheel carries its own HIP runtime (same soname), and the
+        import torch                          # process must end up with one copy - torch cannot enumerate the GPU after
+        if torch.cuda.is_available():         # the system runtime has initialised it ("No HIP GPUs are available")
+            torch.cuda.init()
+    except ImportError:
+        pass
     L = C.CDLL(LIB_PATH)
     img = [_u8p, C.c_int64, C.c_int64, C.c_int64]
     ptr = [C.c_void_p, C.c_int64, C.c_int64, C.c_int64]
@@ -95,6 +104,9 @@ def lib():
     L.sid_stage_scale_u8.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_float, C.c_float, C.c_void_p,
                                      C.c_int64, C.c_void_p]
     L.sid_stage_last_error.restype = C.c_char_p
+    L.sid_orb_detect.argtypes = [C.c_int, _u8p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.POINTER(C.c_int8), _i32p,
+                                 _f32p, _i32p, C.POINTER(C.c_int64), _u8p, C.c_int64, C.POINTER(C.c_int64)]
+    L.sid_orb_last_error.restype = C.c_char_p
     for name in SYMBOLS:
         getattr(L, name)                      # AttributeError here = header/library mismatch
     if L.sid_pm_abi_version() != ABI_VERSION:

@@ -1,0 +1,276 @@
+// orb.hip - key points and 256-bit descriptors on gfx950 (C ABI: include/sid_orb.h; serves the interface of the
+// reference's ftlib.find_key_points, ftlib.py:26-61, whose arithmetic is OpenCV's ORB and is not reproduced - see
+// the header).  Every step is integer arithmetic with the specification of oracle/orb_oracle.py.
+//
+// Data flow per pyramid level: resample -> FAST-9 score map -> 3x3 non-maximum suppression + Harris response ->
+// candidate list (device) -> host: sort by (response desc, y, x), keep the level's share -> device: orientation
+// (intensity centroid, 32 directions) -> binomial blur -> 256 comparisons through the pre-rotated pattern.
+// All kernels are streaming passes over uint8 images (one thread per pixel or per key point); the detector runs once
+// per image and is a small part of the feature-tracking + pattern-matching chain (tools/ftpm_bench.py).
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdarg.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <algorithm>
+#include <vector>
+
+#include "../../include/sid_orb.h"
+#include "../../include/sid_pm.h"
+
+#define SID_EXPORT extern "C" __attribute__((visibility("default")))
+
+namespace {
+
+thread_local char g_err[256] = "";
+int fail(int code, const char *fmt, ...)
+{
+    va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof g_err, fmt, ap); va_end(ap);
+    return code;
+}
+#define HIP_TRY(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { rc = fail(SID_PM_ERR_HIP, "%s: %s", #x, hipGetErrorString(e_)); goto done; } } while (0)
+
+struct Cand { int32_t x, y; long long resp; };
+
+// ---- level l of the pyramid from level 0: 16.16 fixed-point source coordinates, 8-bit bilinear weights ----
+__global__ void k_resize(const uint8_t *src, int rows0, int cols0, long long stride0, uint8_t *dst, int rows, int cols,
+                         unsigned long long step_x, unsigned long long step_y)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= cols || y >= rows) return;
+    long long fx = (long long)x * (long long)step_x + (long long)(step_x >> 1) - 32768;
+    long long fy = (long long)y * (long long)step_y + (long long)(step_y >> 1) - 32768;
+    const long long mx = (long long)(cols0 - 1) << 16, my = (long long)(rows0 - 1) << 16;
+    fx = fx < 0 ? 0 : (fx > mx ? mx : fx);
+    fy = fy < 0 ? 0 : (fy > my ? my : fy);
+    const int x0 = (int)(fx >> 16), y0 = (int)(fy >> 16);
+    const int wx = (int)((fx >> 8) & 255), wy = (int)((fy >> 8) & 255);
+    const int x1 = x0 + 1 < cols0 ? x0 + 1 : cols0 - 1, y1 = y0 + 1 < rows0 ? y0 + 1 : rows0 - 1;
+    const int a = src[y0 * stride0 + x0], b = src[y0 * stride0 + x1], c = src[y1 * stride0 + x0], d = src[y1 * stride0 + x1];
+    const int top = a * (256 - wx) + b * wx, bot = c * (256 - wx) + d * wx;
+    dst[(long long)y * cols + x] = (uint8_t)((top * (256 - wy) + bot * wy + 32768) >> 16);
+}
+
+// ---- FAST-9 score (0 = no corner at threshold t) ----
+__constant__ int8_t c_ring[16][2] = {{0, -3}, {1, -3}, {2, -2}, {3, -1}, {3, 0}, {3, 1}, {2, 2}, {1, 3},
+                                     {0, 3}, {-1, 3}, {-2, 2}, {-3, 1}, {-3, 0}, {-3, -1}, {-2, -2}, {-1, -3}};
+
+__global__ void k_fast(const uint8_t *img, int rows, int cols, int edge, int t, uint8_t *score)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= cols || y >= rows) return;
+    int sc = 0;
+    if (x >= edge && x < cols - edge && y >= edge && y < rows - edge) {
+        const uint8_t *p = img + (long long)y * cols + x;
+        const int c = p[0];
+        int d[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) d[i] = (int)p[c_ring[i][1] * cols + c_ring[i][0]] - c;
+        // quick reject: a 9-arc contains at least two of the four compass points on either side
+        int best = -256;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            int mb = 255, md = 255;
+#pragma unroll
+            for (int k = 0; k < 9; ++k) { const int v = d[(s + k) & 15]; mb = v < mb ? v : mb; md = -v < md ? -v : md; }
+            const int m = mb > md ? mb : md;
+            best = m > best ? m : best;
+        }
+        sc = best > t ? best : 0;
+    }
+    score[(long long)y * cols + x] = (uint8_t)sc;
+}
+
+// ---- 3x3 non-maximum suppression + Harris response -> candidate list ----
+__global__ void k_nms_harris(const uint8_t *img, const uint8_t *score, int rows, int cols, int edge, Cand *out,
+                             unsigned int *count, unsigned int cap)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x < edge || x >= cols - edge || y < edge || y >= rows - edge) return;
+    const uint8_t *s = score + (long long)y * cols + x;
+    const int v = s[0];
+    if (v == 0) return;
+    if (!(v > s[-1] && v > s[1] && v > s[-cols] && v > s[cols] && v > s[-cols - 1] && v > s[-cols + 1] &&
+          v > s[cols - 1] && v > s[cols + 1])) return;
+    long long a = 0, b = 0, c = 0;
+    for (int dy = -3; dy <= 3; ++dy) {
+        const uint8_t *p = img + (long long)(y + dy) * cols + x;
+        for (int dx = -3; dx <= 3; ++dx) {
+            const int ix = (int)p[dx + 1] - (int)p[dx - 1], iy = (int)p[dx + cols] - (int)p[dx - cols];
+            a += ix * ix; b += iy * iy; c += ix * iy;
+        }
+    }
+    const long long resp = 25 * (a * b - c * c) - (a + b) * (a + b);
+    const unsigned int k = atomicAdd(count, 1u);
+    if (k < cap) { out[k].x = x; out[k].y = y; out[k].resp = resp; }
+}
+
+// ---- orientation: intensity centroid over the disc of radius R, quantised to 32 directions ----
+__global__ void k_orient(const uint8_t *img, int cols, const int32_t *kp /* [n][4]: x, y, level, dir */, int n, int R,
+                         const int32_t *dirs, int32_t *dir_out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int x = kp[4 * i], y = kp[4 * i + 1];
+    long long m10 = 0, m01 = 0;
+    for (int dy = -R; dy <= R; ++dy) {
+        const uint8_t *p = img + (long long)(y + dy) * cols + x;
+        for (int dx = -R; dx <= R; ++dx)
+            if (dx * dx + dy * dy <= R * R) { const int v = p[dx]; m10 += dx * v; m01 += dy * v; }
+    }
+    int best = 0; long long bv = m10 * dirs[0] + m01 * dirs[1];
+    for (int b = 1; b < 32; ++b) { const long long v = m10 * dirs[2 * b] + m01 * dirs[2 * b + 1]; if (v > bv) { bv = v; best = b; } }
+    dir_out[i] = best;
+}
+
+// ---- 5x5 binomial blur (1 4 6 4 1 / 16 per axis, replicated borders, round half up once) ----
+__global__ void k_blur(const uint8_t *img, int rows, int cols, uint8_t *out)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= cols || y >= rows) return;
+    const int w[5] = {1, 4, 6, 4, 1};
+    int acc = 0;
+#pragma unroll
+    for (int j = -2; j <= 2; ++j) {
+        const int yy = y + j < 0 ? 0 : (y + j >= rows ? rows - 1 : y + j);
+        const uint8_t *p = img + (long long)yy * cols;
+        int h = 0;
+#pragma unroll
+        for (int k = -2; k <= 2; ++k) { const int xx = x + k < 0 ? 0 : (x + k >= cols ? cols - 1 : x + k); h += w[k + 2] * p[xx]; }
+        acc += w[j + 2] * h;
+    }
+    out[(long long)y * cols + x] = (uint8_t)((acc + 128) >> 8);
+}
+
+// ---- descriptor: 256 comparisons through the pattern of the key point's direction; one wavefront per key point ----
+__global__ void k_describe(const uint8_t *blur, int cols, const int32_t *kp, const int32_t *dir, int n, const int8_t *pattern,
+                           uint8_t *desc)
+{
+    const int i = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (i >= n) return;
+    const int x = kp[4 * i], y = kp[4 * i + 1];
+    const int8_t *pt = pattern + (long long)dir[i] * 1024;
+    const uint8_t *c = blur + (long long)y * cols + x;
+    uint32_t bits = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {                                      // lane handles bits 4 lane .. 4 lane + 3
+        const int8_t *q = pt + 4 * (4 * lane + k);
+        const int a = c[q[1] * cols + q[0]], b = c[q[3] * cols + q[2]];
+        bits |= (a < b ? 1u : 0u) << k;
+    }
+    // two lanes make a byte (bits 8 j .. 8 j + 7, least significant first)
+    const uint32_t hi = __shfl_down(bits, 1);
+    if (!(lane & 1)) desc[(long long)i * 32 + (lane >> 1)] = (uint8_t)(bits | (hi << 4));
+}
+
+}  // namespace
+
+SID_EXPORT const char *sid_orb_last_error(void) { return g_err; }
+
+SID_EXPORT int sid_orb_detect(int device, const uint8_t *img, int64_t rows, int64_t cols, int64_t stride,
+                              const sid_orb_params *P, const int8_t *pattern, const int32_t *dirs,
+                              float *xy, int32_t *meta, int64_t *response, uint8_t *desc, int64_t max_out, int64_t *n_out)
+{
+    if (!img || !P || !pattern || !dirs || !xy || !desc || !n_out || max_out < 0) return fail(SID_PM_ERR_ARG, "null argument");
+    if (rows < 1 || cols < 1 || stride < cols || rows > 65535 || cols > 65535) return fail(SID_PM_ERR_ARG, "bad image shape/stride");
+    if (P->n_levels < 1 || P->n_levels > 16 || P->edge_threshold < 16 || P->patch_size < 2 || P->patch_size / 2 + 1 > P->edge_threshold ||
+        P->n_features < 0 || P->fast_threshold < 1 || P->fast_threshold > 254 || !(P->scale_factor > 1.0f))
+        return fail(SID_PM_ERR_ARG, "bad detector parameters (edge_threshold >= 16 and >= patch_size / 2 + 1, 1..16 levels, scale > 1)");
+    *n_out = 0;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return fail(SID_PM_ERR_NODEVICE, "no such HIP device");
+    int prev = 0; (void)hipGetDevice(&prev); (void)hipSetDevice(device);
+    int rc = SID_PM_OK;
+    const int L = P->n_levels, edge = P->edge_threshold, R = P->patch_size / 2;
+    uint8_t *d_img0 = nullptr, *d_lvl = nullptr, *d_aux = nullptr, *d_desc = nullptr;
+    Cand *d_cand = nullptr; unsigned int *d_count = nullptr;
+    int8_t *d_pat = nullptr; int32_t *d_dirs = nullptr, *d_kp = nullptr, *d_dir = nullptr;
+    std::vector<Cand> cand;
+    std::vector<int32_t> kp, dir_h;
+    std::vector<uint8_t> desc_h;
+    int64_t total = 0;
+    {
+        // level geometry and the per-level share of n_features (OpenCV's geometric split), all in double
+        std::vector<double> sc(L); std::vector<int> lr(L), lc(L), want(L);
+        double s = 1.0;
+        for (int l = 0; l < L; ++l) { sc[l] = s; lr[l] = (int)floor((double)rows / s + 0.5); lc[l] = (int)floor((double)cols / s + 0.5); s *= (double)P->scale_factor; }
+        {
+            const double factor = 1.0 / (double)P->scale_factor;
+            double nd = (double)P->n_features * (1.0 - factor) / (1.0 - pow(factor, (double)L));
+            int sum = 0;
+            for (int l = 0; l < L - 1; ++l) { want[l] = (int)floor(nd + 0.5); sum += want[l]; nd *= factor; }
+            want[L - 1] = std::max(P->n_features - sum, 0);
+        }
+        const size_t area0 = (size_t)rows * cols;
+        HIP_TRY(hipMalloc(&d_img0, area0));
+        HIP_TRY(hipMalloc(&d_lvl, area0));
+        HIP_TRY(hipMalloc(&d_aux, area0));
+        HIP_TRY(hipMalloc(&d_cand, (area0 / 4 + 16) * sizeof(Cand)));
+        HIP_TRY(hipMalloc(&d_count, sizeof(unsigned int)));
+        HIP_TRY(hipMalloc(&d_pat, 32 * 1024));
+        HIP_TRY(hipMalloc(&d_dirs, 64 * sizeof(int32_t)));
+        HIP_TRY(hipMemcpy2D(d_img0, (size_t)cols, img, (size_t)stride, (size_t)cols, (size_t)rows, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(d_pat, pattern, 32 * 1024, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(d_dirs, dirs, 64 * sizeof(int32_t), hipMemcpyHostToDevice));
+        for (int l = 0; l < L && total < max_out; ++l) {
+            const int r = lr[l], c = lc[l];
+            if (r <= 2 * edge || c <= 2 * edge || want[l] <= 0) continue;
+            const dim3 blk(256), grd((unsigned)((c + 255) / 256), (unsigned)r);
+            const uint8_t *lvl = d_img0;
+            if (l > 0) {
+                const unsigned long long sx = ((unsigned long long)cols << 16) / (unsigned long long)c,
+                                         sy = ((unsigned long long)rows << 16) / (unsigned long long)r;
+                hipLaunchKernelGGL(k_resize, grd, blk, 0, 0, d_img0, (int)rows, (int)cols, (long long)cols, d_lvl, r, c, sx, sy);
+                lvl = d_lvl;
+            }
+            hipLaunchKernelGGL(k_fast, grd, blk, 0, 0, lvl, r, c, edge, P->fast_threshold, d_aux);
+            HIP_TRY(hipMemset(d_count, 0, sizeof(unsigned int)));
+            const unsigned int cap = (unsigned int)((size_t)r * c / 4 + 16);
+            hipLaunchKernelGGL(k_nms_harris, grd, blk, 0, 0, lvl, d_aux, r, c, edge, d_cand, d_count, cap);
+            unsigned int nc = 0;
+            HIP_TRY(hipMemcpy(&nc, d_count, sizeof nc, hipMemcpyDeviceToHost));
+            if (nc > cap) { rc = fail(SID_PM_ERR_HIP, "candidate list overflow (cannot happen: one maximum per 2x2 block)"); goto done; }
+            if (nc == 0) continue;
+            cand.resize(nc);
+            HIP_TRY(hipMemcpy(cand.data(), d_cand, (size_t)nc * sizeof(Cand), hipMemcpyDeviceToHost));
+            std::sort(cand.begin(), cand.end(), [](const Cand &p, const Cand &q) {
+                if (p.resp != q.resp) return p.resp > q.resp;
+                if (p.y != q.y) return p.y < q.y;
+                return p.x < q.x;
+            });
+            int64_t n = std::min<int64_t>(std::min<int64_t>(nc, want[l]), max_out - total);
+            kp.resize((size_t)(4 * n));
+            for (int64_t i = 0; i < n; ++i) { kp[4 * i] = cand[(size_t)i].x; kp[4 * i + 1] = cand[(size_t)i].y; kp[4 * i + 2] = l; kp[4 * i + 3] = 0; }
+            if (d_kp) { (void)hipFree(d_kp); d_kp = nullptr; }
+            if (d_dir) { (void)hipFree(d_dir); d_dir = nullptr; }
+            if (d_desc) { (void)hipFree(d_desc); d_desc = nullptr; }
+            HIP_TRY(hipMalloc(&d_kp, (size_t)(4 * n) * sizeof(int32_t)));
+            HIP_TRY(hipMalloc(&d_dir, (size_t)n * sizeof(int32_t)));
+            HIP_TRY(hipMalloc(&d_desc, (size_t)n * 32));
+            HIP_TRY(hipMemcpy(d_kp, kp.data(), (size_t)(4 * n) * sizeof(int32_t), hipMemcpyHostToDevice));
+            hipLaunchKernelGGL(k_orient, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, lvl, c, d_kp, (int)n, R, d_dirs, d_dir);
+            hipLaunchKernelGGL(k_blur, grd, blk, 0, 0, lvl, r, c, d_aux);                 // the score map is no longer needed
+            hipLaunchKernelGGL(k_describe, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, 0, d_aux, c, d_kp, d_dir, (int)n, d_pat, d_desc);
+            HIP_TRY(hipGetLastError());
+            dir_h.resize((size_t)n); desc_h.resize((size_t)n * 32);
+            HIP_TRY(hipMemcpy(dir_h.data(), d_dir, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost));
+            HIP_TRY(hipMemcpy(desc_h.data(), d_desc, (size_t)n * 32, hipMemcpyDeviceToHost));
+            for (int64_t i = 0; i < n; ++i) {
+                const int64_t o = total + i;
+                xy[2 * o] = (float)((double)cand[(size_t)i].x * sc[l]);
+                xy[2 * o + 1] = (float)((double)cand[(size_t)i].y * sc[l]);
+                if (meta) { meta[4 * o] = cand[(size_t)i].x; meta[4 * o + 1] = cand[(size_t)i].y; meta[4 * o + 2] = l; meta[4 * o + 3] = dir_h[(size_t)i]; }
+                if (response) response[o] = cand[(size_t)i].resp;
+            }
+            memcpy(desc + total * 32, desc_h.data(), (size_t)n * 32);
+            total += n;
+        }
+        *n_out = total;
+    }
+done:
+    (void)hipFree(d_img0); (void)hipFree(d_lvl); (void)hipFree(d_aux); (void)hipFree(d_cand); (void)hipFree(d_count);
+    (void)hipFree(d_pat); (void)hipFree(d_dirs); (void)hipFree(d_kp); (void)hipFree(d_dir); (void)hipFree(d_desc);
+    (void)hipSetDevice(prev);
+    return rc;
+}

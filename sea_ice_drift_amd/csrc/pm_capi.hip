@@ -99,6 +99,7 @@ struct sid_pm_ctx {
     int64_t cls_rows2 = -1, cls_cols2 = -1;
     DevBuf<double> out;
     DevBuf<int32_t> out_ij;
+    DevBuf<int32_t> dbg_err;            // debugging builds only (SID_PM_DEBUG_CHECK=1)
     double *user_out = nullptr;         // caller-owned result arrays (bind_results)
     int32_t *user_ij = nullptr;
     std::vector<Bucket> buckets;
@@ -257,6 +258,10 @@ int fill_args(sid_pm_ctx *ctx, sid::PMArgs &A)
     A.angles = ctx->d_angles; A.rot = ctx->d_rot; A.samp = ctx->have_samp ? ctx->d_samp : nullptr; A.samp_nflag = ctx->samp_nflag;
     A.out = ctx->user_out ? ctx->user_out : ctx->out.p;
     A.out_ij = ctx->user_out ? ctx->user_ij : ctx->out_ij.p;
+    if (getenv("SID_PM_DEBUG_CHECK")) {
+        if (!ctx->dbg_err.p && ctx->dbg_err.reserve(320) == SID_PM_OK) (void)hipMemset(ctx->dbg_err.p, 0, 320 * sizeof(int32_t));
+        A.dbg_err = ctx->dbg_err.p;
+    }
     return SID_PM_OK;
 }
 
@@ -431,7 +436,7 @@ SID_EXPORT void sid_pm_destroy(sid_pm_ctx *ctx)
     }
     for (auto &pair : ctx->own) for (auto &b : pair) b.release();
     ctx->arena.release();
-    ctx->out.release(); ctx->out_ij.release();
+    ctx->out.release(); ctx->out_ij.release(); ctx->dbg_err.release();
     delete ctx;
 }
 
@@ -579,15 +584,17 @@ SID_EXPORT int sid_pm_run(sid_pm_ctx *ctx)
     for (const Bucket &b : ctx->buckets) {
         A.order = ctx->d_order + b.offset;
         A.n_launch = b.count;
-        A.lds_bytes = b.lds;
+        static const int lds_pad = getenv("SID_PM_LDS_PAD") ? atoi(getenv("SID_PM_LDS_PAD")) : 0;   // debugging aid (race hunt)
+        const int lds_launch = std::min(b.lds + lds_pad, sid::max_lds_bytes());
+        A.lds_bytes = lds_launch;
         // 256 threads per point; 768 when the LDS footprint leaves room for one point per CU only, so that
         // the CU still carries 12 wavefronts (3 per SIMD = the register budget).  (Measured: 384- and
         // 512-thread groups lose to 2 x 256 - they do not pack onto the SIMDs and serialise the phases.)
         const int per_cu = std::max(1, std::min(b.band == 8 ? 2 : 8, blocks_per_cu(b.lds)));
         const int nthreads = b.band == 8 ? 256 : (per_cu == 1 ? 768 : 256);
         const int e = use_rp(ctx->img_size, ctx->n_angles)
-                          ? sid::launch_pm_rp(A, b.lds, nthreads, ctx->stream)
-                          : sid::launch_pm_mfma(A, b.lds, nthreads, b.band, use_paired(ctx->n_angles), ctx->stream);
+                          ? sid::launch_pm_rp(A, lds_launch, nthreads, ctx->stream)
+                          : sid::launch_pm_mfma(A, lds_launch, nthreads, b.band, use_paired(ctx->n_angles), ctx->stream);
         if (e != 0) return fail(SID_PM_ERR_HIP, "kernel launch failed: %s", hipGetErrorString((hipError_t)e));
     }
     if (ctx->cur_slot >= 0) {
@@ -619,6 +626,21 @@ SID_EXPORT int sid_pm_fetch(sid_pm_ctx *ctx, double *out, int32_t *out_ij)
             HIP_TRY(hipMemcpyAsync(out_ij, src_ij, sizeof(int32_t) * 3 * (size_t)ctx->n, hipMemcpyDeviceToHost, ctx->stream));
     }
     HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (ctx->dbg_err.p) {
+        int32_t e[320];
+        if (hipMemcpy(e, ctx->dbg_err.p, sizeof e, hipMemcpyDeviceToHost) == hipSuccess && (e[0] || e[1] || e[2] || e[3])) {
+            if (e[4] > 0) {
+                fprintf(stderr, "first event, (i,j got want):");
+                for (int k = 0; k < e[4] && k < 200; ++k) fprintf(stderr, " (%d,%d %d %d)", (e[64 + k] >> 24) & 255, (e[64 + k] >> 16) & 255, (e[64 + k] >> 8) & 255, e[64 + k] & 255);
+                fprintf(stderr, "\n");
+            }
+            fprintf(stderr, "SID_PM_DEBUG_CHECK: sum mismatches after sampling %d, after sweep %d; table bytes != exact resampling %d (pt %d slot %d n %d); patch bytes != image %d;", e[0], e[1], e[2], e[40], e[41], e[42], e[3]);
+            for (int t = 0; t < 2; ++t) for (int k = 0; k < 4 && k < e[t]; ++k)
+                fprintf(stderr, " [tag %d pt %d slot %d dST %d dSTT %d]", t, e[8 + 16 * t + 4 * k], e[9 + 16 * t + 4 * k], e[10 + 16 * t + 4 * k], e[11 + 16 * t + 4 * k]);
+            fprintf(stderr, "\n");
+            (void)hipMemset(ctx->dbg_err.p, 0, sizeof e);
+        }
+    }
     return SID_PM_OK;
 }
 

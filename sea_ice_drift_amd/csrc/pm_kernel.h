@@ -31,6 +31,7 @@ struct PMArgs {
     // diagnostics (debug_point only; null in production launches)
     uint8_t *dbg_templates; float *dbg_ccm; float *dbg_hes; int32_t *dbg_shape; int64_t dbg_cap;
     long long *dbg_cycles;                          // [16] shader-clock stamps at phase boundaries
+    int32_t *dbg_err;                               // [64] consistency-check counters of debugging builds (SID_DBG_CHECK); null otherwise
 };
 
 __host__ __device__ inline int round_up(int v, int m) { return (v + m - 1) / m * m; }

@@ -72,8 +72,13 @@ struct MiscM {                       // LDS offset 0, kMiscMfmaBytes reserved
     double sTd[kMaxAngles];          // sum t' per angle
     float rTf[kMaxAngles];
     int constT[kMaxAngles];
-    // row-pair kernel: float32 pre-filter terms of the current group's slots (pm_kernel_rp.inc)
-    int mTi[kSlots]; float cTf[kSlots], aTf[kSlots];
+    // row-pair kernel: float32 pre-filter terms of the current group's slots (pm_kernel_rp.inc), 16-byte aligned:
+    // a lane fetches the terms of its four slots with one ds_read_b128 each
+    __attribute__((aligned(16))) int nmTi[kSlots];      // -round(S_T' / N)
+    __attribute__((aligned(16))) float ncTf[kSlots];    // -(S_T' - N round(S_T' / N)) / N
+    __attribute__((aligned(16))) float aTf[kSlots];     // N / sqrt(dT); NaN: constant template; 0: dead slot
+    __attribute__((aligned(16))) float biasf[kSlots];   // 0, or -inf for a dead slot
+    float maxA;
     int any_const;
 };
 
@@ -1295,31 +1300,51 @@ __device__ __noinline__ void ph_hessian(unsigned flags, int iy, int ix, float be
             const float gm = (fc - fd) * ((km > 0 && km < n - 1) ? 0.5f : 1.0f);
             return (gp - gm) * ((k > 0 && k < n - 1) ? 0.5f : 1.0f);
         };
-        // four placements per thread in flight: the chains (index arithmetic -> 8 LDS reads -> double sqrt)
-        // are long and independent, so their latencies overlap; y = idx / rw through the reciprocal
-        const u32 magic = G.rw_magic;
+        // Interior placements (two or more away from every edge: 80-90 % of the matrix) need no index clamping
+        // and only five reads: g(k+1) = (f[k+2] - f[k]) / 2 and g(k-1) = (f[k] - f[k-2]) / 2 are central differences
+        // themselves, d2 = (g(k+1) - g(k-1)) / 2 - the same float32 operations np.gradient performs there.
+        // The frame of width two around them takes the general form.  Four placements per thread in flight.
         constexpr int kHes = 4;
-        for (int base = 0; base < npos; base += kHes * kBlockM) {
-            float hv[kHes];
+        auto emit = [&](int idx, float d2x, float d2y) {
+            const double hh = (double)d2x * (double)d2x + (double)d2y * (double)d2y;
+            const float hv = (float)sqrt(hh);                          // hypotf: double sqrt, narrowed
+            hes[idx] = hv;
+            sx += (double)hv; sxx += (double)hv * (double)hv;
+            hmin = fminf(hmin, hv); hmax = fmaxf(hmax, hv);
+        };
+        const int iw = rw - 4, ih = rh - 4;
+        if (iw > 0 && ih > 0) {
+            const u32 imagic = 0xffffffffu / (u32)iw + 1u;
+            const int nin = iw * ih;
+            for (int base = 0; base < nin; base += kHes * kBlockM) {
+                float d2xv[kHes], d2yv[kHes];
 #pragma unroll
-            for (int u = 0; u < kHes; ++u) {
-                const int idx = base + u * kBlockM + tid;
-                const int idc = idx < npos ? idx : 0;
-                const int y = (int)__umulhi((u32)idc, magic), x = idc - y * rw;
-                const float d2x = d2(ccm + y * rw, 1, x, rw);
-                const float d2y = d2(ccm + x, rw, y, rh);
-                const double hh = (double)d2x * (double)d2x + (double)d2y * (double)d2y;
-                hv[u] = (float)sqrt(hh);                               // hypotf: double sqrt, narrowed
-            }
+                for (int u = 0; u < kHes; ++u) {
+                    const int q = base + u * kBlockM + tid;
+                    const int qc = q < nin ? q : 0;
+                    const int yy = (int)__umulhi((u32)qc, imagic), xx = qc - yy * iw;
+                    const float *f = ccm + (yy + 2) * rw + (xx + 2);
+                    const float c = f[0], xr = f[2], xl = f[-2], yd = f[2 * rw], yu = f[-2 * rw];
+                    d2xv[u] = ((xr - c) * 0.5f - (c - xl) * 0.5f) * 0.5f;
+                    d2yv[u] = ((yd - c) * 0.5f - (c - yu) * 0.5f) * 0.5f;
+                }
 #pragma unroll
-            for (int u = 0; u < kHes; ++u) {
-                const int idx = base + u * kBlockM + tid;
-                if (idx < npos) {
-                    hes[idx] = hv[u];
-                    sx += (double)hv[u]; sxx += (double)hv[u] * (double)hv[u];
-                    hmin = fminf(hmin, hv[u]); hmax = fmaxf(hmax, hv[u]);
+                for (int u = 0; u < kHes; ++u) {
+                    const int q = base + u * kBlockM + tid;
+                    if (q < nin) { const int yy = (int)__umulhi((u32)q, imagic), xx = q - yy * iw; emit((yy + 2) * rw + xx + 2, d2xv[u], d2yv[u]); }
                 }
             }
+        }
+        // frame: rows 0, 1, rh-2, rh-1 in full, columns 0, 1, rw-2, rw-1 of the rows between (everything when the
+        // matrix is too small to have an interior)
+        const bool has_in = iw > 0 && ih > 0;
+        const int nfr = has_in ? 4 * rw + 4 * ih : npos;
+        for (int q = tid; q < nfr; q += kBlockM) {
+            int y, x;
+            if (!has_in) { y = q / rw; x = q - y * rw; }
+            else if (q < 4 * rw) { const int rr = q / rw; x = q - rr * rw; y = rr < 2 ? rr : rh - 4 + rr; }
+            else { const int e = q - 4 * rw; const int yy = e >> 2, cc = e & 3; y = yy + 2; x = cc < 2 ? cc : rw - 4 + cc; }
+            emit(y * rw + x, d2(ccm + y * rw, 1, x, rw), d2(ccm + x, rw, y, rh));
         }
     }
     __syncthreads();

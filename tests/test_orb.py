@@ -1,0 +1,68 @@
+"""Key-point detector (the ORB half): the NumPy oracle of the package's own specification on the CPU,
+and on the GPU the kernels against that oracle bit for bit, then the whole feature-tracking chain on a synthetic
+pair with a known displacement field.  Parity with OpenCV's ORB is unpinned by construction (cv2 absent)."""
+import numpy as np
+import pytest
+
+from oracle import orb_oracle as oo
+from sea_ice_drift_amd import orb, synthetic as syn
+
+
+def test_tables_are_well_formed():
+    d = orb.direction_table()
+    assert d.shape == (32, 2) and d[0].tolist() == [16384, 0] and d[8].tolist() == [0, 16384]
+    p = orb.rotated_pattern()
+    assert p.shape == (32, 256, 4) and p.dtype == np.int8
+    assert (np.abs(p.astype(int)) <= 14).all()
+    assert not ((p[0, :, 0] == p[0, :, 2]) & (p[0, :, 1] == p[0, :, 3])).any()
+    # direction 8 is a quarter turn: (x, y) -> (-y, x)
+    np.testing.assert_array_equal(p[8, :, 0], -p[0, :, 1])
+    np.testing.assert_array_equal(p[8, :, 1], p[0, :, 0])
+
+
+def test_oracle_finds_planted_corners_and_their_orientation():
+    img = np.full((200, 220), 60, dtype=np.uint8)
+    img[80:, 100:] = 200                                           # one bright quadrant: a corner at (100, 80)
+    xy, meta, resp, desc = oo.detect_and_compute(img, orb.rotated_pattern(), orb.direction_table(), n_levels=1,
+                                                 n_features=50)
+    assert len(xy) >= 1
+    d = np.hypot(xy[:, 0] - 100, xy[:, 1] - 80)
+    k = int(np.argmin(d))
+    assert d[k] <= 3
+    # the bright mass lies towards +x, +y: direction index near 4 (45 degrees)
+    assert meta[k, 3] in (3, 4, 5)
+    assert desc.shape[1] == 32 and (resp[:-1] >= resp[1:]).all()
+
+
+def test_oracle_level_split_matches_opencv_rule():
+    sc, lr, lc, want = oo.level_geometry(1000, 800, 7, 1.2, 1000)
+    assert sum(want) == 1000 and want[0] > want[1] > want[5] and lr[0] == 1000 and lc[1] == 667
+    np.testing.assert_allclose(sc[3], float(np.float32(1.2)) ** 3, rtol=1e-15)
+
+
+@pytest.mark.gpu
+def test_kernels_equal_the_oracle():
+    img = syn.make_pair(700, 640, seed=91)[0]
+    for kw in (dict(n_features=1500, n_levels=4), dict(n_features=300, n_levels=2, fast_threshold=35, patch_size=31)):
+        exp_xy, exp_meta, exp_resp, exp_desc = oo.detect_and_compute(img, orb.rotated_pattern(), orb.direction_table(), **kw)
+        xy, desc, meta, resp = orb.detect_and_compute(img, full=True, **kw)
+        assert len(exp_xy) > 100
+        np.testing.assert_array_equal(meta, exp_meta)
+        np.testing.assert_array_equal(resp, exp_resp)
+        np.testing.assert_array_equal(xy.astype(np.float32), exp_xy)
+        np.testing.assert_array_equal(desc, exp_desc)
+
+
+@pytest.mark.gpu
+def test_feature_tracking_end_to_end_with_the_gpu_detector():
+    """ftlib.feature_tracking with the package's detector + the GPU matcher: the matched vectors follow the synthetic
+    displacement field (ftlib.py:241-285 chain, config 4 of BASELINE.json in miniature)."""
+    from sea_ice_drift_amd import ftlib
+    from sea_ice_drift_amd.domain import ArrayNansat
+    img1, img2 = syn.make_pair(2000, 2000, seed=55, speckle=0.03)
+    n1, n2 = ArrayNansat(img1, matrix=((1e-4, 0.0), (0.0, 1e-4))), ArrayNansat(img2, matrix=((1e-4, 0.0), (0.0, 1e-4)))
+    x1, y1, x2, y2 = ftlib.feature_tracking(n1, n2, nFeatures=20000, max_drift=1e9, ratio_test=0.75)
+    assert len(x1) > 300
+    dc, dr = syn.true_displacement(x1, y1)
+    err = np.hypot(x2 - x1 - dc, y2 - y1 - dr)
+    assert (err < 3.0).mean() > 0.9

@@ -1,0 +1,16 @@
+R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/r2d; mkdir -p $OUT
+cd $R
+timeout 900 python3 tools/soak_debug.py > $OUT/soak_debug.txt 2>&1
+SID_PM_NO_RP=1 timeout 900 python3 tools/soak_debug.py > $OUT/soak_debug_classic.txt 2>&1
+timeout 1800 python3 -m pytest tests/test_gpu_parity.py tests/test_gpu_golden.py tests/test_gpu_soak.py -m gpu -q > $OUT/pytest.txt 2>&1
+tail -15 $OUT/pytest.txt
+for cfg in "" "--border 20" "--border 50" "--img-size 35"; do
+timeout 600 python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline $cfg 2>> $OUT/bench.err | python3 -c "
+import sys, json
+d = json.loads(sys.stdin.read())
+print(json.dumps({'args': '$cfg', 'ms_per_step': d['ms_per_step'], 'kernel_ms': d['roofline']['kernel_ms_per_step'], 'value': d['value'], 'mfma_frac': d['roofline']['frac'], 'parity_check': d['parity_check']['ok']}))" >> $OUT/configs.jsonl
+done
+cat $OUT/configs.jsonl
+python3 tools/phase_cycles.py > $OUT/phase_cycles.txt 2>&1
+head -12 $OUT/phase_cycles.txt
+cat $OUT/soak_debug.txt; tail -4 $OUT/soak_debug_classic.txt
