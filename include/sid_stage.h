@@ -24,6 +24,21 @@
 extern "C" {
 #endif
 
+/* Workspace handle: device histograms + a pinned host copy, created once and reused (no allocation per call). */
+typedef struct sid_stage_ws sid_stage_ws;
+int  sid_stage_create(int device, sid_stage_ws **ws);
+void sid_stage_destroy(sid_stage_ws *ws);
+
+/* First pass over the image: histogram of the leading 11 key bits of every non-NaN pixel -> *n_valid (host) = their
+ * number (what np.nanpercentile needs to turn a percentile into ranks).  The histogram stays in the workspace. */
+int sid_stage_begin(sid_stage_ws *ws, const float *d_img, int64_t rows, int64_t cols, int64_t stride, int64_t *n_valid,
+                    void *hip_stream);
+
+/* Exact order statistics of the image of the last sid_stage_begin: values[k] (host) = the ranks[k]-th smallest
+ * (0-based) non-NaN pixel; two more passes over the image per group of up to eight ranks. */
+int sid_stage_order_stats_ws(sid_stage_ws *ws, const int64_t *ranks, int n_ranks, float *values);
+
+/* One-shot forms of the above (a temporary workspace per call). */
 /* Number of non-NaN pixels of a float32 image [rows][cols] with row stride `stride` (in elements) -> *n_valid (host). */
 int sid_stage_count_valid(const float *d_img, int64_t rows, int64_t cols, int64_t stride, int64_t *n_valid,
                           void *hip_stream);

@@ -30,7 +30,8 @@ SYMBOLS = (
 FT_SYMBOLS = ('sid_ft_knn2', 'sid_ft_knn2_device', 'sid_ft_workspace_bytes', 'sid_ft_last_error')
 
 # every symbol include/sid_stage.h declares (uint8 staging, same library)
-STAGE_SYMBOLS = ('sid_stage_count_valid', 'sid_stage_order_stats', 'sid_stage_scale_u8', 'sid_stage_last_error')
+STAGE_SYMBOLS = ('sid_stage_create', 'sid_stage_destroy', 'sid_stage_begin', 'sid_stage_order_stats_ws',
+                 'sid_stage_count_valid', 'sid_stage_order_stats', 'sid_stage_scale_u8', 'sid_stage_last_error')
 
 # every symbol include/sid_orb.h declares (key-point detector, same library)
 ORB_SYMBOLS = ('sid_orb_detect', 'sid_orb_last_error')
@@ -104,6 +105,11 @@ def lib():
     L.sid_stage_scale_u8.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_float, C.c_float, C.c_void_p,
                                      C.c_int64, C.c_void_p]
     L.sid_stage_last_error.restype = C.c_char_p
+    L.sid_stage_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
+    L.sid_stage_destroy.argtypes = [C.c_void_p]
+    L.sid_stage_destroy.restype = None
+    L.sid_stage_begin.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.POINTER(C.c_int64), C.c_void_p]
+    L.sid_stage_order_stats_ws.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.c_int, _f32p]
     L.sid_orb_detect.argtypes = [C.c_int, _u8p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.POINTER(C.c_int8), _i32p,
                                  _f32p, _i32p, C.POINTER(C.c_int64), _u8p, C.c_int64, C.POINTER(C.c_int64)]
     L.sid_orb_last_error.restype = C.c_char_p
@@ -322,6 +328,33 @@ def ft_knn2(desc1, desc2, device=0):
 def _stage_check(rc):
     if rc != 0:
         raise SidPmError(rc, lib().sid_stage_last_error().decode())
+
+
+class StageWorkspace(object):
+    """Persistent device + pinned host buffers of the staging step (include/sid_stage.h sid_stage_create)."""
+
+    def __init__(self, device=0):
+        self._h = C.c_void_p()
+        _stage_check(lib().sid_stage_create(int(device), C.byref(self._h)))
+
+    def close(self):
+        if getattr(self, '_h', None) is not None and self._h.value:
+            lib().sid_stage_destroy(self._h)
+            self._h = C.c_void_p()
+
+    __del__ = close
+
+    def begin(self, ptr, rows, cols, stride, stream=0):
+        """First pass: number of non-NaN pixels; keeps the leading-digit histogram for order_stats."""
+        n = C.c_int64(0)
+        _stage_check(lib().sid_stage_begin(self._h, C.c_void_p(int(ptr)), rows, cols, stride, C.byref(n), C.c_void_p(int(stream))))
+        return int(n.value)
+
+    def order_stats(self, ranks):
+        r = np.ascontiguousarray(ranks, dtype=np.int64)
+        out = np.empty(len(r), dtype=np.float32)
+        _stage_check(lib().sid_stage_order_stats_ws(self._h, r.ctypes.data_as(C.POINTER(C.c_int64)), len(r), out.ctypes.data_as(_f32p)))
+        return out
 
 
 def stage_count_valid(ptr, rows, cols, stride, stream=0):

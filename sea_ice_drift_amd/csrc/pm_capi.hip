@@ -591,7 +591,8 @@ SID_EXPORT int sid_pm_run(sid_pm_ctx *ctx)
         // the CU still carries 12 wavefronts (3 per SIMD = the register budget).  (Measured: 384- and
         // 512-thread groups lose to 2 x 256 - they do not pack onto the SIMDs and serialise the phases.)
         const int per_cu = std::max(1, std::min(b.band == 8 ? 2 : 8, blocks_per_cu(b.lds)));
-        const int nthreads = b.band == 8 ? 256 : (per_cu == 1 ? 768 : 256);
+        static const int nt2 = getenv("SID_PM_THREADS2") ? atoi(getenv("SID_PM_THREADS2")) : 256;   // A/B: two-per-CU class
+        const int nthreads = b.band == 8 ? 256 : (per_cu == 1 ? 768 : (per_cu == 2 ? nt2 : 256));
         const int e = use_rp(ctx->img_size, ctx->n_angles)
                           ? sid::launch_pm_rp(A, lds_launch, nthreads, ctx->stream)
                           : sid::launch_pm_mfma(A, lds_launch, nthreads, b.band, use_paired(ctx->n_angles), ctx->stream);

@@ -1565,7 +1565,7 @@ int launch_pm_rp(const PMArgs &args, int lds_bytes, int nthreads, void *stream)
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, max_lds_bytes());
     if (e != hipSuccess) return (int)e;
-    if (lds_bytes > max_lds_bytes() || (nthreads != 256 && nthreads != 768)) return (int)hipErrorInvalidValue;
+    if (lds_bytes > max_lds_bytes() || nthreads < 256 || nthreads > 768 || (nthreads & 63)) return (int)hipErrorInvalidValue;
     hipLaunchKernelGGL(kern, dim3(args.n_launch), dim3(nthreads), lds_bytes, st, args);
     return (int)hipGetLastError();
 }

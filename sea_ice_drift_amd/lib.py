@@ -148,6 +148,9 @@ def _lerp(a, b, t):
     return r
 
 
+_STAGE_WS = {}                     # one staging workspace per device, created on first use
+
+
 def get_uint8_image(image, vmin, vmax, pmin, pmax, device=0):
     """Scale a float32 image to uint8 on the GPU: signature and results of the reference's
     ``get_uint8_image`` (lib.py:27-59): ``1 + 254 * (image - vmin) / (vmax - vmin)`` clipped to [1, 255],
@@ -175,14 +178,18 @@ def get_uint8_image(image, vmin, vmax, pmin, pmax, device=0):
     stream = torch.cuda.current_stream(t.device).cuda_stream
     ftype = np.float32
     if vmin is None or vmax is None:
-        n = _capi.stage_count_valid(t.data_ptr(), rows, cols, stride, stream)
+        dev_index = t.device.index or 0
+        ws = _STAGE_WS.get(dev_index)
+        if ws is None:
+            ws = _STAGE_WS[dev_index] = _capi.StageWorkspace(dev_index)
+        n = ws.begin(t.data_ptr(), rows, cols, stride, stream)
         want = [p for p, v in ((pmin, vmin), (pmax, vmax)) if v is None]
         if n == 0:
             vals = {p: ftype(np.nan) for p in want}
         else:
             rk = {p: _percentile_ranks(n, p, ftype) for p in want}
             ranks = sorted({r for p in want for r in rk[p][:2]})
-            stat = dict(zip(ranks, _capi.stage_order_stats(t.data_ptr(), rows, cols, stride, ranks, stream)))
+            stat = dict(zip(ranks, ws.order_stats(ranks)))
             vals = {p: _lerp(stat[rk[p][0]], stat[rk[p][1]], rk[p][2]) for p in want}
         if vmin is None:
             vmin = vals[pmin]
