@@ -1,0 +1,44 @@
+/* sid_fg.h - C ABI of the first-guess evaluation on MI355X (gfx950): SURVEY.md section 8, row f4.
+ *
+ * Replaces, in the reference's prelude of pattern matching (sea_ice_drift v0.7.1):
+ *
+ *   sid_fg_interp_linear   the evaluation half of lib.interpolation_near (lib.py:179-201):
+ *                              griddata(src, x2, dst, method='linear'), griddata(src, y2, dst, method='linear')
+ *                          i.e. point location in the Delaunay triangulation of the key points + barycentric
+ *                          interpolation of both components at the N grid points, NaN outside the convex hull.
+ *                          The triangulation itself stays SciPy's (Qhull) on the host - the simplices are an input -
+ *                          so the triangles, and with them the interpolant, are the reference's.
+ *   sid_fg_nearest_dist    pmlib.get_distance_to_nearest_keypoint (pmlib.py:61-77) sampled at the grid points
+ *                          (pmlib.py:300-305): distance from each (row, col) to the nearest key-point pixel - the
+ *                          exact Euclidean distance the full-image EDT holds there (sqrt of an exact integer).
+ *
+ * Arithmetic of the interpolation: per simplex the 2x2 system of the barycentric transform is solved by LU with
+ * partial pivoting, c = Tinv (x - r), c2 = 1 - c0 - c1, value = c0 v0 + c1 v1 + c2 v2 accumulated in vertex order
+ * (scipy.spatial.Delaunay.transform / LinearNDInterpolator); a point belongs to the first simplex (lowest index)
+ * with all c >= -eps, eps = 100 * DBL_EPSILON.  SciPy reaches a simplex by a directed walk and its BLAS may round
+ * the 2x2 solve differently, so values can differ from SciPy's in the last bits (<= 1e-12 relative; the reference
+ * rounds them to integer pixels next, pmlib.py:285-288).
+ * Host buffers in / host buffers out; 0 on success, a negative SID_PM_ERR_* code otherwise (sid_pm.h).
+ */
+#ifndef SID_FG_H
+#define SID_FG_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* pts [n_pts][2], simplices [n_simp][3] (indices into pts), values [n_pts][2], q [n_q][2] -> out [n_q][2] */
+int sid_fg_interp_linear(int device, const double *pts, int64_t n_pts, const int32_t *simplices, int64_t n_simp,
+                         const double *values, const double *q, int64_t n_q, double *out);
+
+/* seeds [n_seeds][2], q [n_q][2] -> dist [n_q] = min over seeds of the Euclidean distance */
+int sid_fg_nearest_dist(int device, const double *seeds, int64_t n_seeds, const double *q, int64_t n_q, double *dist);
+
+const char *sid_fg_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -36,6 +36,9 @@ STAGE_SYMBOLS = ('sid_stage_create', 'sid_stage_destroy', 'sid_stage_begin', 'si
 # every symbol include/sid_orb.h declares (key-point detector, same library)
 ORB_SYMBOLS = ('sid_orb_detect', 'sid_orb_last_error')
 
+# every symbol include/sid_fg.h declares (first-guess evaluation, same library)
+FG_SYMBOLS = ('sid_fg_interp_linear', 'sid_fg_nearest_dist', 'sid_fg_last_error')
+
 _u8p = C.POINTER(C.c_uint8)
 _f64p = C.POINTER(C.c_double)
 _f32p = C.POINTER(C.c_float)
@@ -113,6 +116,9 @@ def lib():
     L.sid_orb_detect.argtypes = [C.c_int, _u8p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.POINTER(C.c_int8), _i32p,
                                  _f32p, _i32p, C.POINTER(C.c_int64), _u8p, C.c_int64, C.POINTER(C.c_int64)]
     L.sid_orb_last_error.restype = C.c_char_p
+    L.sid_fg_interp_linear.argtypes = [C.c_int, _f64p, C.c_int64, _i32p, C.c_int64, _f64p, _f64p, C.c_int64, _f64p]
+    L.sid_fg_nearest_dist.argtypes = [C.c_int, _f64p, C.c_int64, _f64p, C.c_int64, _f64p]
+    L.sid_fg_last_error.restype = C.c_char_p
     for name in SYMBOLS:
         getattr(L, name)                      # AttributeError here = header/library mismatch
     if L.sid_pm_abi_version() != ABI_VERSION:
@@ -376,3 +382,28 @@ def stage_order_stats(ptr, rows, cols, stride, ranks, stream=0):
 def stage_scale_u8(ptr, rows, cols, stride, vmin, denom, out_ptr, out_stride, stream=0):
     _stage_check(lib().sid_stage_scale_u8(C.c_void_p(int(ptr)), rows, cols, stride, float(vmin), float(denom),
                                           C.c_void_p(int(out_ptr)), out_stride, C.c_void_p(int(stream))))
+
+
+def fg_interp_linear(pts, simplices, values, q, device=0):
+    """Piecewise-linear interpolation of two value columns at the points q in a given triangulation
+    (include/sid_fg.h sid_fg_interp_linear): pts [n,2], simplices [m,3], values [n,2], q [k,2] -> [k,2] (NaN outside)."""
+    pts, values, q = _f64(pts), _f64(values), _f64(q)
+    simp = np.ascontiguousarray(simplices, dtype=np.int32)
+    out = np.empty((len(q), 2), dtype=np.float64)
+    L = lib()
+    rc = L.sid_fg_interp_linear(int(device), _p(pts, _f64p), len(pts), simp.ctypes.data_as(_i32p), len(simp), _p(values, _f64p),
+                                _p(q, _f64p), len(q), _p(out, _f64p))
+    if rc != 0:
+        raise SidPmError(rc, L.sid_fg_last_error().decode())
+    return out
+
+
+def fg_nearest_dist(seeds, q, device=0):
+    """Distance from every point of q [k,2] to the nearest of seeds [n,2] (include/sid_fg.h sid_fg_nearest_dist)."""
+    seeds, q = _f64(seeds), _f64(q)
+    out = np.empty(len(q), dtype=np.float64)
+    L = lib()
+    rc = L.sid_fg_nearest_dist(int(device), _p(seeds, _f64p), len(seeds), _p(q, _f64p), len(q), _p(out, _f64p))
+    if rc != 0:
+        raise SidPmError(rc, L.sid_fg_last_error().decode())
+    return out

@@ -1,0 +1,174 @@
+// first_guess.hip - evaluation of the first guess on gfx950 (C ABI: include/sid_fg.h; the reference's
+// lib.interpolation_near, lib.py:179-201, and pmlib.get_distance_to_nearest_keypoint, pmlib.py:61-77).
+// Both kernels are brute force over (query, simplex | seed) pairs - 1.6e9 pairs for 40 000 grid points against
+// 40 000 triangles, a few milliseconds of float64 VALU work - with the triangles / seeds staged through LDS.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <float.h>
+#include <stdarg.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/sid_fg.h"
+#include "../../include/sid_pm.h"
+
+#define SID_EXPORT extern "C" __attribute__((visibility("default")))
+
+namespace {
+
+thread_local char g_err[256] = "";
+int fail(int code, const char *fmt, ...)
+{
+    va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof g_err, fmt, ap); va_end(ap);
+    return code;
+}
+
+struct Simp { double t00, t01, t10, t11, rx, ry; int v0, v1, v2, ok; };
+
+// barycentric transform of every simplex: LU with partial pivoting of M = [[x0 - xr, y0 - yr], [x1 - xr, y1 - yr]],
+// Tinv = M^-T (scipy.spatial.Delaunay.transform); degenerate simplices are marked and never match
+__global__ void k_transform(const double *pts, const int32_t *simp, int64_t ns, Simp *out)
+{
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= ns) return;
+    const int a = simp[3 * k], b = simp[3 * k + 1], c = simp[3 * k + 2];
+    const double rx = pts[2 * c], ry = pts[2 * c + 1];
+    double m00 = pts[2 * a] - rx, m01 = pts[2 * a + 1] - ry, m10 = pts[2 * b] - rx, m11 = pts[2 * b + 1] - ry;
+    const bool swap = fabs(m10) > fabs(m00);
+    if (swap) { double t = m00; m00 = m10; m10 = t; t = m01; m01 = m11; m11 = t; }
+    Simp s; s.rx = rx; s.ry = ry; s.v0 = a; s.v1 = b; s.v2 = c;
+    const double l = m10 * (1.0 / m00), u11 = m11 - l * m01;
+    s.ok = (m00 != 0.0 && u11 != 0.0 && isfinite(l) && isfinite(1.0 / u11)) ? 1 : 0;
+    const double iu11 = 1.0 / u11, iu00 = 1.0 / m00;
+    double x[2][2];
+    for (int col = 0; col < 2; ++col) {
+        double b0 = col == 0 ? 1.0 : 0.0, b1 = col == 1 ? 1.0 : 0.0;
+        if (swap) { const double t = b0; b0 = b1; b1 = t; }
+        const double y1 = fma(-l, b0, b1);
+        const double x1 = y1 * iu11;
+        const double x0 = fma(-m01, x1, b0) * iu00;
+        x[0][col] = x0; x[1][col] = x1;
+    }
+    // M^-1 = x; Tinv (rows = barycentric coordinates, columns = x, y) = (M^-1)^T
+    s.t00 = x[0][0]; s.t01 = x[1][0]; s.t10 = x[0][1]; s.t11 = x[1][1];
+    out[k] = s;
+}
+
+constexpr int kTile = 256;
+__global__ __launch_bounds__(256) void k_interp(const Simp *simp, int64_t ns, const double *values, const double *q, int64_t nq,
+                                                double *out)
+{
+    __shared__ Simp tile[kTile];
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const double x = i < nq ? q[2 * i] : 0.0, y = i < nq ? q[2 * i + 1] : 0.0;
+    const double eps = 100.0 * DBL_EPSILON;
+    bool found = false;
+    double o0 = NAN, o1 = NAN;
+    for (int64_t base = 0; base < ns; base += kTile) {
+        __syncthreads();
+        if (base + (int64_t)threadIdx.x < ns) tile[threadIdx.x] = simp[base + threadIdx.x];
+        __syncthreads();
+        const int n = (int)((ns - base) < kTile ? (ns - base) : kTile);
+        if (!found && i < nq) {
+            for (int k = 0; k < n; ++k) {
+                const Simp &s = tile[k];
+                const double dx = x - s.rx, dy = y - s.ry;
+                const double c0 = s.t00 * dx + s.t01 * dy, c1 = s.t10 * dx + s.t11 * dy;
+                const double c2 = 1.0 - c0 - c1;
+                if (s.ok && c0 >= -eps && c1 >= -eps && c2 >= -eps) {
+                    const double *v0 = values + 2 * (int64_t)s.v0, *v1 = values + 2 * (int64_t)s.v1, *v2 = values + 2 * (int64_t)s.v2;
+                    o0 = c0 * v0[0]; o0 += c1 * v1[0]; o0 += c2 * v2[0];
+                    o1 = c0 * v0[1]; o1 += c1 * v1[1]; o1 += c2 * v2[1];
+                    found = true;
+                    break;
+                }
+            }
+        }
+    }
+    if (i < nq) { out[2 * i] = o0; out[2 * i + 1] = o1; }
+}
+
+__global__ __launch_bounds__(256) void k_nearest(const double *seeds, int64_t ns, const double *q, int64_t nq, double *dist)
+{
+    __shared__ double sx[1024], sy[1024];
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const double x = i < nq ? q[2 * i] : 0.0, y = i < nq ? q[2 * i + 1] : 0.0;
+    double best = INFINITY;
+    for (int64_t base = 0; base < ns; base += 1024) {
+        __syncthreads();
+        for (int k = threadIdx.x; k < 1024 && base + k < ns; k += 256) { sx[k] = seeds[2 * (base + k)]; sy[k] = seeds[2 * (base + k) + 1]; }
+        __syncthreads();
+        const int n = (int)((ns - base) < 1024 ? (ns - base) : 1024);
+        for (int k = 0; k < n; ++k) {
+            const double dx = x - sx[k], dy = y - sy[k];
+            const double d2 = dx * dx + dy * dy;
+            best = d2 < best ? d2 : best;
+        }
+    }
+    if (i < nq) dist[i] = sqrt(best);
+}
+
+#define HIP_TRY(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { rc = fail(SID_PM_ERR_HIP, "%s: %s", #x, hipGetErrorString(e_)); goto done; } } while (0)
+
+int pick_device(int device, int &prev)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n) return fail(SID_PM_ERR_NODEVICE, "no such HIP device");
+    (void)hipGetDevice(&prev); (void)hipSetDevice(device);
+    return SID_PM_OK;
+}
+
+}  // namespace
+
+SID_EXPORT const char *sid_fg_last_error(void) { return g_err; }
+
+SID_EXPORT int sid_fg_interp_linear(int device, const double *pts, int64_t n_pts, const int32_t *simplices, int64_t n_simp,
+                                    const double *values, const double *q, int64_t n_q, double *out)
+{
+    if (n_q == 0) return SID_PM_OK;
+    if (!pts || !simplices || !values || !q || !out || n_pts < 3 || n_simp < 1 || n_q < 0) return fail(SID_PM_ERR_ARG, "bad argument");
+    int prev = 0;
+    if (int rc0 = pick_device(device, prev)) return rc0;
+    int rc = SID_PM_OK;
+    double *d_pts = nullptr, *d_val = nullptr, *d_q = nullptr, *d_out = nullptr; int32_t *d_simp = nullptr; Simp *d_t = nullptr;
+    HIP_TRY(hipMalloc(&d_pts, sizeof(double) * 2 * n_pts));
+    HIP_TRY(hipMalloc(&d_val, sizeof(double) * 2 * n_pts));
+    HIP_TRY(hipMalloc(&d_q, sizeof(double) * 2 * n_q));
+    HIP_TRY(hipMalloc(&d_out, sizeof(double) * 2 * n_q));
+    HIP_TRY(hipMalloc(&d_simp, sizeof(int32_t) * 3 * n_simp));
+    HIP_TRY(hipMalloc(&d_t, sizeof(Simp) * n_simp));
+    HIP_TRY(hipMemcpy(d_pts, pts, sizeof(double) * 2 * n_pts, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d_val, values, sizeof(double) * 2 * n_pts, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d_q, q, sizeof(double) * 2 * n_q, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d_simp, simplices, sizeof(int32_t) * 3 * n_simp, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_transform, dim3((unsigned)((n_simp + 255) / 256)), dim3(256), 0, 0, d_pts, d_simp, n_simp, d_t);
+    hipLaunchKernelGGL(k_interp, dim3((unsigned)((n_q + 255) / 256)), dim3(256), 0, 0, d_t, n_simp, d_val, d_q, n_q, d_out);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(out, d_out, sizeof(double) * 2 * n_q, hipMemcpyDeviceToHost));
+done:
+    (void)hipFree(d_pts); (void)hipFree(d_val); (void)hipFree(d_q); (void)hipFree(d_out); (void)hipFree(d_simp); (void)hipFree(d_t);
+    (void)hipSetDevice(prev);
+    return rc;
+}
+
+SID_EXPORT int sid_fg_nearest_dist(int device, const double *seeds, int64_t n_seeds, const double *q, int64_t n_q, double *dist)
+{
+    if (n_q == 0) return SID_PM_OK;
+    if (!seeds || !q || !dist || n_seeds < 1 || n_q < 0) return fail(SID_PM_ERR_ARG, "bad argument");
+    int prev = 0;
+    if (int rc0 = pick_device(device, prev)) return rc0;
+    int rc = SID_PM_OK;
+    double *d_s = nullptr, *d_q = nullptr, *d_d = nullptr;
+    HIP_TRY(hipMalloc(&d_s, sizeof(double) * 2 * n_seeds));
+    HIP_TRY(hipMalloc(&d_q, sizeof(double) * 2 * n_q));
+    HIP_TRY(hipMalloc(&d_d, sizeof(double) * n_q));
+    HIP_TRY(hipMemcpy(d_s, seeds, sizeof(double) * 2 * n_seeds, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d_q, q, sizeof(double) * 2 * n_q, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_nearest, dim3((unsigned)((n_q + 255) / 256)), dim3(256), 0, 0, d_s, n_seeds, d_q, n_q, d_d);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(dist, d_d, sizeof(double) * n_q, hipMemcpyDeviceToHost));
+done:
+    (void)hipFree(d_s); (void)hipFree(d_q); (void)hipFree(d_d);
+    (void)hipSetDevice(prev);
+    return rc;
+}

@@ -105,18 +105,29 @@ def interpolation_poly(x1, y1, x2, y2, x1grd, y1grd, order=1, **kwargs):
     return fx.reshape(np.shape(x1grd)), fy.reshape(np.shape(x1grd))
 
 
-def interpolation_near(x1, y1, x2, y2, x1grd, y1grd, method='linear', **kwargs):
+def interpolation_near(x1, y1, x2, y2, x1grd, y1grd, method='linear', first_guess_device=None, **kwargs):
     """scipy griddata of x2/y2 from the keypoints onto the grid points; NaN outside the
-    convex hull (reference lib.py:179-201; note the (row, col) point order)."""
+    convex hull (reference lib.py:179-201; note the (row, col) point order).
+
+    ``first_guess_device`` (not a reference argument): GPU index on which the grid points are located in the
+    triangulation and interpolated (include/sid_fg.h) - the triangulation is SciPy's Delaunay either way.  ``None``
+    evaluates with SciPy on the host."""
     src = np.array([y1, x1]).T
     dst = np.array([y1grd, x1grd]).T
     if method == 'linear' and src.shape[1] == 2:
         # The reference calls griddata twice, i.e. triangulates the same keypoints twice - the slowest
         # step of the whole prelude.  One Delaunay triangulation serves both components; every component
         # is the same barycentric sum, so the values are bit-identical to the two separate calls.
-        from scipy.interpolate import LinearNDInterpolator
         from scipy.spatial import Delaunay
-        both = LinearNDInterpolator(Delaunay(src), np.array([x2, y2], dtype=np.float64).T)(dst)
+        tri = Delaunay(src)
+        vals = np.array([x2, y2], dtype=np.float64).T
+        if first_guess_device is not None:
+            from . import _capi
+            both = _capi.fg_interp_linear(tri.points, tri.simplices, vals, dst.reshape(-1, 2), device=first_guess_device)
+            both = both.reshape(dst.shape[:-1] + (2,))
+        else:
+            from scipy.interpolate import LinearNDInterpolator
+            both = LinearNDInterpolator(tri, vals)(dst)
         return both[..., 0].T, both[..., 1].T
     return griddata(src, x2, dst, method=method).T, griddata(src, y2, dst, method=method).T
 

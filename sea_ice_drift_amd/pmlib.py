@@ -57,7 +57,24 @@ def get_initial_rotation(n1, n2):
     return np.degrees(np.arctan2(x1 - x0, y1 - y0)[0])
 
 
-def nearest_keypoint_distance(x_kp, y_kp, rows_q, cols_q, shape=None):
+def _first_guess_device(kwargs):
+    """Where the first guess is evaluated: kwarg ``first_guess_on`` = 'device' | 'host' | 'auto' (default: the GPU
+    when one is visible).  Not a reference kwarg; the reference's own code path is 'host'."""
+    mode = kwargs.get('first_guess_on', 'auto')
+    if mode == 'host':
+        return None
+    if mode == 'device':
+        return int(kwargs.get('device', 0))
+    if mode != 'auto':
+        raise ValueError("first_guess_on must be 'auto', 'device' or 'host'")
+    try:
+        import torch
+        return int(kwargs.get('device', 0)) if torch.cuda.is_available() else None
+    except ImportError:
+        return None
+
+
+def nearest_keypoint_distance(x_kp, y_kp, rows_q, cols_q, shape=None, device=None):
     """Distance from integer pixels (rows_q, cols_q) to the nearest keypoint pixel.
 
     Same numbers as sampling the reference's full-image Euclidean distance transform
@@ -74,8 +91,10 @@ def nearest_keypoint_distance(x_kp, y_kp, rows_q, cols_q, shape=None):
         raise IndexError('key point %d at pixel (row %d, col %d) is out of bounds for image 2 of shape %s '
                          '(reference pmlib.py:73)' % (bad, int(seed_r[bad]), int(seed_c[bad]), tuple(shape[:2])))
     seeds = np.stack([seed_r.astype(np.float64), seed_c.astype(np.float64)], axis=1)
-    tree = cKDTree(seeds)
     q = np.stack([np.asarray(rows_q, dtype=np.float64), np.asarray(cols_q, dtype=np.float64)], axis=1)
+    if device is not None:                                      # brute force on the GPU: the same exact distances
+        return _capi.fg_nearest_dist(seeds, q, device=device)
+    tree = cKDTree(seeds)
     d, _ = tree.query(q, k=1)
     return d
 
@@ -84,11 +103,12 @@ def prepare_first_guess(c2pm1, r2pm1, n1, c1, r1, n2, c2, r2, img_size,
                         min_fg_pts=5, min_border=20, max_border=50, old_border=True, **kwargs):
     """First-guess position and search border per grid point (reference pmlib.py:249-324)."""
     n2_shape = n2.shape()
+    fg_dev = _first_guess_device(kwargs)
     lon1, lat1 = n1.transform_points(c1, r1)
     c1n2, r1n2 = n2.transform_points(lon1, lat1, 1)
 
     c2p, r2p = np.round(interpolation_poly(c1n2, r1n2, c2, r2, c2pm1, r2pm1, **kwargs))
-    c2fg, r2fg = np.round(interpolation_near(c1n2, r1n2, c2, r2, c2pm1, r2pm1, **kwargs))
+    c2fg, r2fg = np.round(interpolation_near(c1n2, r1n2, c2, r2, c2pm1, r2pm1, first_guess_device=fg_dev, **kwargs))
 
     if old_border:
         border = np.zeros(c2pm1.size) + max_border
@@ -99,10 +119,10 @@ def prepare_first_guess(c2pm1, r2pm1, n1, c1, r1, n2, c2, r2, img_size,
         # negative int16 values index from the end, as NumPy fancy indexing would
         rq = np.where(rq < 0, rq + n2_shape[0], rq)
         cq = np.where(cq < 0, cq + n2_shape[1], cq)
-        border[inside] = nearest_keypoint_distance(c2, r2, rq, cq, shape=n2_shape)
+        border[inside] = nearest_keypoint_distance(c2, r2, rq, cq, shape=n2_shape, device=fg_dev)
     else:
         c2t, r2t = interpolation_poly(c1n2, r1n2, c2, r2, c1n2, r1n2, **kwargs)
-        c2d, r2d = interpolation_near(c1n2, r1n2, c2 - c2t, r2 - r2t, c2pm1, r2pm1, **kwargs)
+        c2d, r2d = interpolation_near(c1n2, r1n2, c2 - c2t, r2 - r2t, c2pm1, r2pm1, first_guess_device=fg_dev, **kwargs)
         border = np.hypot(c2d, r2d)
 
     border[border < min_border] = min_border
@@ -178,26 +198,32 @@ def _sweep_options(kwargs):
     return angles, flags
 
 
+_CONTEXTS = {}                      # one device handle per GPU, created on first use and kept (streams, buffers)
+
+
+def _shared_context(device):
+    ctx = _CONTEXTS.get(device)
+    if ctx is None:
+        ctx = _CONTEXTS[device] = _capi.PMContext(device)
+    return ctx
+
+
 def pm_dispatch(img1, img2, c1, r1, c2fg, r2fg, border, img_size, alpha0, device=0, context=None, **kwargs):
-    """The batch seam (reference pmlib.py:436-448): N points -> (N,5) float64 on the GPU."""
+    """The batch seam (reference pmlib.py:436-448): N points -> (N,5) float64 on the GPU.
+    ``context``: a PMContext to run on; by default one handle per device is created on first use and reused, so
+    that repeated calls pay neither for streams and events nor for device buffers again."""
     angles, flags = _sweep_options(kwargs)
     rot = rotation_table(angles, alpha0, img_size)
-    own = context is None
-    ctx = _capi.PMContext(device) if own else context
+    ctx = _shared_context(device) if context is None else context
+    ctx.upload_pair(img1, img2)             # slot 0, and selected: the handle may have had another pair current
     try:
-        ctx.upload_pair(img1, img2)
-        ctx.select_pair(0)                  # a reused context may have another slot or a borrowed pair current
-        try:
-            ctx.set_points(c1, r1, c2fg, r2fg, border, img_size, alpha0, angles, rot=rot, flags=flags)
-        except _capi.SidPmError as e:
-            if e.code == -4:
-                raise NotImplementedError(str(e))
-            raise
-        ctx.run()
-        return ctx.fetch(want_ij=False)
-    finally:
-        if own:
-            ctx.close()
+        ctx.set_points(c1, r1, c2fg, r2fg, border, img_size, alpha0, angles, rot=rot, flags=flags)
+    except _capi.SidPmError as e:
+        if e.code == -4:
+            raise NotImplementedError(str(e))
+        raise
+    ctx.run()
+    return ctx.fetch(want_ij=False)
 
 
 def use_mcc(c1, r1, c2fg, r2fg, border, img1, img2, img_size, alpha0, **kwargs):

@@ -33,17 +33,24 @@ def orb_header_functions():
     return sorted(set(re.findall(r'\b(sid_orb_[a-z_0-9]+)\s*\(', src)))
 
 
+def fg_header_functions():
+    src = open(os.path.join(ROOT, 'include', 'sid_fg.h')).read()
+    src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
+    return sorted(set(re.findall(r'\b(sid_fg_[a-z_0-9]+)\s*\(', src)))
+
+
 def test_header_and_binding_agree():
     assert header_functions() == sorted(_capi.SYMBOLS)
     assert ft_header_functions() == sorted(_capi.FT_SYMBOLS)
     assert stage_header_functions() == sorted(_capi.STAGE_SYMBOLS)
     assert orb_header_functions() == sorted(_capi.ORB_SYMBOLS)
+    assert fg_header_functions() == sorted(_capi.FG_SYMBOLS)
 
 
 def test_library_exports_every_declared_symbol():
     assert os.path.exists(_capi.LIB_PATH), 'build with __graft_entry__.build() first'
     lib = ctypes.CDLL(_capi.LIB_PATH)
-    for name in header_functions() + ft_header_functions() + stage_header_functions() + orb_header_functions():
+    for name in header_functions() + ft_header_functions() + stage_header_functions() + orb_header_functions() + fg_header_functions():
         assert hasattr(lib, name), name
     assert lib.sid_pm_abi_version() == _capi.ABI_VERSION
     lib.sid_pm_strerror.restype = ctypes.c_char_p

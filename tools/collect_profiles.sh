@@ -1,6 +1,6 @@
 #!/bin/bash
 # Collects the round's measurement evidence on the GPU box into gpurun_out/<tag>/ (copy what is to be judged
-# into profiles/).  Usage (through gpurun): bash tools/collect_profiles.sh r01_final
+# into profiles/).  Usage (through gpurun): bash tools/collect_profiles.sh r02_rp
 set -u
 TAG=${1:-prof}
 R=${GRAFT_REPO_ROOT:-$PWD}
@@ -14,12 +14,32 @@ import sys, json
 d = json.loads(sys.stdin.read())
 print(json.dumps({'args': '$cfg', 'ms_per_step': d['ms_per_step'], 'value': d['value'], 'workload': d['config']['workload'], 'mfma_frac': d['roofline']['frac'], 'parity_check': d['parity_check']}))" >> $OUT/other_configs.jsonl
 done
+python3 $R/bench.py --mode stream --pairs 16 --steps 2 --warmup 1 --check 32 > $OUT/stream_bench.json 2>> $OUT/bench.err
+python3 $R/bench.py --gpus 2 --steps 5 --warmup 1 --no-cpu-baseline > $OUT/dryrun_2ranks_1gpu.json 2>> $OUT/bench.err
 rocprofv3 --kernel-trace --stats -d /tmp/kt_$TAG -o kt -- python3 $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
 python3 $R/tools/rocpd_summary.py $(find /tmp/kt_$TAG -name "*.db" | head -1) > $OUT/kernel_trace_stats.txt
 rocprofv3 --pmc FETCH_SIZE -d /tmp/pf_$TAG -o pf -- python3 $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE -d /tmp/pw_$TAG -o pw -- python3 $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
 python3 $R/tools/pmc_traffic.py $(find /tmp/pf_$TAG -name "*.db" | head -1) $(find /tmp/pw_$TAG -name "*.db" | head -1) pm_kernel > $OUT/pmc_traffic.json
+python3 - "$OUT/pmc_traffic.json" "$R" > $OUT/traffic.json <<'PY'
+import hashlib, json, sys
+raw = json.load(open(sys.argv[1])); root = sys.argv[2]
+fetch_kb = sum(v.get('fetch_kb', 0.0) for v in raw.values()); write_kb = sum(v.get('write_kb', 0.0) for v in raw.values())
+disp = sum(v.get('dispatches', 0) for v in raw.values())
+steps = 5                                   # --steps 4 --warmup 1
+launches = disp / steps
+fetch = fetch_kb * 1024.0 * 2.0 / steps     # FETCH_SIZE x 2 on gfx950 (MI355X_MICROARCH.md; calibration in profiles/r01_hbm_counter_calibration.json)
+write = write_kb * 1024.0 / steps
+print(json.dumps({
+ 'workload': {'size': 10000, 'grid': 200, 'angles': 7, 'border': 'mixed', 'img_size': 34},
+ 'so_md5': hashlib.md5(open(root + '/sea_ice_drift_amd/libsid_pm.so', 'rb').read()).hexdigest(),
+ 'launches_per_step': launches, 'fetch_bytes_per_step_raw': fetch / 2.0, 'fetch_correction': 2.0, 'fetch_bytes_per_step': fetch,
+ 'write_bytes_per_step': write, 'hbm_bytes_per_step': fetch + write, 'hbm_bytes_per_launch': (fetch + write) / max(launches, 1),
+ 'source': 'rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `python3 bench.py --steps 4 --warmup 1 --no-cpu-baseline` (%d dispatches), summed with tools/pmc_traffic.py (tools/collect_profiles.sh)' % disp,
+ 'note': 'fetch: search windows, image-1 patches, sampling table; write: 52 B of results per point (+ callee-saved register saves); algorithmic bytes = both images once (0.2 GB per step)'}, indent=1))
+PY
 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU -d /tmp/p1_$TAG -o p1 -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
 rocprofv3 --pmc SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_LDS -d /tmp/p2_$TAG -o p2 -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
 for p in p1 p2; do python3 $R/tools/rocpd_summary.py $(find /tmp/${p}_$TAG -name "*.db" | head -1) | sed -n '/PMC per dispatch/,$p' >> $OUT/pmc_counters.txt; done
+python3 $R/tools/e2e_bench.py > $OUT/e2e_pattern_matching.json 2>> $OUT/bench.err
 ls -la $OUT

@@ -31,12 +31,14 @@ with contextlib.redirect_stdout(io.StringIO()):
                                                               pre['r2fg'][gpi], pre['brd2'][gpi], 34, pre['alpha0'], angles=angles))
     post, t_post = timed('postlude', lambda: pmlib.pm_postlude(pre, res, n2))
     full, t_full = timed('all', lambda: pmlib.pattern_matching(lon, lat, n1, c1, r1, n2, c2, r2, img_size=34, angles=angles))
+    _, t_full_host = timed('all_host_fg', lambda: pmlib.pattern_matching(lon, lat, n1, c1, r1, n2, c2, r2, img_size=34, angles=angles, first_guess_on='host'))
+    _, t_pre_host = timed('prelude_host', lambda: pmlib.pm_prelude(lon, lat, n1, c1, r1, n2, c2, r2, img_size=34, angles=angles, first_guess_on='host'))
 u, v = full[0], full[1]
 ok = np.isfinite(u)
 tdc, tdr = syn.true_displacement(cg, rg)
 err = np.hypot(u[ok] - tdc[ok], v[ok] - tdr[ok])
 print(json.dumps({'metric': 'pattern_matching end to end, 200x200 grid on a 10000x10000 pair, K=15, %d FT points' % nkp,
-                  'valid_points': int(ok.sum()), 'total_s': t_full, 'prelude_s': t_pre,
+                  'valid_points': int(ok.sum()), 'total_s': t_full, 'prelude_s': t_pre, 'total_s_first_guess_on_host': t_full_host, 'prelude_s_first_guess_on_host': t_pre_host,
                   'dispatch_s_incl_200MB_upload_and_context': t_disp, 'postlude_s': t_post,
                   'grid_points_per_s_end_to_end': float(ok.sum()) / t_full,
                   'median_abs_drift_error_px': float(np.median(err)), 'borders': [float(pre['brd2'][gpi].min()), float(pre['brd2'][gpi].max())]}))
