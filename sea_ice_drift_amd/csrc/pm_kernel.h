@@ -126,8 +126,9 @@ __host__ __device__ inline RpLdsLayout rp_lds_layout(int wh, int ww, int s)
     // a single item reads 5 dwords from (x0 + n + 16 (g & 1)) & ~3 (<= x0 + 51); the winner (k-groups 0..2 + the
     // broadcast group) 5 dwords up to 16 ntx + 52
     int need = ww;
-    if (L.npair && 32 * (L.npair - 1) + 64 > need) need = 32 * (L.npair - 1) + 64;
-    if (L.nsingle && 32 * L.npair + 52 > need) need = 32 * L.npair + 52;
+    // (+ 16 / + 16: the winner's strip operands read the same runs 32 columns further right)
+    if (L.npair && 32 * (L.npair - 1) + 80 > need) need = 32 * (L.npair - 1) + 80;
+    if (L.nsingle && 32 * L.npair + 68 > need) need = 32 * L.npair + 68;
     const int ntx = (rw + 15) / 16;
     if (16 * ntx + 52 > need) need = 16 * ntx + 52;
     L.wpitch = round_up(need, 8);
@@ -152,7 +153,7 @@ __host__ __device__ inline RpLdsLayout rp_lds_layout(int wh, int ww, int s)
     L.ppitch = round_up(L.pdim, 4);
     L.patch_off = L.strip_off + L.ncp * L.nrg * 1024 + 16;      // + 16 scratch bytes
     L.queue_off = round_up(L.patch_off + L.pdim * L.ppitch + 1, 16);
-    L.trow_bytes = 4 * (s + kTrowPad) * 16;
+    L.trow_bytes = 4096;                            // half of the 8 KB the row-pair winner's operands take (rp_winner_stage)
     // the column-pair copy only lives during the sweep: behind the queue, inside the union (built after the
     // column sums are dead, overwritten by the winner's NCC matrix)
     L.wp_off = round_up(L.queue_off + kQueueCap * 16, 16);
