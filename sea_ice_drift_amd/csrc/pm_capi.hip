@@ -219,7 +219,7 @@ bool use_rp(int s, int K)
 
 int lds_need(int wh, int ww, int s, int K, int band = 4)
 {
-    if (use_rp(s, K)) return sid::rp_lds_layout(wh, ww, s).total;
+    if (use_rp(s, K)) return sid::rp_lds_layout(wh, ww, s, K <= sid::kRpGroup).total;
     return sid::mfma_lds_layout(wh, ww, s, band, use_paired(K) && band == 4).total;
 }
 

@@ -100,6 +100,7 @@ __host__ __device__ inline MfmaLdsLayout mfma_lds_layout(int wh, int ww, int s, 
 // from which one MFMA operand = two consecutive template rows x 32 columns (K = 64 all useful); the columns
 // 32.. ("strip") are multiplied through a column-pair copy of the window, WP[u][rho] = (W[rho][u], W[rho][u+1]),
 // so that K = 32 window rows x 2 columns.
+constexpr int kRpGroup = 15;    // angles per group of MFMA slots (the 16th slot is the all-ones template)
 struct RpLdsLayout {
     int wpitch, wrows;          // window pitch (multiple of 8) and rows written (window + zero rows)
     int win_off, sii_off;
@@ -114,7 +115,9 @@ struct RpLdsLayout {
 
 __host__ __device__ inline bool rp_size_supported(int s) { return s == 34 || s == 35; }
 
-__host__ __device__ inline RpLdsLayout rp_lds_layout(int wh, int ww, int s)
+// one_group: all angles fit one group of MFMA slots (K <= 15).  The winner then takes its template from the sweep's
+// operand table, the image-1 patch is dead once the table is built and the candidate queue lies over it.
+__host__ __device__ inline RpLdsLayout rp_lds_layout(int wh, int ww, int s, bool one_group)
 {
     RpLdsLayout L;
     const int rh = wh - s + 1, rw = ww - s + 1;
@@ -152,11 +155,13 @@ __host__ __device__ inline RpLdsLayout rp_lds_layout(int wh, int ww, int s)
     L.pdim = 2 * L.pradius + 2;
     L.ppitch = round_up(L.pdim, 4);
     L.patch_off = L.strip_off + L.ncp * L.nrg * 1024 + 16;      // + 16 scratch bytes
-    L.queue_off = round_up(L.patch_off + L.pdim * L.ppitch + 1, 16);
+    const int patch_end = round_up(L.patch_off + L.pdim * L.ppitch + 1, 16);
+    L.queue_off = one_group ? round_up(L.patch_off, 16) : patch_end;
     L.trow_bytes = 4096;                            // half of the 8 KB the row-pair winner's operands take (rp_winner_stage)
     // the column-pair copy only lives during the sweep: behind the queue, inside the union (built after the
     // column sums are dead, overwritten by the winner's NCC matrix)
     L.wp_off = round_up(L.queue_off + kQueueCap * 16, 16);
+    if (L.wp_off < patch_end) L.wp_off = patch_end;              // (the column-pair copy is built while the patch is live)
     int u = rh * ww * 4;
     const int sweep = L.wp_off + L.wp_rows * L.wp_pitch - L.u_off;
     if (u < sweep) u = sweep;

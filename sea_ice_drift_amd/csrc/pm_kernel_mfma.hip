@@ -52,7 +52,7 @@ constexpr int kMaxBlockM = 768;
 #define kWavesM ((int)(blockDim.x >> 6))
 constexpr int kOccM = 3;             // wavefronts per SIMD the register allocation must allow
 constexpr int kSlots = 16;           // MFMA M: 15 angles + ones
-constexpr int kAnglesPerGroup = 15;
+constexpr int kAnglesPerGroup = kRpGroup;
 constexpr float kMargin = 1e-5f;     // pre-filter margin (see header)
 
 struct MiscM {                       // LDS offset 0, kMiscMfmaBytes reserved

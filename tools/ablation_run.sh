@@ -8,7 +8,7 @@ R=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-for v in A0 A1 A2 A3 A4; do
+for v in ${VARIANTS:-A0 A1 A2 A3 A4 A5 A6}; do
   [ -f $R/tools/ab/lib_$v.so ] || continue
   export SID_PM_LIB=$R/tools/ab/lib_$v.so
   python3 $R/bench.py --border $BORDER --steps 10 --warmup 2 --no-cpu-baseline --check 0 2>/dev/null | python3 -c "
