@@ -159,6 +159,13 @@ int sid_pm_debug_point(sid_pm_ctx *ctx, double c1, double r1, double c2fg, doubl
  * step of the NCC specification; lets a test pin device vs host rounding. */
 int sid_pm_debug_rsqrt(sid_pm_ctx *ctx, const double *x, double *y, int64_t n);
 
+/* The kernel evaluates the NCC matrix of the winning angle through a shortened form of the specification's
+ * normalisation (no IEEE square root / division; values whose float32 rounding could differ take the
+ * specification's own route).  This runs both forms on `evaluations` pseudo-random sums on the device:
+ * counts[0] = evaluations done, counts[1] = results that differ (must be 0), counts[2] = evaluations that
+ * needed the specification's route. */
+int sid_pm_debug_ncc_selftest(sid_pm_ctx *ctx, uint64_t seed, int64_t evaluations, int img_size, uint64_t counts[3]);
+
 #ifdef __cplusplus
 }
 #endif

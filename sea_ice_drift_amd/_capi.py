@@ -22,7 +22,7 @@ SYMBOLS = (
     'sid_pm_abi_version', 'sid_pm_strerror', 'sid_pm_last_error', 'sid_pm_device_count',
     'sid_pm_batch', 'sid_pm_create', 'sid_pm_destroy', 'sid_pm_set_stream', 'sid_pm_upload_pair',
     'sid_pm_select_pair', 'sid_pm_bind_pair', 'sid_pm_set_points', 'sid_pm_bind_results', 'sid_pm_run', 'sid_pm_sync',
-    'sid_pm_fetch', 'sid_pm_device_results', 'sid_pm_work_info', 'sid_pm_debug_point',
+    'sid_pm_fetch', 'sid_pm_device_results', 'sid_pm_work_info', 'sid_pm_debug_point', 'sid_pm_debug_ncc_selftest',
     'sid_pm_debug_rsqrt',
 )
 
@@ -97,6 +97,7 @@ def lib():
                                                                       C.c_uint32, _u8p, _f32p, _f32p, C.c_int64,
                                                                       _i32p, _f64p, _i32p, C.POINTER(C.c_int64)]
     L.sid_pm_debug_rsqrt.argtypes = [C.c_void_p, _f64p, _f64p, C.c_int64]
+    L.sid_pm_debug_ncc_selftest.argtypes = [C.c_void_p, C.c_uint64, C.c_int64, C.c_int, C.POINTER(C.c_uint64)]
     L.sid_ft_knn2.argtypes = [C.c_int, _u8p, C.c_int64, _u8p, C.c_int64, _i32p, _i32p]
     L.sid_ft_knn2_device.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.sid_ft_workspace_bytes.argtypes = [C.c_int64, C.c_int64]
@@ -313,6 +314,12 @@ class PMContext(object):
         y = np.empty_like(x)
         _check(lib().sid_pm_debug_rsqrt(self._h, _p(x, _f64p), _p(y, _f64p), x.size))
         return y
+
+    def debug_ncc_selftest(self, evaluations, img_size=34, seed=1):
+        """(evaluations, mismatches, spec-route evaluations) of the shortened NCC normalisation against the full one."""
+        counts = (C.c_uint64 * 3)()
+        _check(lib().sid_pm_debug_ncc_selftest(self._h, int(seed), int(evaluations), int(img_size), counts))
+        return int(counts[0]), int(counts[1]), int(counts[2])
 
 
 def ft_knn2(desc1, desc2, device=0):

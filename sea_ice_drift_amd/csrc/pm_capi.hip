@@ -779,3 +779,24 @@ SID_EXPORT int sid_pm_debug_rsqrt(sid_pm_ctx *ctx, const double *x, double *y, i
     if (e != hipSuccess) return fail(SID_PM_ERR_HIP, "debug_rsqrt: %s", hipGetErrorString(e));
     return SID_PM_OK;
 }
+
+
+SID_EXPORT int sid_pm_debug_ncc_selftest(sid_pm_ctx *ctx, uint64_t seed, int64_t evaluations, int img_size, uint64_t counts[3])
+{
+    if (!ctx || !counts || evaluations <= 0 || img_size < 2 || img_size > 64) return fail(SID_PM_ERR_ARG, "bad argument");
+    Guard g(ctx->device);
+    DevBuf<unsigned long long> d;
+    int rc;
+    if ((rc = d.reserve(3))) return rc;
+    const int per_thread = 256;
+    const int blocks = (int)std::min<int64_t>((evaluations + 256 * per_thread - 1) / (256 * per_thread), 1 << 20);
+    hipError_t e = hipMemsetAsync(d.p, 0, 3 * sizeof(unsigned long long), ctx->stream);
+    if (e == hipSuccess) e = (hipError_t)sid::launch_ncc_selftest(seed, blocks, per_thread, img_size, d.p, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    unsigned long long h[3] = {0, 0, 0};
+    if (e == hipSuccess) e = hipMemcpy(h, d.p, sizeof(h), hipMemcpyDeviceToHost);
+    d.release();
+    if (e != hipSuccess) return fail(SID_PM_ERR_HIP, "debug_ncc_selftest: %s", hipGetErrorString(e));
+    for (int k = 0; k < 3; ++k) counts[k] = h[k];
+    return SID_PM_OK;
+}

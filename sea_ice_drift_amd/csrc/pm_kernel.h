@@ -126,14 +126,11 @@ __host__ __device__ inline RpLdsLayout rp_lds_layout(int wh, int ww, int s, bool
     L.npair = rw / 32 + (rem > 16 ? 1 : 0);
     L.nsingle = (rem > 0 && rem <= 16) ? 1 : 0;
     // bytes a window row must hold: a pair item at x0 reads 24 B from x0 + 8 (n >> 2) + 16 (g & 1) (<= x0 + 64);
-    // a single item reads 5 dwords from (x0 + n + 16 (g & 1)) & ~3 (<= x0 + 51); the winner (k-groups 0..2 + the
-    // broadcast group) 5 dwords up to 16 ntx + 52
+    // a single item reads 5 dwords from (x0 + n + 16 (g & 1)) & ~3 (<= x0 + 51)
     int need = ww;
     // (+ 16 / + 16: the winner's strip operands read the same runs 32 columns further right)
     if (L.npair && 32 * (L.npair - 1) + 80 > need) need = 32 * (L.npair - 1) + 80;
     if (L.nsingle && 32 * L.npair + 68 > need) need = 32 * L.npair + 68;
-    const int ntx = (rw + 15) / 16;
-    if (16 * ntx + 52 > need) need = 16 * ntx + 52;
     L.wpitch = round_up(need, 8);
     const int y0max = 4 * ((rh + 3) / 4 - 1);
     L.wrows = y0max + 2 * nst;                       // last step reads rows y0 + 2 (nst - 1) and + 1
@@ -181,6 +178,7 @@ bool mfma_band8_supported(int s);
 bool mfma_img_size_supported(int s);
 
 int launch_rsqrt(const double *x, double *y, int64_t n, void *stream);
+int launch_ncc_selftest(unsigned long long seed, int blocks, int per_thread, int s, unsigned long long *out, void *stream);
 int max_lds_bytes();
 
 }  // namespace sid

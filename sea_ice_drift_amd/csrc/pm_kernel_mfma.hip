@@ -345,6 +345,35 @@ __device__ __forceinline__ float exact_from_sums(int p, int swp, u32 siiv, doubl
     return exact_ncc(numer, dI, rTd, cT, lowvar);
 }
 
+// The same value by a shorter route (the winner's matrix evaluates thousands of these per point).  1 / sqrt(dI) comes
+// from v_rsq_f64 and two coupled Newton steps - no IEEE square root, no IEEE division - so the product q' differs from
+// the spec's q (whose own 1 / sqrt carries two roundings) by less than 2^-49 |q|.  (float)q' = (float)q unless q' lies
+// that close to a rounding boundary of float32 (the middle of the 29 discarded mantissa bits) or to one of the clamp
+// thresholds 1 and 1.125: those lanes - about 1e-7 of them, plus the perfect matches - take the spec's route.
+__device__ __forceinline__ float exact_from_sums_fast(int p, int swp, u32 siiv, double nd, double sT, double rTd, bool cT)
+{
+    const double swd = (double)swp, siid = (double)siiv;
+    const double dI = nd * siid - swd * swd;                           // exact
+    const double numer = nd * (double)p - swd * sT;                    // exact
+    bool slow = 2.0 * dI <= nd;                                        // the low-variance rule needs a second look
+    const double x = slow ? 1.0 : dI;
+    const double y0 = __builtin_amdgcn_rsq(x);
+    double g = x * y0, h = 0.5 * y0;
+    double r = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, r, g); h = __builtin_fma(h, r, h);
+    r = __builtin_fma(-h, g, 0.5);
+    h = __builtin_fma(h, r, h);                                        // 1 / (2 sqrt(dI))
+    const double q = (numer * h) * (2.0 * rTd);
+    const double aq = fabs(q);
+    const u32 lo29 = (u32)__double2loint(q) & 0x1fffffffu;
+    slow |= (lo29 - (0x10000000u - 64u)) <= 128u;
+    slow |= fabs(aq - 1.0) < 1e-13 || fabs(aq - 1.125) < 1e-13;
+    float out = aq < 1.0 ? (float)q : (aq < 1.125 ? (q > 0.0 ? 1.0f : -1.0f) : 0.0f);
+    if (cT) out = 1.0f;
+    if (slow && !cT) out = exact_from_sums(p, swp, siiv, nd, sT, rTd, cT);
+    return out;
+}
+
 struct Score { float lmax, bestv; int bestkey; };
 
 __device__ __forceinline__ void take_better(Score &sc, float rv, int key)
@@ -1508,6 +1537,43 @@ __global__ __launch_bounds__(BAND == 8 ? 512 : kMaxBlockM, BAND == 8 ? 2 : kOccM
 
 #include "pm_kernel_rp.inc"
 
+// exact_from_sums_fast against exact_from_sums on pseudo-random sums of plausible windows (diagnostic):
+// out[0] = evaluations, out[1] = results that differ, out[2] = evaluations that took the spec's route
+__global__ void ncc_selftest_kernel(unsigned long long seed, int per_thread, int s, unsigned long long *out)
+{
+    unsigned long long st = seed ^ (0x9e3779b97f4a7c15ull * (unsigned long long)(blockIdx.x * blockDim.x + threadIdx.x + 1));
+    auto next = [&]() { st ^= st << 13; st ^= st >> 7; st ^= st << 17; return st; };
+    const double nd = (double)(s * s);
+    unsigned long long bad = 0, slow = 0;
+    for (int it = 0; it < per_thread; ++it) {
+        // template: sum sT (re-centred), denominator dT = N S_TT - S_T^2 > 0
+        const int sT = (int)(next() % (unsigned)(2 * 128 * s * s + 1)) - 128 * s * s;
+        const double dTmin = 1.0, dT = dTmin + (double)(next() % (1ull << (20 + (int)(next() % 28))));
+        const double rTd = 1.0 / sqrt(dT);
+        const int swp = (int)(next() % (unsigned)(2 * 128 * s * s + 1)) - 128 * s * s;
+        const unsigned long long sw2 = (unsigned long long)((long long)swp * swp);
+        const u32 sii_min = (u32)((sw2 + (unsigned long long)(s * s) - 1) / (unsigned long long)(s * s));
+        const u32 room = (u32)(s * s) * 16384u - sii_min;                 // S_I'I' <= N 128^2
+        const u32 siiv = sii_min + (u32)(next() % (unsigned long long)(room + 1u)) % (1u << (1 + (int)(next() % 27)));
+        const double dI = nd * (double)siiv - (double)swp * (double)swp;
+        // numerator within (and sometimes just beyond) the Cauchy-Schwarz bound: nd p - swp sT = f sqrt(dI dT)
+        const double f = ((double)(long long)(next() % 2400001ull) - 1200000.0) / 1000000.0;
+        const double target = f * sqrt(dI > 0 ? dI : 0.0) * sqrt(dT);
+        const int p = (int)llrint((target + (double)swp * (double)sT) / nd);
+        const float a = exact_from_sums(p, swp, siiv, nd, (double)sT, rTd, false);
+        const float b = exact_from_sums_fast(p, swp, siiv, nd, (double)sT, rTd, false);
+        bad += __float_as_uint(a) != __float_as_uint(b) ? 1ull : 0ull;
+        // (the count of spec-route evaluations is re-derived: same predicate as in exact_from_sums_fast)
+        const double y = 1.0 / sqrt(dI > 0 ? dI : 1.0);
+        const double q = ((nd * (double)p - (double)swp * (double)sT) * y) * rTd, aq = fabs(q);
+        const u32 lo29 = (u32)__double2loint(q) & 0x1fffffffu;
+        slow += (2.0 * dI <= nd || (lo29 - (0x10000000u - 64u)) <= 128u || fabs(aq - 1.0) < 1e-13 || fabs(aq - 1.125) < 1e-13) ? 1ull : 0ull;
+    }
+    atomicAdd(&out[0], (unsigned long long)per_thread);
+    if (bad) atomicAdd(&out[1], bad);
+    if (slow) atomicAdd(&out[2], slow);
+}
+
 __global__ void rsqrt_kernel(const double *x, double *y, int64_t n)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1523,6 +1589,13 @@ int launch_rsqrt(const double *x, double *y, int64_t n, void *stream)
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (n <= 0) return (int)hipSuccess;
     hipLaunchKernelGGL(rsqrt_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, y, n);
+    return (int)hipGetLastError();
+}
+
+int launch_ncc_selftest(unsigned long long seed, int blocks, int per_thread, int s, unsigned long long *out, void *stream)
+{
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(ncc_selftest_kernel, dim3((unsigned)blocks), dim3(256), 0, st, seed, per_thread, s, out);
     return (int)hipGetLastError();
 }
 

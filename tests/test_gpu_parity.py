@@ -185,3 +185,14 @@ def test_hessian_options_incl_gaussian_smoothing(pm_ctx, c_oracle, flags):
     np.testing.assert_array_equal(got[:, :3], exp[:, :3])
     np.testing.assert_allclose(got[:, 3], exp[:, 3], rtol=1e-5, atol=1e-5)      # r: exact unless mcc_norm
     np.testing.assert_allclose(got[:, 4], exp[:, 4], rtol=1e-5, atol=1e-5)      # h
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('s', [34, 35])
+def test_shortened_normalisation_is_the_specification(pm_ctx, s):
+    """The winner's NCC matrix uses exact_from_sums_fast (pm_kernel_mfma.hip): 2^27 pseudo-random sums, bit for bit
+    against the specification's IEEE route; the guard must fire (perfect matches, float32 rounding boundaries)."""
+    n, bad, slow = pm_ctx.debug_ncc_selftest(1 << 27, img_size=s, seed=20240917 + s)
+    assert n >= 1 << 27
+    assert bad == 0
+    assert 0 < slow < n // 20                                          # (the generator over-samples flat windows)
