@@ -385,9 +385,39 @@ __device__ __forceinline__ void take_better(Score &sc, float rv, int key)
 // Phase 0a: search window of image 2 -> LDS, re-centred to int8 (w ^ 0x80), zero beyond the window.
 // Loads are issued four dwords deep before any is consumed (HBM/L2 latency overlaps).
 // ---------------------------------------------------------------------------------------------
-__device__ __noinline__ void ph_window(const uint8_t *img2, long long rows2, long long cols2, long long stride2)
+// PATCH: the image-1 patch (ph_patch's fast path; the caller checked that it lies inside image 1 and that its LDS
+// region is free already) is fetched in the same round trip: its loads are issued before the window's.
+template <bool PATCH>
+__device__ __noinline__ void ph_window_t(const uint8_t *img2, long long rows2, long long cols2, long long stride2,
+                                         const uint8_t *img1, long long rows1, long long cols1, long long stride1)
 {
     SID_PHASE_LOCALS;
+    constexpr int kPat = 4;                                            // patch dwords per thread and trip (ph_patch)
+    u32 plo[kPat] = {}, phi[kPat] = {}, psh[kPat] = {};
+    const int pdw = G.ppitch >> 2, pndw = G.pdim * pdw;
+    if (PATCH) {
+        const u32 pmagic = G.patch_magic;
+        const int pst = (int)stride1;
+        const uint8_t *porg = img1 + (long long)G.pr0 * stride1 + G.pc0;
+        const u32 pmis = (u32)(reinterpret_cast<uintptr_t>(porg) & 3);
+        const uint8_t *porg4 = porg - pmis;
+        const long long plast_ll = (long long)((reinterpret_cast<uintptr_t>(img1 + (rows1 - 1) * stride1 + cols1) - 1) & ~(uintptr_t)3) -
+                                   (long long)reinterpret_cast<uintptr_t>(porg4);
+        const u32 plast = plast_ll > 0x7ffffff0ll ? 0x7ffffff0u : (u32)plast_ll;
+#pragma unroll
+        for (int u = 0; u < kPat; ++u) {
+            const int idx = u * kBlockM + tid;
+            const int idc = idx < pndw ? idx : 0;
+            const int row = (int)__umulhi((u32)idc, pmagic);
+            const int dq = idc - row * pdw;
+            const u32 o = (u32)(row * pst + 4 * dq) + pmis;
+            const u32 oa = o & ~3u;
+            const u32 ob = oa + 4 <= plast ? oa + 4 : plast;
+            psh[u] = o & 3u;
+            plo[u] = *reinterpret_cast<const u32 *>(porg4 + oa);
+            phi[u] = *reinterpret_cast<const u32 *>(porg4 + ob);
+        }
+    }
     uint8_t *win = smem + G.win_off;
     const int wpitch = G.wpitch, ww = G.ww, wh = G.wh;
     const int dw_per_row = wpitch >> 2, ndw = (wh + G.band - 1) * dw_per_row;   // + band-1 zero rows below
@@ -433,6 +463,21 @@ __device__ __noinline__ void ph_window(const uint8_t *img2, long long rows2, lon
             }
         }
     }
+    if (PATCH) {
+        uint8_t *patch = smem + G.patch_off;
+        if (tid == 0) patch[G.pdim * G.ppitch] = 128;                  // (as ph_patch)
+#pragma unroll
+        for (int u = 0; u < kPat; ++u) {
+            const int idx = u * kBlockM + tid;
+            if (idx < pndw) reinterpret_cast<u32 *>(patch)[idx] = __builtin_amdgcn_alignbyte(phi[u], plo[u], psh[u]);
+        }
+        // (larger patches than kPat * blockDim dwords do not occur: pdim <= 58 for s <= 35, 256 threads)
+    }
+}
+
+__device__ __forceinline__ void ph_window(const uint8_t *img2, long long rows2, long long cols2, long long stride2)
+{
+    ph_window_t<false>(img2, rows2, cols2, stride2, nullptr, 0, 0, 0);
 }
 
 // ---------------------------------------------------------------------------------------------
