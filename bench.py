@@ -320,7 +320,9 @@ def grid_mode(args, torch, dist, dev, world, rank, local_rank):
             # the sweep runs on v_mfma_i32_16x16x64_i8: the matrix cores are the roofline that bounds it
             'bound': 'mfma', 'achieved': mfma_achieved, 'peak': MFMA_I8_PEAK_TOPS, 'unit': 'TFLOP/s',
             'frac': mfma_achieved / MFMA_I8_PEAK_TOPS, 'traffic': traffic, 'traffic_note': traffic_note,
-            'kernel': 'sid::pm_kernel_mfma<%d,...> (one instantiation per band height)' % (s if s in (34, 35) else 0),
+            'kernel': ('sid::pm_kernel_rp<%d> (row-pair sweep; one launch per LDS class: 3 / 2 / 1 workgroups per CU)' % s
+                       if s in (34, 35) and len(angles) > 7 else
+                       'sid::pm_kernel_mfma<%d,...> (classic sweep: one instantiation per band height / pairing)' % (s if s in (34, 35) else 0)),
             'launches_per_step': launches, 'kernel_ms_per_step': kern_ms, 'avg_launch_ms': kern_ms / launches,
             'algorithmic_macs_per_step': info['macs'], 'algorithmic_bytes_per_step': info['hbm_bytes'],
             'note': 'rank 0 share: achieved = 2 x algorithmic MACs (sum K*Rh*Rw*s*s, integer ops) / kernel time from HIP '

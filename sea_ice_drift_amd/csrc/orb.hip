@@ -15,6 +15,7 @@
 #include <string.h>
 #include <algorithm>
 #include <vector>
+#include <chrono>
 
 #include "../../include/sid_orb.h"
 #include "../../include/sid_pm.h"
@@ -106,6 +107,35 @@ __global__ void k_nms_harris(const uint8_t *img, const uint8_t *score, int rows,
     if (k < cap) { out[k].x = x; out[k].y = y; out[k].resp = resp; }
 }
 
+// ---- the n best candidates without sorting them all: order-preserving 32-bit key of the response (float32 of the
+//      int64, so a < b never turns into key(a) > key(b)), three histogram passes (11 / 11 / 10 bits, most significant
+//      first) find the key of rank n from the top, a compaction keeps every candidate at or above it.  Everything left
+//      out has a strictly smaller response than everything kept; the host then orders the kept ones exactly. ----
+__device__ __forceinline__ uint32_t resp_key(long long r)
+{
+    const uint32_t b = __float_as_uint((float)r);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+
+__global__ void k_key_hist(const Cand *c, unsigned int n, uint32_t prefix, uint32_t prefix_mask, int shift, uint32_t digit_mask,
+                           unsigned int *hist)
+{
+    const unsigned int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t k = resp_key(c[i].resp);
+    if ((k & prefix_mask) == prefix) atomicAdd(&hist[(k >> shift) & digit_mask], 1u);
+}
+
+__global__ void k_compact(const Cand *c, unsigned int n, uint32_t kmin, Cand *out, unsigned int *count, unsigned int cap)
+{
+    const unsigned int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (resp_key(c[i].resp) >= kmin) {
+        const unsigned int k = atomicAdd(count, 1u);
+        if (k < cap) out[k] = c[i];
+    }
+}
+
 // ---- orientation: intensity centroid over the disc of radius R, quantised to 32 directions ----
 __global__ void k_orient(const uint8_t *img, int cols, const int32_t *kp /* [n][4]: x, y, level, dir */, int n, int R,
                          const int32_t *dirs, int32_t *dir_out)
@@ -183,8 +213,19 @@ SID_EXPORT int sid_orb_detect(int device, const uint8_t *img, int64_t rows, int6
     int prev = 0; (void)hipGetDevice(&prev); (void)hipSetDevice(device);
     int rc = SID_PM_OK;
     const int L = P->n_levels, edge = P->edge_threshold, R = P->patch_size / 2;
+    // SID_ORB_VERBOSE=1: wall-clock milliseconds per stage on stderr (synchronises after every stage)
+    const bool verbose = getenv("SID_ORB_VERBOSE") != nullptr;
+    auto t_last = std::chrono::steady_clock::now();
+    auto tick = [&](const char *what, int level) {
+        if (!verbose) return;
+        (void)hipDeviceSynchronize();
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[sid_orb] level %d %-22s %8.3f ms\n", level, what, std::chrono::duration<double, std::milli>(now - t_last).count());
+        t_last = now;
+    };
     uint8_t *d_img0 = nullptr, *d_lvl = nullptr, *d_aux = nullptr, *d_desc = nullptr;
-    Cand *d_cand = nullptr; unsigned int *d_count = nullptr;
+    Cand *d_cand = nullptr, *d_sel = nullptr; unsigned int *d_count = nullptr, *d_hist = nullptr;
+    const unsigned int sel_cap = (unsigned int)std::min<int64_t>((int64_t)4 * (int64_t)P->n_features + 65536, (int64_t)1 << 26);
     int8_t *d_pat = nullptr; int32_t *d_dirs = nullptr, *d_kp = nullptr, *d_dir = nullptr;
     std::vector<Cand> cand;
     std::vector<int32_t> kp, dir_h;
@@ -208,11 +249,14 @@ SID_EXPORT int sid_orb_detect(int device, const uint8_t *img, int64_t rows, int6
         HIP_TRY(hipMalloc(&d_aux, area0));
         HIP_TRY(hipMalloc(&d_cand, (area0 / 4 + 16) * sizeof(Cand)));
         HIP_TRY(hipMalloc(&d_count, sizeof(unsigned int)));
+        HIP_TRY(hipMalloc(&d_hist, 2048 * sizeof(unsigned int)));
+        HIP_TRY(hipMalloc(&d_sel, (size_t)sel_cap * sizeof(Cand)));
         HIP_TRY(hipMalloc(&d_pat, 32 * 1024));
         HIP_TRY(hipMalloc(&d_dirs, 64 * sizeof(int32_t)));
         HIP_TRY(hipMemcpy2D(d_img0, (size_t)cols, img, (size_t)stride, (size_t)cols, (size_t)rows, hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(d_pat, pattern, 32 * 1024, hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(d_dirs, dirs, 64 * sizeof(int32_t), hipMemcpyHostToDevice));
+        tick("alloc + upload", -1);
         for (int l = 0; l < L && total < max_out; ++l) {
             const int r = lr[l], c = lc[l];
             if (r <= 2 * edge || c <= 2 * edge || want[l] <= 0) continue;
@@ -230,15 +274,40 @@ SID_EXPORT int sid_orb_detect(int device, const uint8_t *img, int64_t rows, int6
             hipLaunchKernelGGL(k_nms_harris, grd, blk, 0, 0, lvl, d_aux, r, c, edge, d_cand, d_count, cap);
             unsigned int nc = 0;
             HIP_TRY(hipMemcpy(&nc, d_count, sizeof nc, hipMemcpyDeviceToHost));
+            tick("resize + fast + nms", l);
             if (nc > cap) { rc = fail(SID_PM_ERR_HIP, "candidate list overflow (cannot happen: one maximum per 2x2 block)"); goto done; }
             if (nc == 0) continue;
+            const Cand *d_src = d_cand;
+            const int64_t keep = std::min<int64_t>(want[l], max_out - total);
+            if ((int64_t)nc > 2 * keep + 1024) {
+                // key of rank `keep` from the top, digit by digit
+                uint32_t prefix = 0, pmask = 0;
+                unsigned int above = 0;                                // candidates with a larger key than the prefix so far
+                const int shifts[3] = {21, 10, 0}; const uint32_t dmask[3] = {2047u, 2047u, 1023u};
+                std::vector<unsigned int> hist(2048);
+                for (int pass = 0; pass < 3; ++pass) {
+                    HIP_TRY(hipMemset(d_hist, 0, 2048 * sizeof(unsigned int)));
+                    hipLaunchKernelGGL(k_key_hist, dim3((nc + 255) / 256), dim3(256), 0, 0, d_cand, nc, prefix, pmask, shifts[pass], dmask[pass], d_hist);
+                    HIP_TRY(hipMemcpy(hist.data(), d_hist, 2048 * sizeof(unsigned int), hipMemcpyDeviceToHost));
+                    int d = (int)dmask[pass];
+                    for (; d > 0; --d) { if ((int64_t)above + hist[(size_t)d] >= keep) break; above += hist[(size_t)d]; }
+                    prefix |= (uint32_t)d << shifts[pass]; pmask |= dmask[pass] << shifts[pass];
+                }
+                HIP_TRY(hipMemset(d_count, 0, sizeof(unsigned int)));
+                hipLaunchKernelGGL(k_compact, dim3((nc + 255) / 256), dim3(256), 0, 0, d_cand, nc, prefix, d_sel, d_count, sel_cap);
+                unsigned int ns = 0;
+                HIP_TRY(hipMemcpy(&ns, d_count, sizeof ns, hipMemcpyDeviceToHost));
+                if (ns <= sel_cap && (int64_t)ns >= keep) { d_src = d_sel; nc = ns; }   // (else: massive ties - order them all)
+            }
+            tick("select", l);
             cand.resize(nc);
-            HIP_TRY(hipMemcpy(cand.data(), d_cand, (size_t)nc * sizeof(Cand), hipMemcpyDeviceToHost));
+            HIP_TRY(hipMemcpy(cand.data(), d_src, (size_t)nc * sizeof(Cand), hipMemcpyDeviceToHost));
             std::sort(cand.begin(), cand.end(), [](const Cand &p, const Cand &q) {
                 if (p.resp != q.resp) return p.resp > q.resp;
                 if (p.y != q.y) return p.y < q.y;
                 return p.x < q.x;
             });
+            tick("copy + host sort", l);
             int64_t n = std::min<int64_t>(std::min<int64_t>(nc, want[l]), max_out - total);
             kp.resize((size_t)(4 * n));
             for (int64_t i = 0; i < n; ++i) { kp[4 * i] = cand[(size_t)i].x; kp[4 * i + 1] = cand[(size_t)i].y; kp[4 * i + 2] = l; kp[4 * i + 3] = 0; }
@@ -265,12 +334,14 @@ SID_EXPORT int sid_orb_detect(int device, const uint8_t *img, int64_t rows, int6
             }
             memcpy(desc + total * 32, desc_h.data(), (size_t)n * 32);
             total += n;
+            tick("orient + describe", l);
         }
         *n_out = total;
     }
 done:
     (void)hipFree(d_img0); (void)hipFree(d_lvl); (void)hipFree(d_aux); (void)hipFree(d_cand); (void)hipFree(d_count);
     (void)hipFree(d_pat); (void)hipFree(d_dirs); (void)hipFree(d_kp); (void)hipFree(d_dir); (void)hipFree(d_desc);
+    (void)hipFree(d_hist); (void)hipFree(d_sel);
     (void)hipSetDevice(prev);
     return rc;
 }

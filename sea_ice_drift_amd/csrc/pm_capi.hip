@@ -584,15 +584,14 @@ SID_EXPORT int sid_pm_run(sid_pm_ctx *ctx)
     for (const Bucket &b : ctx->buckets) {
         A.order = ctx->d_order + b.offset;
         A.n_launch = b.count;
-        static const int lds_pad = getenv("SID_PM_LDS_PAD") ? atoi(getenv("SID_PM_LDS_PAD")) : 0;   // debugging aid (race hunt)
-        const int lds_launch = std::min(b.lds + lds_pad, sid::max_lds_bytes());
+        const int lds_launch = std::min(b.lds, sid::max_lds_bytes());
         A.lds_bytes = lds_launch;
         // 256 threads per point; 768 when the LDS footprint leaves room for one point per CU only, so that
-        // the CU still carries 12 wavefronts (3 per SIMD = the register budget).  (Measured: 384- and
-        // 512-thread groups lose to 2 x 256 - they do not pack onto the SIMDs and serialise the phases.)
+        // the CU still carries 12 wavefronts (3 per SIMD = the register budget).  (Measured for the
+        // two-per-CU class, border 28: 256 threads 5.8 ms, 384: 9.1, 512: 7.8, 768: 7.8 - six wavefronts per group
+        // land 2/2/1/1 on the SIMDs, a second group of 168-VGPR wavefronts then no longer fits.)
         const int per_cu = std::max(1, std::min(b.band == 8 ? 2 : 8, blocks_per_cu(b.lds)));
-        static const int nt2 = getenv("SID_PM_THREADS2") ? atoi(getenv("SID_PM_THREADS2")) : 256;   // A/B: two-per-CU class
-        const int nthreads = b.band == 8 ? 256 : (per_cu == 1 ? 768 : (per_cu == 2 ? nt2 : 256));
+        const int nthreads = b.band == 8 ? 256 : (per_cu == 1 ? 768 : 256);
         const int e = use_rp(ctx->img_size, ctx->n_angles)
                           ? sid::launch_pm_rp(A, lds_launch, nthreads, ctx->stream)
                           : sid::launch_pm_mfma(A, lds_launch, nthreads, b.band, use_paired(ctx->n_angles), ctx->stream);
