@@ -83,28 +83,69 @@ __global__ void k_fast(const uint8_t *img, int rows, int cols, int edge, int t, 
     score[(long long)y * cols + x] = (uint8_t)sc;
 }
 
-// ---- 3x3 non-maximum suppression + Harris response -> candidate list ----
-__global__ void k_nms_harris(const uint8_t *img, const uint8_t *score, int rows, int cols, int edge, Cand *out,
-                             unsigned int *count, unsigned int cap)
+// one atomicAdd per wavefront instead of one per candidate (millions of appends to a single counter serialise)
+__device__ __forceinline__ unsigned int wave_append(bool take, unsigned int *count)
 {
-    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
-    if (x < edge || x >= cols - edge || y < edge || y >= rows - edge) return;
-    const uint8_t *s = score + (long long)y * cols + x;
-    const int v = s[0];
-    if (v == 0) return;
-    if (!(v > s[-1] && v > s[1] && v > s[-cols] && v > s[cols] && v > s[-cols - 1] && v > s[-cols + 1] &&
-          v > s[cols - 1] && v > s[cols + 1])) return;
-    long long a = 0, b = 0, c = 0;
+    const unsigned long long mask = __ballot(take);
+    if (mask == 0ull) return 0xffffffffu;
+    const int lane = (int)(threadIdx.x & 63u), leader = __ffsll((long long)mask) - 1;
+    unsigned int base = 0;
+    if (lane == leader) base = atomicAdd(count, (unsigned int)__popcll(mask));
+    base = (unsigned int)__shfl((int)base, leader);
+    return take ? base + (unsigned int)__popcll(mask & ((1ull << lane) - 1ull)) : 0xffffffffu;
+}
+
+// ---- 3x3 non-maximum suppression -> candidate list (x, y); the Harris response is filled in by k_harris, one
+//      thread per candidate (the maxima are a few per cent of the pixels: computed in place they leave most lanes of
+//      every wavefront idle through the 7x7 loop) ----
+constexpr int kNmsRows = 16;                   // image rows per block of k_nms (256 columns wide)
+__global__ void k_nms(const uint8_t *score, int rows, int cols, int edge, Cand *out, unsigned int *count, unsigned int cap)
+{
+    // the maxima of a 256 x 16 tile are collected in LDS (at most one per 2 x 2 pixels) and appended with ONE atomic per
+    // block: a few million appends to a single counter take longer than everything else in the detector together
+    __shared__ uint32_t list[256 * kNmsRows / 4 + 64];
+    __shared__ unsigned int nlist, gbase;
+    if (threadIdx.x == 0) nlist = 0;
+    __syncthreads();
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    for (int k = 0; k < kNmsRows; ++k) {
+        const int y = blockIdx.y * kNmsRows + k;
+        bool peak = false;
+        if (x >= edge && x < cols - edge && y >= edge && y < rows - edge) {
+            const uint8_t *s = score + (long long)y * cols + x;
+            const int v = s[0];
+            peak = v != 0 && v > s[-1] && v > s[1] && v > s[-cols] && v > s[cols] && v > s[-cols - 1] && v > s[-cols + 1] &&
+                   v > s[cols - 1] && v > s[cols + 1];
+        }
+        const unsigned int slot = wave_append(peak, &nlist);
+        if (peak) list[slot] = ((uint32_t)y << 16) | (uint32_t)x;      // rows, cols <= 65535 (checked by the caller)
+    }
+    __syncthreads();
+    const unsigned int nl = nlist;
+    if (threadIdx.x == 0 && nl) gbase = atomicAdd(count, nl);
+    __syncthreads();
+    for (unsigned int i = threadIdx.x; i < nl; i += blockDim.x) {
+        const unsigned int o = gbase + i;
+        if (o < cap) { out[o].x = (int32_t)(list[i] & 0xffffu); out[o].y = (int32_t)(list[i] >> 16); out[o].resp = 0; }
+    }
+}
+
+__global__ void k_harris(const uint8_t *img, int cols, Cand *cand, unsigned int n)
+{
+    const unsigned int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int x = cand[i].x, y = cand[i].y;
+    int a = 0, b = 0, c = 0;                                           // <= 49 * 255^2: int32 is enough
     for (int dy = -3; dy <= 3; ++dy) {
         const uint8_t *p = img + (long long)(y + dy) * cols + x;
+#pragma unroll
         for (int dx = -3; dx <= 3; ++dx) {
             const int ix = (int)p[dx + 1] - (int)p[dx - 1], iy = (int)p[dx + cols] - (int)p[dx - cols];
             a += ix * ix; b += iy * iy; c += ix * iy;
         }
     }
-    const long long resp = 25 * (a * b - c * c) - (a + b) * (a + b);
-    const unsigned int k = atomicAdd(count, 1u);
-    if (k < cap) { out[k].x = x; out[k].y = y; out[k].resp = resp; }
+    const long long A = a, B = b, C = c;
+    cand[i].resp = 25 * (A * B - C * C) - (A + B) * (A + B);
 }
 
 // ---- the n best candidates without sorting them all: order-preserving 32-bit key of the response (float32 of the
@@ -117,41 +158,56 @@ __device__ __forceinline__ uint32_t resp_key(long long r)
     return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
 }
 
+constexpr int kHistPer = 16;
 __global__ void k_key_hist(const Cand *c, unsigned int n, uint32_t prefix, uint32_t prefix_mask, int shift, uint32_t digit_mask,
                            unsigned int *hist)
 {
-    const unsigned int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const uint32_t k = resp_key(c[i].resp);
-    if ((k & prefix_mask) == prefix) atomicAdd(&hist[(k >> shift) & digit_mask], 1u);
+    // a block counts kHistPer candidates per thread in LDS and flushes the bins it touched
+    __shared__ unsigned int h[2048];
+    for (int b = threadIdx.x; b < 2048; b += blockDim.x) h[b] = 0;
+    __syncthreads();
+    const unsigned int i0 = blockIdx.x * blockDim.x * kHistPer + threadIdx.x;
+#pragma unroll 4
+    for (int u = 0; u < kHistPer; ++u) {
+        const unsigned int i = i0 + u * blockDim.x;
+        if (i < n) {
+            const uint32_t k = resp_key(c[i].resp);
+            if ((k & prefix_mask) == prefix) atomicAdd(&h[(k >> shift) & digit_mask], 1u);
+        }
+    }
+    __syncthreads();
+    for (int b = threadIdx.x; b < 2048; b += blockDim.x) { const unsigned int v = h[b]; if (v) atomicAdd(&hist[b], v); }
 }
 
 __global__ void k_compact(const Cand *c, unsigned int n, uint32_t kmin, Cand *out, unsigned int *count, unsigned int cap)
 {
     const unsigned int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    if (resp_key(c[i].resp) >= kmin) {
-        const unsigned int k = atomicAdd(count, 1u);
-        if (k < cap) out[k] = c[i];
-    }
+    const bool take = i < n && resp_key(c[i].resp) >= kmin;
+    const unsigned int k = wave_append(take, count);
+    if (take && k < cap) out[k] = c[i];
 }
 
-// ---- orientation: intensity centroid over the disc of radius R, quantised to 32 directions ----
+// ---- orientation: intensity centroid over the disc of radius R, quantised to 32 directions; one wavefront per key
+//      point (the lanes share the (2R+1)^2 pixels of the bounding square) ----
 __global__ void k_orient(const uint8_t *img, int cols, const int32_t *kp /* [n][4]: x, y, level, dir */, int n, int R,
                          const int32_t *dirs, int32_t *dir_out)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (i >= n) return;
     const int x = kp[4 * i], y = kp[4 * i + 1];
-    long long m10 = 0, m01 = 0;
-    for (int dy = -R; dy <= R; ++dy) {
-        const uint8_t *p = img + (long long)(y + dy) * cols + x;
-        for (int dx = -R; dx <= R; ++dx)
-            if (dx * dx + dy * dy <= R * R) { const int v = p[dx]; m10 += dx * v; m01 += dy * v; }
+    const int w = 2 * R + 1, np = w * w;
+    int m10 = 0, m01 = 0;                                              // <= R * 255 * (2R+1)^2 < 2^31 for R <= 32
+    for (int q = lane; q < np; q += 64) {
+        const int dy = q / w - R, dx = q - (dy + R) * w - R;
+        if (dx * dx + dy * dy <= R * R) { const int v = img[(long long)(y + dy) * cols + x + dx]; m10 += dx * v; m01 += dy * v; }
     }
-    int best = 0; long long bv = m10 * dirs[0] + m01 * dirs[1];
-    for (int b = 1; b < 32; ++b) { const long long v = m10 * dirs[2 * b] + m01 * dirs[2 * b + 1]; if (v > bv) { bv = v; best = b; } }
-    dir_out[i] = best;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { m10 += __shfl_xor(m10, o); m01 += __shfl_xor(m01, o); }
+    if (lane == 0) {
+        int best = 0; long long bv = (long long)m10 * dirs[0] + (long long)m01 * dirs[1];
+        for (int b = 1; b < 32; ++b) { const long long v = (long long)m10 * dirs[2 * b] + (long long)m01 * dirs[2 * b + 1]; if (v > bv) { bv = v; best = b; } }
+        dir_out[i] = best;
+    }
 }
 
 // ---- 5x5 binomial blur (1 4 6 4 1 / 16 per axis, replicated borders, round half up once) ----
@@ -204,7 +260,7 @@ SID_EXPORT int sid_orb_detect(int device, const uint8_t *img, int64_t rows, int6
 {
     if (!img || !P || !pattern || !dirs || !xy || !desc || !n_out || max_out < 0) return fail(SID_PM_ERR_ARG, "null argument");
     if (rows < 1 || cols < 1 || stride < cols || rows > 65535 || cols > 65535) return fail(SID_PM_ERR_ARG, "bad image shape/stride");
-    if (P->n_levels < 1 || P->n_levels > 16 || P->edge_threshold < 16 || P->patch_size < 2 || P->patch_size / 2 + 1 > P->edge_threshold ||
+    if (P->n_levels < 1 || P->n_levels > 16 || P->edge_threshold < 16 || P->patch_size < 2 || P->patch_size > 200 || P->patch_size / 2 + 1 > P->edge_threshold ||
         P->n_features < 0 || P->fast_threshold < 1 || P->fast_threshold > 254 || !(P->scale_factor > 1.0f))
         return fail(SID_PM_ERR_ARG, "bad detector parameters (edge_threshold >= 16 and >= patch_size / 2 + 1, 1..16 levels, scale > 1)");
     *n_out = 0;
@@ -271,12 +327,13 @@ SID_EXPORT int sid_orb_detect(int device, const uint8_t *img, int64_t rows, int6
             hipLaunchKernelGGL(k_fast, grd, blk, 0, 0, lvl, r, c, edge, P->fast_threshold, d_aux);
             HIP_TRY(hipMemset(d_count, 0, sizeof(unsigned int)));
             const unsigned int cap = (unsigned int)((size_t)r * c / 4 + 16);
-            hipLaunchKernelGGL(k_nms_harris, grd, blk, 0, 0, lvl, d_aux, r, c, edge, d_cand, d_count, cap);
+            hipLaunchKernelGGL(k_nms, dim3(grd.x, (unsigned)((r + kNmsRows - 1) / kNmsRows)), blk, 0, 0, d_aux, r, c, edge, d_cand, d_count, cap);
             unsigned int nc = 0;
             HIP_TRY(hipMemcpy(&nc, d_count, sizeof nc, hipMemcpyDeviceToHost));
             tick("resize + fast + nms", l);
             if (nc > cap) { rc = fail(SID_PM_ERR_HIP, "candidate list overflow (cannot happen: one maximum per 2x2 block)"); goto done; }
             if (nc == 0) continue;
+            hipLaunchKernelGGL(k_harris, dim3((nc + 255) / 256), dim3(256), 0, 0, lvl, c, d_cand, nc);
             const Cand *d_src = d_cand;
             const int64_t keep = std::min<int64_t>(want[l], max_out - total);
             if ((int64_t)nc > 2 * keep + 1024) {
@@ -287,7 +344,7 @@ SID_EXPORT int sid_orb_detect(int device, const uint8_t *img, int64_t rows, int6
                 std::vector<unsigned int> hist(2048);
                 for (int pass = 0; pass < 3; ++pass) {
                     HIP_TRY(hipMemset(d_hist, 0, 2048 * sizeof(unsigned int)));
-                    hipLaunchKernelGGL(k_key_hist, dim3((nc + 255) / 256), dim3(256), 0, 0, d_cand, nc, prefix, pmask, shifts[pass], dmask[pass], d_hist);
+                    hipLaunchKernelGGL(k_key_hist, dim3((nc + 256 * kHistPer - 1) / (256 * kHistPer)), dim3(256), 0, 0, d_cand, nc, prefix, pmask, shifts[pass], dmask[pass], d_hist);
                     HIP_TRY(hipMemcpy(hist.data(), d_hist, 2048 * sizeof(unsigned int), hipMemcpyDeviceToHost));
                     int d = (int)dmask[pass];
                     for (; d > 0; --d) { if ((int64_t)above + hist[(size_t)d] >= keep) break; above += hist[(size_t)d]; }
@@ -318,7 +375,7 @@ SID_EXPORT int sid_orb_detect(int device, const uint8_t *img, int64_t rows, int6
             HIP_TRY(hipMalloc(&d_dir, (size_t)n * sizeof(int32_t)));
             HIP_TRY(hipMalloc(&d_desc, (size_t)n * 32));
             HIP_TRY(hipMemcpy(d_kp, kp.data(), (size_t)(4 * n) * sizeof(int32_t), hipMemcpyHostToDevice));
-            hipLaunchKernelGGL(k_orient, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, lvl, c, d_kp, (int)n, R, d_dirs, d_dir);
+            hipLaunchKernelGGL(k_orient, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, 0, lvl, c, d_kp, (int)n, R, d_dirs, d_dir);
             hipLaunchKernelGGL(k_blur, grd, blk, 0, 0, lvl, r, c, d_aux);                 // the score map is no longer needed
             hipLaunchKernelGGL(k_describe, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, 0, d_aux, c, d_kp, d_dir, (int)n, d_pat, d_desc);
             HIP_TRY(hipGetLastError());

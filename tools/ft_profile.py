@@ -2,7 +2,7 @@
 """Where get_drift_FT spends its time on the benchmark pair: detector stages (SID_ORB_VERBOSE on stderr), matcher, host
 filters.  Usage: python3 tools/ft_profile.py [size]"""
 import contextlib, io, json, os, sys, time
-os.environ.setdefault('SID_ORB_VERBOSE', '1')
+os.environ.setdefault('SID_ORB_VERBOSE', '1') if os.environ.get('SID_ORB_VERBOSE', None) != '' else os.environ.pop('SID_ORB_VERBOSE')
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from sea_ice_drift_amd import ftlib, synthetic as syn
