@@ -219,6 +219,40 @@ class PMContext(object):
         if select:
             self.select_pair(slot)
 
+    def upload_pair_background(self, img1, img2, slot=0):
+        """upload_pair on a worker thread, entered before this returns: the C call runs without the interpreter lock,
+        so host work of the caller (however long it keeps the lock itself) overlaps the copy.  Returns an object
+        whose wait() joins the thread and re-raises what the upload raised."""
+        import threading
+        img1, img2 = _u8(img1), _u8(img2)
+        self._keep = (self._keep + [img1, img2])[-4:]
+        fn, h, s = lib().sid_pm_upload_pair, self._h, int(slot)
+        args = (h, s, _p(img1, _u8p), img1.shape[0], img1.shape[1], img1.strides[0],
+                _p(img2, _u8p), img2.shape[0], img2.shape[1], img2.strides[0])
+        box = {'rc': None, 'exc': None}
+        entered = threading.Event()
+
+        def run():
+            try:
+                entered.set()                       # the next thing this thread does is the C call (lock released there)
+                box['rc'] = fn(*args)
+            except BaseException as e:              # noqa: handed to the waiting thread
+                box['exc'] = e
+
+        t = threading.Thread(target=run, daemon=True)
+        t.start()
+        entered.wait()
+        ctx = self
+
+        class _Pending:
+            def wait(self_inner):
+                t.join()
+                if box['exc'] is not None:
+                    raise box['exc']
+                _check(box['rc'])
+                ctx.select_pair(s)
+        return _Pending()
+
     def select_pair(self, slot):
         _check(lib().sid_pm_select_pair(self._h, int(slot)))
 

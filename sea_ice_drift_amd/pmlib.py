@@ -215,7 +215,8 @@ def pm_dispatch(img1, img2, c1, r1, c2fg, r2fg, border, img_size, alpha0, device
     angles, flags = _sweep_options(kwargs)
     rot = rotation_table(angles, alpha0, img_size)
     ctx = _shared_context(device) if context is None else context
-    ctx.upload_pair(img1, img2)             # slot 0, and selected: the handle may have had another pair current
+    if img1 is not None:                    # (None: the caller uploaded the pair to ``context`` already)
+        ctx.upload_pair(img1, img2)         # slot 0, and selected: the handle may have had another pair current
     try:
         ctx.set_points(c1, r1, c2fg, r2fg, border, img_size, alpha0, angles, rot=rot, flags=flags)
     except _capi.SidPmError as e:
@@ -239,13 +240,21 @@ def pattern_matching(lon_pm1, lat_pm1, n1, c1, r1, n2, c2, r2,
     (pmlib.py:326-392): u, v, a, r, h, lon2_dst, lat2_dst, each shaped like lon_pm1."""
     t0 = time.time()
     img1, img2 = n1[1], n2[1]
-    pre = pm_prelude(lon_pm1, lat_pm1, n1, c1, r1, n2, c2, r2, margin=margin, img_size=img_size, **kwargs)
+    _sweep_options(kwargs)                                            # unsupported options fail before any work
+    # The image pair goes to the device while the host works on the first guess (its Delaunay triangulation is the
+    # longest step of the prelude): the upload is a C call that does not hold the interpreter lock.
+    ctx = kwargs.pop('context', None)
+    ctx = _shared_context(kwargs.get('device', 0)) if ctx is None else ctx
+    upload = ctx.upload_pair_background(img1, img2)
+    try:
+        pre = pm_prelude(lon_pm1, lat_pm1, n1, c1, r1, n2, c2, r2, margin=margin, img_size=img_size, **kwargs)
+    finally:
+        upload.wait()                                                 # (re-raises what the upload raised)
     gpi = pre['gpi']
     if gpi.any():
-        results = pm_dispatch(img1, img2, pre['c1pm1i'][gpi], pre['r1pm1i'][gpi], pre['c2fg'][gpi],
-                              pre['r2fg'][gpi], pre['brd2'][gpi], img_size, pre['alpha0'], **kwargs)
+        results = pm_dispatch(None, None, pre['c1pm1i'][gpi], pre['r1pm1i'][gpi], pre['c2fg'][gpi],
+                              pre['r2fg'][gpi], pre['brd2'][gpi], img_size, pre['alpha0'], context=ctx, **kwargs)
     else:
-        _sweep_options(kwargs)
         results = np.zeros((0, 5))
     print('\n', 'Pattern matching - OK! (%3.0f sec)' % (time.time() - t0))
     return pm_postlude(pre, results, n2, srs=srs)
