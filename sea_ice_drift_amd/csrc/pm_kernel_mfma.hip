@@ -34,6 +34,9 @@
 // own register allocation; throughput is set by the latency of a workgroup's phase chain.
 // Compile with -ffp-contract=off.
 #include <hip/hip_runtime.h>
+#include <mutex>
+#include <set>
+#include <utility>
 #include <math.h>
 #include <type_traits>
 #include "pm_kernel.h"
@@ -1646,6 +1649,24 @@ int launch_ncc_selftest(unsigned long long seed, int blocks, int per_thread, int
 
 bool mfma_img_size_supported(int s) { return s >= 2 && s + 15 <= 64; }
 
+// The dynamic-LDS limit belongs to the function and the device, not to the stream: it is raised to the maximum once per
+// (kernel, device) - always the maximum, so that launches of different footprints from different host threads cannot
+// undercut each other - instead of on every launch.
+static hipError_t allow_max_lds(void (*kern)(const PMArgs))
+{
+    static std::mutex mu;
+    static std::set<std::pair<const void *, int>> done;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    const std::pair<const void *, int> key(reinterpret_cast<const void *>(kern), dev);
+    std::lock_guard<std::mutex> lock(mu);
+    if (done.count(key)) return hipSuccess;
+    e = hipFuncSetAttribute(key.first, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds_bytes());
+    if (e == hipSuccess) done.insert(key);
+    return e;
+}
+
 bool mfma_band8_supported(int s) { return s == 34 || s == 35; }
 
 int launch_pm_mfma(const PMArgs &args, int lds_bytes, int nthreads, int band, bool paired, void *stream)
@@ -1664,10 +1685,7 @@ int launch_pm_mfma(const PMArgs &args, int lds_bytes, int nthreads, int band, bo
         kern = args.img_size == 34 ? pm_kernel_mfma<34, 4, false> : args.img_size == 35 ? pm_kernel_mfma<35, 4, false>
                                                                                          : pm_kernel_mfma<0, 4, false>;
     } else return (int)hipErrorInvalidValue;
-    // the attribute belongs to the function, not to the stream: always the maximum, so that launches of different
-    // footprints from different host threads cannot undercut each other
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, max_lds_bytes());
+    const hipError_t e = allow_max_lds(kern);
     if (e != hipSuccess) return (int)e;
     if (lds_bytes > max_lds_bytes() || (nthreads != 256 && nthreads != 768)) return (int)hipErrorInvalidValue;
     hipLaunchKernelGGL(kern, dim3(args.n_launch), dim3(nthreads), lds_bytes, st, args);
@@ -1680,8 +1698,7 @@ int launch_pm_rp(const PMArgs &args, int lds_bytes, int nthreads, void *stream)
     if (args.n_launch <= 0) return (int)hipSuccess;
     if (!rp_size_supported(args.img_size)) return (int)hipErrorInvalidValue;
     void (*kern)(const PMArgs) = args.img_size == 34 ? pm_kernel_rp<34> : pm_kernel_rp<35>;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, max_lds_bytes());
+    const hipError_t e = allow_max_lds(kern);
     if (e != hipSuccess) return (int)e;
     if (lds_bytes > max_lds_bytes() || nthreads < 256 || nthreads > 768 || (nthreads & 63)) return (int)hipErrorInvalidValue;
     hipLaunchKernelGGL(kern, dim3(args.n_launch), dim3(nthreads), lds_bytes, st, args);
