@@ -235,25 +235,12 @@ __device__ __forceinline__ float block_median(const float *v, int n, MiscM *m, u
     return (key2f(key1) + key2f(key2)) / 2.0f;
 }
 
-// np.median, fast path: one log-spaced histogram over [min, max] of the keys (1024 buckets: the float bit
-// patterns are spread evenly, no hot bins), the bucket holding the middle rank is compacted into a list and
-// ranked by brute force.  Two passes over the data instead of the radix select's five; falls back to the
-// radix select when the bucket holds more than kMedList elements (massive ties).
-// hist: 1024 counters, list: kMedList keys (LDS scratch); tmin / tmax: this thread's min / max key of v.
 constexpr int kMedList = 256;
-__device__ __forceinline__ float block_median_fast(const float *v, int n, MiscM *m, u32 *hist, u32 *list, u32 tmin, u32 tmax)
+// The part after the key range [kmin, kmax] is known to every thread.  Expects hist[0..1023] = 0 and m->sel_cle = 0, made
+// visible by a barrier.
+__device__ __forceinline__ float block_median_ranged(const float *v, int n, MiscM *m, u32 *hist, u32 *list, u32 kmin, u32 kmax)
 {
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    u32 *red_max = reinterpret_cast<u32 *>(m->red_f);
-    tmin = wave_umin_dpp(tmin);
-    tmax = ~wave_umin_dpp(~tmax);
-    __syncthreads();
-    if (lane == 0) { m->red_i[w] = (int)tmin; red_max[w] = tmax; }
-    for (int i = tid; i < 1024; i += kBlockM) hist[i] = 0;
-    if (tid == 0) m->sel_cle = 0;
-    __syncthreads();
-    u32 kmin = (u32)m->red_i[0], kmax = red_max[0];
-    for (int q = 1; q < kWavesM; ++q) { const u32 a = (u32)m->red_i[q], b = red_max[q]; kmin = a < kmin ? a : kmin; kmax = b > kmax ? b : kmax; }
     const u32 range = kmax - kmin;
     const int shift = range < 1024u ? 0 : 22 - __clz(range);           // (range >> shift) < 1024
     for (int i = tid; i < n; i += kBlockM) atomicAdd(&hist[(f2key(v[i]) - kmin) >> shift], 1u);
@@ -284,13 +271,17 @@ __device__ __forceinline__ float block_median_fast(const float *v, int n, MiscM 
     __syncthreads();
     const u32 bin = m->sel_key, before = (u32)m->red_i[14], cnt = (u32)m->red_i[15];
     if (cnt > (u32)kMedList) return block_median(v, n, m, hist);       // block-uniform
-    u32 above = 0xffffffffu;                                           // smallest key beyond the bucket
+    // the second middle value of an even-sized set lies in the same bucket unless the first is the bucket's last
+    // element (block-uniform): only then is the smallest key beyond the bucket needed
+    const bool need_above = two && !(k1 + 1 - before < cnt);
+    u32 above = 0xffffffffu;
     for (int i = tid; i < n; i += kBlockM) {
         const u32 key = f2key(v[i]), b = (key - kmin) >> shift;
         if (b == bin) list[atomicAdd(&m->sel_cle, 1u)] = key;
-        else if (b > bin && key < above) above = key;
+        else if (need_above && b > bin && key < above) above = key;
     }
-    above = block_min(above, m);                                       // (barriers inside: the list is complete)
+    if (need_above) above = block_min(above, m);                       // (barriers inside: the list is complete)
+    else __syncthreads();
     if ((u32)tid < cnt) {
         const u32 mine = list[tid];
         u32 rank = 0;
@@ -301,8 +292,29 @@ __device__ __forceinline__ float block_median_fast(const float *v, int n, MiscM 
     __syncthreads();
     const u32 key1 = m->sel_key;
     if (!two) return key2f(key1);
-    const u32 key2 = (k1 + 1 - before < cnt) ? (u32)m->best_key : above;
+    const u32 key2 = need_above ? above : (u32)m->best_key;
     return (key2f(key1) + key2f(key2)) / 2.0f;
+}
+
+// np.median, fast path: one log-spaced histogram over [min, max] of the keys (1024 buckets: the float bit
+// patterns are spread evenly, no hot bins), the bucket holding the middle rank is compacted into a list and
+// ranked by brute force.  Two passes over the data instead of the radix select's five; falls back to the
+// radix select when the bucket holds more than kMedList elements (massive ties).
+// hist: 1024 counters, list: kMedList keys (LDS scratch); tmin / tmax: this thread's min / max key of v.
+__device__ __forceinline__ float block_median_fast(const float *v, int n, MiscM *m, u32 *hist, u32 *list, u32 tmin, u32 tmax)
+{
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    u32 *red_max = reinterpret_cast<u32 *>(m->red_f);
+    tmin = wave_umin_dpp(tmin);
+    tmax = ~wave_umin_dpp(~tmax);
+    __syncthreads();
+    if (lane == 0) { m->red_i[w] = (int)tmin; red_max[w] = tmax; }
+    for (int i = tid; i < 1024; i += kBlockM) hist[i] = 0;
+    if (tid == 0) m->sel_cle = 0;
+    __syncthreads();
+    u32 kmin = (u32)m->red_i[0], kmax = red_max[0];
+    for (int q = 1; q < kWavesM; ++q) { const u32 a = (u32)m->red_i[q], b = red_max[q]; kmin = a < kmin ? a : kmin; kmax = b > kmax ? b : kmax; }
+    return block_median_ranged(v, n, m, hist, list, kmin, kmax);
 }
 
 // two block sums with one pair of barriers (scratch: the rotation table of the template phase, dead by now)
@@ -1434,9 +1446,24 @@ __device__ __noinline__ void ph_hessian(unsigned flags, int iy, int ix, float be
     if (dbg_cycles && tid == 0) dbg_cycles[14] = (long long)clock64();
     float h = hes[iy * rw + ix];
     if (flags & 1u) {
-        block_sum2(sx, sxx, m);
-        const float sd = std_from_sums(sx, sxx, npos);
-        const float med = block_median_fast(hes, npos, m, hist4, medlist, f2key(hmin), f2key(hmax));
+        // one reduction round for the two sums and the key range (instead of one for the sums and one for the range)
+        const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+        u32 *red_max = reinterpret_cast<u32 *>(m->red_f);
+        const double wsx = wave_sum_dpp_d(sx), wsxx = wave_sum_dpp_d(sxx);
+        const u32 wmin = wave_umin_dpp(f2key(hmin)), wmax = ~wave_umin_dpp(~f2key(hmax));
+        if (lane == 0) { m->rot[w][0] = wsx; m->rot[w][1] = wsxx; m->red_i[w] = (int)wmin; red_max[w] = wmax; }
+        for (int i = tid; i < 1024; i += kBlockM) hist4[i] = 0;
+        if (tid == 0) m->sel_cle = 0;
+        __syncthreads();
+        double tx = 0.0, txx = 0.0;
+        u32 kmin = 0xffffffffu, kmax = 0u;
+        for (int q = 0; q < kWavesM; ++q) {
+            tx += m->rot[q][0]; txx += m->rot[q][1];
+            const u32 a = (u32)m->red_i[q], b = red_max[q];
+            kmin = a < kmin ? a : kmin; kmax = b > kmax ? b : kmax;
+        }
+        const float sd = std_from_sums(tx, txx, npos);
+        const float med = block_median_ranged(hes, npos, m, hist4, medlist, kmin, kmax);
         h = (h - med) / sd;
     }
     __syncthreads();
