@@ -219,7 +219,7 @@ bool use_rp(int s, int K)
 
 int lds_need(int wh, int ww, int s, int K, int band = 4)
 {
-    if (use_rp(s, K)) return sid::rp_lds_layout(wh, ww, s, K <= sid::kRpGroup).total;
+    if (use_rp(s, K)) return sid::rp_lds_layout(wh, ww, s, K <= sid::kRpGroup, band).total;
     return sid::mfma_lds_layout(wh, ww, s, band, use_paired(K) && band == 4).total;
 }
 
@@ -277,7 +277,7 @@ int classify_points(sid_pm_ctx *ctx)
     const double *c2fg = ctx->h_c2fg.data(), *r2fg = ctx->h_r2fg.data(), *border = ctx->h_border.data();
     struct P { int idx; int lds; int cls; double work; int band = 4; bool force1 = false, force2 = false; };
     static const bool no_band8 = getenv("SID_PM_NO_BAND8") != nullptr;                      // A/B runs
-    const bool band8_ok = sid::mfma_band8_supported(s) && !no_band8 && !use_paired(K) && !use_rp(s, K);
+    const bool band8_ok = sid::mfma_band8_supported(s) && !no_band8 && !use_paired(K);   // (classic and row-pair kernels alike)
     std::vector<P> pts((size_t)n);
     const int lds_min = lds_need(s + 1, s + 1, s, K);
     double macs = 0, bytes = 0, valid = 0;
@@ -292,7 +292,8 @@ int classify_points(sid_pm_ctx *ctx)
                             (long long)i, wh, ww, need, sid::max_lds_bytes());
             p.lds = need;
             // the two-per-CU class runs the 8-row-band kernel (two wavefronts per SIMD leave it 256 VGPRs); its
-            // window carries 4 more zero rows, and a point that then no longer fits twice stays with band 4
+            // window carries a few more zero rows, and a point that then no longer fits twice joins the one-per-CU
+            // class (a launch of their own for the few points in between costs more than it saves)
             if (band8_ok && blocks_per_cu(need) == 2) {
                 const int need8 = lds_need(wh, ww, s, K, 8);
                 if (blocks_per_cu(need8) >= 2) { p.lds = need8; p.band = 8; p.force2 = true; }
@@ -593,7 +594,7 @@ SID_EXPORT int sid_pm_run(sid_pm_ctx *ctx)
         const int per_cu = std::max(1, std::min(b.band == 8 ? 2 : 8, blocks_per_cu(b.lds)));
         const int nthreads = b.band == 8 ? 256 : (per_cu == 1 ? 768 : 256);
         const int e = use_rp(ctx->img_size, ctx->n_angles)
-                          ? sid::launch_pm_rp(A, lds_launch, nthreads, ctx->stream)
+                          ? sid::launch_pm_rp(A, lds_launch, nthreads, b.band, ctx->stream)
                           : sid::launch_pm_mfma(A, lds_launch, nthreads, b.band, use_paired(ctx->n_angles), ctx->stream);
         if (e != 0) return fail(SID_PM_ERR_HIP, "kernel launch failed: %s", hipGetErrorString((hipError_t)e));
     }
@@ -747,7 +748,7 @@ SID_EXPORT int sid_pm_debug_point(sid_pm_ctx *ctx, double c1, double r1, double 
         gauss_taps(A.gauss_w);
         A.samp = sampv.empty() ? nullptr : dsamp.p; A.samp_nflag = nflag;
         A.lds_bytes = lds;
-        step((hipError_t)(use_rp(s, K) ? sid::launch_pm_rp(A, lds, 256, ctx->stream)
+        step((hipError_t)(use_rp(s, K) ? sid::launch_pm_rp(A, lds, 256, 4, ctx->stream)
                                        : sid::launch_pm_mfma(A, lds, 256, 4, use_paired(K), ctx->stream)));
         step(hipStreamSynchronize(ctx->stream));
         if (templates) step(hipMemcpy(templates, dt.p, tcount, hipMemcpyDeviceToHost));

@@ -37,7 +37,7 @@ struct PMArgs {
 __host__ __device__ inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
 // ---- MFMA kernel (pm_kernel_mfma.hip) ----
-constexpr int kMiscMfmaBytes = 3072;
+constexpr int kMiscMfmaBytes = 2688;
 constexpr int kTrowPad = 36;         // zero rows around a winner operand block: 16 above, 20 below (the step loop runs in fours)
 constexpr int kQueueCap = 192;       // arg-max candidates waiting for exact evaluation (16 B each)
 
@@ -117,11 +117,23 @@ __host__ __device__ inline bool rp_size_supported(int s) { return s == 34 || s =
 
 // one_group: all angles fit one group of MFMA slots (K <= 15).  The winner then takes its template from the sweep's
 // operand table, the image-1 patch is dead once the table is built and the candidate queue lies over it.
-__host__ __device__ inline RpLdsLayout rp_lds_layout(int wh, int ww, int s, bool one_group)
+// first output row of band `b` of `nbands` (multiple of 4: the column-pair reads are 8-byte aligned)
+__host__ __device__ inline int rp_band_y0(int b, int nbands, int rh, int band)
+{
+    int y0 = b * band;
+    if (band == 8 && b == nbands - 1 && nbands > 1) {
+        const int up = round_up(rh - 8, 4);
+        if (up < y0) y0 = up;
+    }
+    return y0;
+}
+
+// band: output rows per sweep work item (4, or 8 for the two-workgroups-per-CU class).
+__host__ __device__ inline RpLdsLayout rp_lds_layout(int wh, int ww, int s, bool one_group, int band = 4)
 {
     RpLdsLayout L;
     const int rh = wh - s + 1, rw = ww - s + 1;
-    const int nE = (s + 1) / 2, nO = s / 2 + 1, nst = (nE > nO ? nE : nO) + 1;
+    const int nE = (s + 1) / 2, nO = s / 2 + 1, nst = (nE > nO ? nE : nO) + band / 2 - 1;
     const int rem = rw % 32;
     L.npair = rw / 32 + (rem > 16 ? 1 : 0);
     L.nsingle = (rem > 0 && rem <= 16) ? 1 : 0;
@@ -132,7 +144,9 @@ __host__ __device__ inline RpLdsLayout rp_lds_layout(int wh, int ww, int s, bool
     if (L.npair && 32 * (L.npair - 1) + 80 > need) need = 32 * (L.npair - 1) + 80;
     if (L.nsingle && 32 * L.npair + 68 > need) need = 32 * L.npair + 68;
     L.wpitch = round_up(need, 8);
-    const int y0max = 4 * ((rh + 3) / 4 - 1);
+    // first row of the last band: an 8-row band whose last item would hang over the matrix by more than 4 rows is pulled
+    // up instead (it overlaps the one before; rp_band_y0) - fewer zero rows below the window, shorter column-pair rows
+    const int y0max = rp_band_y0((rh + band - 1) / band - 1, (rh + band - 1) / band, rh, band);
     L.wrows = y0max + 2 * nst;                       // last step reads rows y0 + 2 (nst - 1) and + 1
     if (L.wrows < wh + 3) L.wrows = wh + 3;
     L.win_off = kMiscMfmaBytes;
@@ -140,7 +154,8 @@ __host__ __device__ inline RpLdsLayout rp_lds_layout(int wh, int ww, int s, bool
     L.u_off = round_up(L.sii_off + rh * rw * 4, 16);
     L.ncp = (s - 32 + 1) / 2; L.nrg = 2;
     L.wp_rows = rw + 2 * (L.ncp - 1);
-    L.wp_len = y0max + 44;                           // entries rho = 0 .. y0max + 3 + 32 + 8 (+ slack of a 24-byte read)
+    L.wp_len = y0max + 40 + band;                    // last read: entries y0max + 32 .. + 32 + 11 (band 4: 24 bytes) / + 15 (band 8: 32 bytes)
+    //                           // entries rho = 0 .. y0max + 3 + 32 + 8 (+ slack of a 24-byte read)
     L.wp_pitch = round_up(2 * L.wp_len, 8);
     if (!((L.wp_pitch / 8) & 1)) L.wp_pitch += 8;    // 8 x odd: at most two-way bank conflicts for the lane-private rows
     L.tab_rows = s + 3;
@@ -167,7 +182,7 @@ __host__ __device__ inline RpLdsLayout rp_lds_layout(int wh, int ww, int s, bool
     return L;
 }
 
-int launch_pm_rp(const PMArgs &args, int lds_bytes, int nthreads, void *stream);
+int launch_pm_rp(const PMArgs &args, int lds_bytes, int nthreads, int band, void *stream);
 
 __host__ __device__ inline int samp_pitch(int s) { return round_up(s, 4); }
 constexpr double kSampGuard = 1e-5;   // table entries whose coordinate is this close to k + 1/2 are flagged

@@ -59,7 +59,6 @@ constexpr int kAnglesPerGroup = kRpGroup;
 constexpr float kMargin = 1e-5f;     // pre-filter margin (see header)
 
 struct MiscM {                       // LDS offset 0, kMiscMfmaBytes reserved
-    double red_d[16];
     float red_f[16];
     int red_i[16];
     u32 sel_key, sel_cle;
@@ -73,7 +72,6 @@ struct MiscM {                       // LDS offset 0, kMiscMfmaBytes reserved
     double rot[kSlots][4];           // cos, sin, tcT0, tcT1 of the current group's angles
     double rTd[kMaxAngles];          // 1/sqrt(dT) per angle
     double sTd[kMaxAngles];          // sum t' per angle
-    float rTf[kMaxAngles];
     int constT[kMaxAngles];
     // row-pair kernel: float32 pre-filter terms of the current group's slots (pm_kernel_rp.inc), 16-byte aligned:
     // a lane fetches the terms of its four slots with one ds_read_b128 each
@@ -99,7 +97,7 @@ struct Geo {
     long long r0, c0;                // window origin on image 2
     double c1, r1, nd;
 };
-constexpr int kGeoOff = 2816;
+constexpr int kGeoOff = 2432;
 static_assert(sizeof(MiscM) <= kGeoOff, "misc header too large");
 static_assert(kGeoOff + sizeof(Geo) <= kMiscMfmaBytes, "geometry block does not fit the LDS header");
 
@@ -930,7 +928,6 @@ __device__ __noinline__ void ph_tpl_end(int a0, int Kg, uint8_t *dbg_templates, 
         m->sTd[a0 + tid] = st;
         m->constT[a0 + tid] = dT == 0.0 ? 1 : 0;
         m->rTd[a0 + tid] = rT;
-        m->rTf[a0 + tid] = dT == 0.0 ? NAN : (float)rT;               // NaN estimate => always a candidate
     }
     __syncthreads();
 }
@@ -1719,12 +1716,14 @@ int launch_pm_mfma(const PMArgs &args, int lds_bytes, int nthreads, int band, bo
     return (int)hipGetLastError();
 }
 
-int launch_pm_rp(const PMArgs &args, int lds_bytes, int nthreads, void *stream)
+int launch_pm_rp(const PMArgs &args, int lds_bytes, int nthreads, int band, void *stream)
 {
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (args.n_launch <= 0) return (int)hipSuccess;
     if (!rp_size_supported(args.img_size)) return (int)hipErrorInvalidValue;
-    void (*kern)(const PMArgs) = args.img_size == 34 ? pm_kernel_rp<34> : pm_kernel_rp<35>;
+    if ((band != 4 && band != 8) || (band == 8 && nthreads != 256)) return (int)hipErrorInvalidValue;
+    void (*kern)(const PMArgs) = band == 8 ? (args.img_size == 34 ? pm_kernel_rp<34, 8> : pm_kernel_rp<35, 8>)
+                                           : (args.img_size == 34 ? pm_kernel_rp<34> : pm_kernel_rp<35>);
     const hipError_t e = allow_max_lds(kern);
     if (e != hipSuccess) return (int)e;
     if (lds_bytes > max_lds_bytes() || nthreads < 256 || nthreads > 768 || (nthreads & 63)) return (int)hipErrorInvalidValue;
