@@ -321,7 +321,7 @@ def grid_mode(args, torch, dist, dev, world, rank, local_rank):
             'bound': 'mfma', 'achieved': mfma_achieved, 'peak': MFMA_I8_PEAK_TOPS, 'unit': 'TFLOP/s',
             'frac': mfma_achieved / MFMA_I8_PEAK_TOPS, 'traffic': traffic, 'traffic_note': traffic_note,
             'kernel': ('sid::pm_kernel_rp<%d> (row-pair sweep; one launch per LDS class: 3 / 2 / 1 workgroups per CU)' % s
-                       if s in (34, 35) and len(angles) > 7 else
+                       if s in (34, 35) and not os.environ.get('SID_PM_NO_RP') else
                        'sid::pm_kernel_mfma<%d,...> (classic sweep: one instantiation per band height / pairing)' % (s if s in (34, 35) else 0)),
             'launches_per_step': launches, 'kernel_ms_per_step': kern_ms, 'avg_launch_ms': kern_ms / launches,
             'algorithmic_macs_per_step': info['macs'], 'algorithmic_bytes_per_step': info['hbm_bytes'],

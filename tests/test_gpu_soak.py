@@ -1,9 +1,10 @@
 """Determinism soak (race detector) as part of the GPU suite.
 
 Every configuration runs the same 6 400-point workload 200 times on one handle; every repetition must be bit-identical
-to the first, and the first equals the C oracle on a subsample.  Covers the row-pair sweep (15 angles), the classic
-paired-slot sweep (7 angles), the table sampler and the on-the-fly sampler (SID_PM_NO_SAMP_TABLE, read at every
-set_points), mixed and large borders (all three residency classes).  History: DESIGN.md section 6b.
+to the first, and the first equals the C oracle on a subsample.  Covers the row-pair sweep (15 and 7 angles, 4- and
+8-row bands), the classic kernel's paired-slot and 8-row-band sweeps (SID_PM_NO_RP), the table sampler and the
+on-the-fly sampler (SID_PM_NO_SAMP_TABLE; both switches are read at every set_points), mixed and large borders (all
+three residency classes).  History: DESIGN.md section 6b.
 """
 import os
 
@@ -23,22 +24,27 @@ def workload():
     return img1, img2, size
 
 
-@pytest.mark.parametrize('angles,img_size,border,no_table', [
-    (7, 34, 'mixed', False),     # 15 angles: row-pair sweep, table sampler
-    (7, 34, 'mixed', True),      # ... on-the-fly sampler
-    (3, 34, 'mixed', False),     # 7 angles: paired-slot sweep
-    (3, 34, 'mixed', True),
-    (7, 35, 44, False),          # reference default template side, large windows (one workgroup per CU)
-    (7, 34, 28, False),          # two workgroups per CU
+@pytest.mark.parametrize('angles,img_size,border,no_table,no_rp', [
+    (7, 34, 'mixed', False, False),     # 15 angles: row-pair sweep, table sampler
+    (7, 34, 'mixed', True, False),      # ... on-the-fly sampler
+    (3, 34, 'mixed', False, False),     # 7 angles: row-pair sweep with half of its slots idle
+    (3, 34, 'mixed', False, True),      # ... the classic kernel's paired-slot sweep (SID_PM_NO_RP)
+    (3, 34, 'mixed', True, True),
+    (7, 35, 44, False, False),          # reference default template side, large windows (one workgroup per CU)
+    (7, 34, 28, False, False),          # two workgroups per CU: 8-row band
+    (7, 34, 30, False, True),           # ... of the classic kernel
 ])
-def test_repeated_runs_are_bit_identical(workload, c_oracle, angles, img_size, border, no_table):
+def test_repeated_runs_are_bit_identical(workload, c_oracle, angles, img_size, border, no_table, no_rp):
     img1, img2, size = workload
     g = syn.make_grid(size, size, 80, border=border)
     ang = list(range(-angles, angles + 1))
     rot = my.rotation_table(ang, 0.0, img_size)
     old = os.environ.pop('SID_PM_NO_SAMP_TABLE', None)
+    old_rp = os.environ.pop('SID_PM_NO_RP', None)
     if no_table:
         os.environ['SID_PM_NO_SAMP_TABLE'] = '1'
+    if no_rp:
+        os.environ['SID_PM_NO_RP'] = '1'
     try:
         with _capi.PMContext(0) as ctx:
             ctx.upload_pair(img1, img2)
@@ -53,8 +59,11 @@ def test_repeated_runs_are_bit_identical(workload, c_oracle, angles, img_size, b
                 bad += int((~same).sum())
     finally:
         os.environ.pop('SID_PM_NO_SAMP_TABLE', None)
+        os.environ.pop('SID_PM_NO_RP', None)
         if old is not None:
             os.environ['SID_PM_NO_SAMP_TABLE'] = old
+        if old_rp is not None:
+            os.environ['SID_PM_NO_RP'] = old_rp
     assert bad == 0, '%d point results differed between repetitions' % bad
     sel = np.arange(0, len(ref), 53)
     exp, exp_ij = c_oracle.pm_batch(img1, img2, g['c1'][sel], g['r1'][sel], g['c2fg'][sel], g['r2fg'][sel],
