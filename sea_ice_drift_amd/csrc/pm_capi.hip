@@ -91,7 +91,7 @@ struct sid_pm_ctx {
     int32_t *d_order = nullptr;
     double *d_angles = nullptr, *d_rot = nullptr;
     uint16_t *d_samp = nullptr;         // sampling table of the kernel (make_samp)
-    bool rp = false;                    // the resident points run the row-pair kernel (decided at set_points: use_rp)
+    bool rp = false, rp_paired = false; // the resident points run the row-pair kernel (decided at set_points: use_rp), with paired slots
     bool have_samp = false;             // SID_PM_NO_SAMP_TABLE=1 keeps the on-the-fly sampling (tests of the general sampler)
     int samp_nflag = 0;
     // host copies of what the classification needs: the launch classes depend on the shape of image 2, so a
@@ -222,9 +222,16 @@ bool use_rp(int s, int K)
     return sid::rp_size_supported(s) && getenv("SID_PM_NO_RP") == nullptr;
 }
 
-int lds_need(bool rp, int wh, int ww, int s, int K, int band = 4)
+// row-pair kernel with at most 7 angles: paired slots (8 output rows per item with the 4-row kernel's registers; the LDS
+// layout is that of an 8-row band)
+bool rp_paired(int K)
 {
-    if (rp) return sid::rp_lds_layout(wh, ww, s, K <= sid::kRpGroup, band).total;
+    return K <= sid::kPairedMaxAngles && getenv("SID_PM_NO_PAIRED") == nullptr;
+}
+
+int lds_need(bool rp, bool rpp, int wh, int ww, int s, int K, int band = 4)
+{
+    if (rp) return sid::rp_lds_layout(wh, ww, s, K <= sid::kRpGroup, rpp ? 8 : band).total;
     return sid::mfma_lds_layout(wh, ww, s, band, use_paired(K) && band == 4).total;
 }
 
@@ -283,16 +290,17 @@ int classify_points(sid_pm_ctx *ctx)
     struct P { int idx; int lds; int cls; double work; int band = 4; bool force1 = false, force2 = false; };
     static const bool no_band8 = getenv("SID_PM_NO_BAND8") != nullptr;                      // A/B runs
     const bool rp = ctx->rp;
-    const bool band8_ok = sid::mfma_band8_supported(s) && !no_band8 && (rp || !use_paired(K));   // (classic and row-pair kernels alike)
+    const bool band8_ok = sid::mfma_band8_supported(s) && !no_band8 && (rp ? !ctx->rp_paired : !use_paired(K));   // (classic and row-pair kernels alike)
     std::vector<P> pts((size_t)n);
-    const int lds_min = lds_need(rp, s + 1, s + 1, s, K);
+    const bool rpp = ctx->rp_paired;
+    const int lds_min = lds_need(rp, rpp, s + 1, s + 1, s, K);
     double macs = 0, bytes = 0, valid = 0;
     int lds_max = 0;
     for (int64_t i = 0; i < n; ++i) {
         int wh = 0, ww = 0;
         P p; p.idx = (int)i; p.lds = lds_min; p.cls = 0; p.work = 0.0;
         if (window_dims(c2fg[i], r2fg[i], border[i], s, rows2, cols2, wh, ww)) {
-            const int need = lds_need(rp, wh, ww, s, K);
+            const int need = lds_need(rp, rpp, wh, ww, s, K);
             if (need > sid::max_lds_bytes())
                 return fail(SID_PM_ERR_UNSUPPORTED, "point %lld: search window %dx%d needs %d bytes of LDS (> %d)",
                             (long long)i, wh, ww, need, sid::max_lds_bytes());
@@ -301,7 +309,7 @@ int classify_points(sid_pm_ctx *ctx)
             // window carries a few more zero rows, and a point that then no longer fits twice joins the one-per-CU
             // class (a launch of their own for the few points in between costs more than it saves)
             if (band8_ok && blocks_per_cu(need) == 2) {
-                const int need8 = lds_need(rp, wh, ww, s, K, 8);
+                const int need8 = lds_need(rp, rpp, wh, ww, s, K, 8);
                 if (blocks_per_cu(need8) >= 2) { p.lds = need8; p.band = 8; p.force2 = true; }
                 else p.force1 = true;
             }
@@ -557,7 +565,7 @@ SID_EXPORT int sid_pm_set_points(sid_pm_ctx *ctx, const double *c1, const double
     ctx->h_c2fg.assign(c2fg, c2fg + n); ctx->h_r2fg.assign(r2fg, r2fg + n); ctx->h_border.assign(border, border + n);
 
     ctx->user_out = nullptr; ctx->user_ij = nullptr;
-    ctx->n = n; ctx->img_size = s; ctx->n_angles = K; ctx->flags = flags; ctx->rp = use_rp(s, K);
+    ctx->n = n; ctx->img_size = s; ctx->n_angles = K; ctx->flags = flags; ctx->rp = use_rp(s, K); ctx->rp_paired = ctx->rp && rp_paired(K);
     ctx->have_points = false;
     if (int rc = classify_points(ctx)) return rc;
     ctx->have_points = true;
@@ -600,7 +608,7 @@ SID_EXPORT int sid_pm_run(sid_pm_ctx *ctx)
         const int per_cu = std::max(1, std::min(b.band == 8 ? 2 : 8, blocks_per_cu(b.lds)));
         const int nthreads = b.band == 8 ? 256 : (per_cu == 1 ? 768 : 256);
         const int e = ctx->rp
-                          ? sid::launch_pm_rp(A, lds_launch, nthreads, b.band, ctx->stream)
+                          ? sid::launch_pm_rp(A, lds_launch, nthreads, b.band, ctx->rp_paired, ctx->stream)
                           : sid::launch_pm_mfma(A, lds_launch, nthreads, b.band, use_paired(ctx->n_angles), ctx->stream);
         if (e != 0) return fail(SID_PM_ERR_HIP, "kernel launch failed: %s", hipGetErrorString((hipError_t)e));
     }
@@ -701,10 +709,10 @@ SID_EXPORT int sid_pm_debug_point(sid_pm_ctx *ctx, double c1, double r1, double 
     if (int rc = check_sweep(img_size, angles, n_angles, flags)) return rc;
     Guard g(ctx->device);
     const int s = img_size, K = n_angles;
-    const bool rp = use_rp(s, K);
-    int wh = 0, ww = 0, lds = lds_need(rp, s + 1, s + 1, s, K);
+    const bool rp = use_rp(s, K), rpp = rp && rp_paired(K);
+    int wh = 0, ww = 0, lds = lds_need(rp, rpp, s + 1, s + 1, s, K);
     if (window_dims(c2fg, r2fg, border, s, ctx->cur[1].rows, ctx->cur[1].cols, wh, ww))
-        lds = lds_need(rp, wh, ww, s, K);
+        lds = lds_need(rp, rpp, wh, ww, s, K);
     if (lds > sid::max_lds_bytes()) return fail(SID_PM_ERR_UNSUPPORTED, "search window too large for LDS");
     std::vector<double> rotv;
     make_rot(angles, K, alpha0, s, rot, rotv);
@@ -755,7 +763,7 @@ SID_EXPORT int sid_pm_debug_point(sid_pm_ctx *ctx, double c1, double r1, double 
         gauss_taps(A.gauss_w);
         A.samp = sampv.empty() ? nullptr : dsamp.p; A.samp_nflag = nflag;
         A.lds_bytes = lds;
-        step((hipError_t)(rp ? sid::launch_pm_rp(A, lds, 256, 4, ctx->stream)
+        step((hipError_t)(rp ? sid::launch_pm_rp(A, lds, 256, 4, rpp, ctx->stream)
                                        : sid::launch_pm_mfma(A, lds, 256, 4, use_paired(K), ctx->stream)));
         step(hipStreamSynchronize(ctx->stream));
         if (templates) step(hipMemcpy(templates, dt.p, tcount, hipMemcpyDeviceToHost));

@@ -182,7 +182,7 @@ __host__ __device__ inline RpLdsLayout rp_lds_layout(int wh, int ww, int s, bool
     return L;
 }
 
-int launch_pm_rp(const PMArgs &args, int lds_bytes, int nthreads, int band, void *stream);
+int launch_pm_rp(const PMArgs &args, int lds_bytes, int nthreads, int band, bool paired, void *stream);
 
 __host__ __device__ inline int samp_pitch(int s) { return round_up(s, 4); }
 constexpr double kSampGuard = 1e-5;   // table entries whose coordinate is this close to k + 1/2 are flagged

@@ -1716,13 +1716,15 @@ int launch_pm_mfma(const PMArgs &args, int lds_bytes, int nthreads, int band, bo
     return (int)hipGetLastError();
 }
 
-int launch_pm_rp(const PMArgs &args, int lds_bytes, int nthreads, int band, void *stream)
+int launch_pm_rp(const PMArgs &args, int lds_bytes, int nthreads, int band, bool paired, void *stream)
 {
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (args.n_launch <= 0) return (int)hipSuccess;
     if (!rp_size_supported(args.img_size)) return (int)hipErrorInvalidValue;
     if ((band != 4 && band != 8) || (band == 8 && nthreads != 256)) return (int)hipErrorInvalidValue;
-    void (*kern)(const PMArgs) = band == 8 ? (args.img_size == 34 ? pm_kernel_rp<34, 8> : pm_kernel_rp<35, 8>)
+    if (paired && (band != 4 || args.n_angles > kPairedMaxAngles)) return (int)hipErrorInvalidValue;
+    void (*kern)(const PMArgs) = paired ? (args.img_size == 34 ? pm_kernel_rp<34, 4, true> : pm_kernel_rp<35, 4, true>)
+                               : band == 8 ? (args.img_size == 34 ? pm_kernel_rp<34, 8> : pm_kernel_rp<35, 8>)
                                            : (args.img_size == 34 ? pm_kernel_rp<34> : pm_kernel_rp<35>);
     const hipError_t e = allow_max_lds(kern);
     if (e != hipSuccess) return (int)e;

@@ -27,7 +27,9 @@ def workload():
 @pytest.mark.parametrize('angles,img_size,border,no_table,no_rp', [
     (7, 34, 'mixed', False, False),     # 15 angles: row-pair sweep, table sampler
     (7, 34, 'mixed', True, False),      # ... on-the-fly sampler
-    (3, 34, 'mixed', False, False),     # 7 angles: row-pair sweep with half of its slots idle
+    (3, 34, 'mixed', False, False),     # 7 angles: row-pair sweep with paired slots (8 output rows per item)
+    (3, 35, 'mixed', True, False),      # ... on-the-fly sampler, template side 35 (three strip columns)
+    (1, 34, 30, False, False),          # 3 angles (the reference's default), two workgroups per CU
     (3, 34, 'mixed', False, True),      # ... the classic kernel's paired-slot sweep (SID_PM_NO_RP)
     (3, 34, 'mixed', True, True),
     (7, 35, 44, False, False),          # reference default template side, large windows (one workgroup per CU)
