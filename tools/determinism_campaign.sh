@@ -1,0 +1,21 @@
+#!/bin/bash
+# A longer determinism campaign than tests/test_gpu_soak.py (through gpurun): every line must report 0 differing results.
+R=${GRAFT_REPO_ROOT:-$PWD}; OUT=$R/gpurun_out/campaign.txt; : > $OUT
+run() { timeout 900 python3 $R/tools/determinism_check.py "$@" 2>/dev/null | tail -1 >> $OUT; }
+run 4000 1000 --angles 7
+run 4000 500 --angles 7 --no-table
+run 4000 500 --angles 3
+run 4000 300 --angles 3 --no-table
+run 4000 300 --angles 1
+run 4000 300 --angles 7 --img-size 35
+run 4000 300 --angles 3 --img-size 35
+run 4000 200 --angles 7 --border 28
+run 4000 200 --angles 7 --border 36
+run 4000 100 --angles 7 --border 50
+run 4000 200 --angles 3 --border 30
+run 10000 100 --angles 7
+run 10000 60 --angles 3
+SID_PM_NO_RP=1 run 4000 300 --angles 7
+SID_PM_NO_RP=1 run 4000 300 --angles 3
+run 4000 200 --angles 10 --img-size 40
+cat $OUT
