@@ -9,6 +9,7 @@ uint8 image in, key points + uint8 [N, 32] descriptors out - but not OpenCV's ke
 The tables below (directions, comparison pattern) are part of the specification and are shared with the oracle.
 """
 import ctypes as C
+import functools
 
 import numpy as np
 
@@ -17,10 +18,17 @@ PATTERN_RADIUS = 13
 PATTERN_SEED = 20240531
 
 
-def direction_table():
-    """[32, 2] int32: round(2^14 cos), round(2^14 sin) of the directions 2 pi b / 32."""
+@functools.lru_cache(maxsize=None)
+def _direction_table():
     th = 2.0 * np.pi * np.arange(N_DIRS) / N_DIRS
-    return np.stack([np.rint(16384.0 * np.cos(th)), np.rint(16384.0 * np.sin(th))], axis=1).astype(np.int32)
+    out = np.stack([np.rint(16384.0 * np.cos(th)), np.rint(16384.0 * np.sin(th))], axis=1).astype(np.int32)
+    out.setflags(write=False)
+    return out
+
+
+def direction_table():
+    """[32, 2] int32: round(2^14 cos), round(2^14 sin) of the directions 2 pi b / 32 (built once, read-only)."""
+    return _direction_table()
 
 
 def base_pattern():
@@ -37,8 +45,8 @@ def base_pattern():
     return pts
 
 
-def rotated_pattern():
-    """[32, 256, 4] int8: the base pattern rotated to every direction (rounded to pixels)."""
+@functools.lru_cache(maxsize=None)
+def _rotated_pattern():
     base = base_pattern().astype(np.float64)
     th = 2.0 * np.pi * np.arange(N_DIRS) / N_DIRS
     out = np.empty((N_DIRS, 256, 4), dtype=np.int8)
@@ -48,7 +56,13 @@ def rotated_pattern():
             x, y = base[:, k], base[:, k + 1]
             out[b, :, k] = np.rint(x * c - y * s).astype(np.int8)
             out[b, :, k + 1] = np.rint(x * s + y * c).astype(np.int8)
+    out.setflags(write=False)
     return out
+
+
+def rotated_pattern():
+    """[32, 256, 4] int8: the base pattern rotated to every direction, rounded to pixels (built once, read-only)."""
+    return _rotated_pattern()
 
 
 class OrbParams(C.Structure):
