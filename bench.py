@@ -14,7 +14,7 @@ touches torch or the GPU (a process that has initialised the GPU is never replac
     timed region.  A step = one pass of the hot path over the whole grid: kernel launches for every point,
     the gather of the packed (N,5) float64 + (N,3) int32 results to rank 0 (one RCCL gather when N > 1) and
     their copy to the host (the reference's seam ends with the results in the parent, pmlib.py:444,462).
-    N > 1 is STRONG scaling by default - the same 200x200 grid dealt to the ranks by search-window size
+    N > 1 is STRONG scaling by default - the same 200x200 grid cut into runs of equal estimated cost (by search border)
     (sea_ice_drift_amd/dist.py) - and the weak figure ((200*N)x200 grid, 40 000 points per GPU) is measured
     after it and reported under "weak_scaling"; ``--scaling weak`` makes the weak workload the headline.
 
@@ -119,14 +119,14 @@ class GridRun(object):
     def __init__(self, args, dev, world, rank, local_rank, t1, t2, n_rows, angles, rot):
         import torch
         from sea_ice_drift_amd import _capi, synthetic as syn
-        from sea_ice_drift_amd.dist import PackedGatherer, shard_indices
+        from sea_ice_drift_amd.dist import PackedGatherer, shard_indices_by_cost
         self.torch = torch
         s = args.img_size
         H = W = args.size
         border = args.border if args.border == 'mixed' else int(args.border)
         self.g = g = syn.make_grid(H, W, (n_rows, args.grid), border=border)
         self.n_total = g['c1'].size
-        self.idx = idx = shard_indices(g['border'], world, rank)
+        self.idx = idx = shard_indices_by_cost(g['border'], world, rank)   # (world 1: all points)
         self.ctx = _capi.PMContext(local_rank)
         self.ctx.set_stream(torch.cuda.current_stream().cuda_stream)
         self.ctx.bind_pair_tensors(t1, t2)
@@ -280,6 +280,7 @@ def grid_mode(args, torch, dist, dev, world, rank, local_rank):
     elapsed, kern_ms = timed_steps(torch, dist, world, run, args.steps, args.warmup)
     res, res_ij = run.results() if rank == 0 else (None, None)
     n_total, info, g = run.n_total, run.info, run.g
+    from sea_ice_drift_amd.dist import shard_indices_by_cost
     n_local = len(run.idx)
     run.close()
 
@@ -313,8 +314,10 @@ def grid_mode(args, torch, dist, dev, world, rank, local_rank):
                                'border %s, flags hes_norm' % (headline_rows, args.grid, H, W, s, len(angles), angles[0],
                                                              angles[-1], border),
                    'points_total': int(n_total), 'points_per_gpu': int(n_local),
+                   # (shards of equal estimated cost are unequal in length: rank 0 holds the largest windows)
+                   'points_per_gpu_all': [int(len(shard_indices_by_cost(run.g['border'], world, r))) for r in range(world)],
                    'parallelism': ('single GPU, no collective' if world == 1 else
-                                   'points dealt to %d GPUs by search-window size, one RCCL gather of the packed '
+                                   'points cut into %d runs of equal estimated cost (neighbouring borders per GPU), one RCCL gather of the packed '
                                    'result blocks to rank 0' % world)},
         'roofline': {
             # the sweep runs on v_mfma_i32_16x16x64_i8: the matrix cores are the roofline that bounds it

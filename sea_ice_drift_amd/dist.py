@@ -26,6 +26,42 @@ def shard_indices(border, world_size, rank):
     return np.sort(order[owner == rank])
 
 
+# Nanoseconds per grid point on one MI355X as a function of the search border (tools/border_cost.py: template side 34,
+# 15 angles, 40 000 points of one border each).  The cost is a staircase - it follows the number of placement tiles per
+# output row and the number of workgroups a CU can hold - and the ratios are the same for other angle counts.
+_BORDER_COST_NS = {20: 76.6, 21: 77.2, 22: 79.0, 23: 79.9, 24: 123.8, 25: 124.2, 26: 126.1, 27: 128.0, 28: 128.8, 29: 130.4,
+                   30: 132.1, 31: 133.7, 32: 172.8, 33: 174.3, 34: 176.4, 35: 177.2, 36: 184.6, 37: 246.9, 38: 247.1,
+                   39: 247.6, 40: 275.2, 41: 280.2, 42: 286.5, 43: 286.9, 44: 297.1, 45: 299.0, 46: 300.7, 47: 303.6,
+                   48: 355.1, 49: 359.6, 50: 368.7}
+
+
+def point_cost(border):
+    """Estimated relative cost of a grid point: the measured staircase inside its range, (2 b + 2)^2 scaled to it outside."""
+    b = np.asarray(border, dtype=np.float64)
+    bi = np.clip(np.rint(b), 20, 50).astype(np.int64)
+    table = np.array([_BORDER_COST_NS[k] for k in range(20, 51)])
+    cost = table[bi - 20]
+    outside = (b < 20) | (b > 50)
+    ref = np.where(b < 20, 20.0, 50.0)
+    scale = (2.0 * np.maximum(b, 0.0) + 2.0) ** 2 / (2.0 * ref + 2.0) ** 2
+    return np.where(outside, cost * np.maximum(scale, 0.05), cost)
+
+
+def shard_indices_by_cost(border, world_size, rank):
+    """Indices owned by `rank` when the points, ordered by border (largest first, stable), are cut into `world_size`
+    contiguous runs of equal estimated cost.  A rank then holds one or two neighbouring border classes instead of an
+    eighth of every class, i.e. one or two launches that are eight times longer: at 5 000 points per rank the tails of
+    three short launches cost a quarter of the step."""
+    border = np.asarray(border)
+    order = np.argsort(-border, kind='stable')
+    cum = np.cumsum(point_cost(border[order]))
+    total = cum[-1] if cum.size else 0.0
+    # point k goes to the rank whose cost interval holds the middle of its own
+    mid = cum - 0.5 * point_cost(border[order])
+    owner = np.minimum((mid * world_size / total).astype(np.int64), world_size - 1) if total > 0 else np.zeros(0, np.int64)
+    return np.sort(order[owner == rank])
+
+
 def shard_size(n_total, world_size):
     """Rows of the padded per-rank block (equal on all ranks so one gather suffices)."""
     return (int(n_total) + world_size - 1) // world_size
@@ -116,11 +152,17 @@ class PackedGatherer(object):
         self.rank = dist.get_rank(group) if self.distributed else 0
         self.is_dst = self.rank == dst
         self.n_total, self.device = int(n_total), torch.device(device)
-        self.m = m = shard_size(n_total, self.world)
         self.n_local = len(idx_local)
-        if self.n_local > m:
-            raise ValueError('shard larger than the padded block')
         self.host_staged = self.distributed and dist.get_backend(group) == 'gloo' and self.device.type != 'cpu'
+        # rows of the padded block = the largest shard (the shards of shard_indices_by_cost differ in length)
+        if self.world > 1:
+            t = torch.tensor([self.n_local], dtype=torch.int64,
+                             device='cpu' if dist.get_backend(group) == 'gloo' else self.device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+            m = int(t.item())
+        else:
+            m = self.n_local
+        self.m = m = max(m, 1)
         self.block = torch.zeros(m * self.ROW, dtype=torch.uint8, device=self.device)
         self.out_local = self.block[:m * 40].view(torch.float64).view(m, 5)
         self.ij_local = self.block[m * 40:].view(torch.int32).view(m, 3)

@@ -8,7 +8,8 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from sea_ice_drift_amd.dist import PackedGatherer, ResultGatherer, shard_indices, shard_size
+from sea_ice_drift_amd.dist import (PackedGatherer, ResultGatherer, point_cost, shard_indices, shard_indices_by_cost,
+                                    shard_size)
 
 
 def _free_port():
@@ -46,6 +47,16 @@ def _worker(rank, world, port, n_total, q):
     if rank == 0:
         p_out, p_ij = pg.host_results()
         assert np.array_equal(p_out, truth) and np.array_equal(p_ij, truth_ij)
+    # shards of equal estimated cost (what bench.py uses): unequal lengths, block rows = the largest shard
+    idx_c = shard_indices_by_cost(border, world, rank)
+    pc = PackedGatherer(n_total, idx_c, torch.device('cpu'))
+    o_v, j_v = pc.local_views()
+    o_v.copy_(torch.from_numpy(truth[idx_c]))
+    j_v.copy_(torch.from_numpy(truth_ij[idx_c]))
+    pc.gather_to_host()
+    if rank == 0:
+        c_out, c_ij = pc.host_results()
+        assert np.array_equal(c_out, truth) and np.array_equal(c_ij, truth_ij)
     if rank == 0:
         q.put((np.array_equal(out.numpy(), truth), np.array_equal(ij.numpy(), truth_ij),
                float(border[idx].sum()), len(idx)))
@@ -66,6 +77,21 @@ def test_shards_partition_and_balance():
         assert max(len(p) for p in parts) <= shard_size(1001, world)
         work = [((2 * border[p] + 2) ** 2).sum() for p in parts]
         assert max(work) / min(work) < 1.02                                   # balanced by window size
+
+
+def test_cost_shards_partition_and_balance():
+    rng = np.random.default_rng(2)
+    border = np.clip(np.floor(rng.rayleigh(16.0, 40000)), 20, 50)
+    for world in (1, 2, 4, 8):
+        parts = [shard_indices_by_cost(border, world, r) for r in range(world)]
+        np.testing.assert_array_equal(np.sort(np.concatenate(parts)), np.arange(border.size))   # a partition
+        cost = [point_cost(border[p]).sum() for p in parts]
+        assert max(cost) / min(cost) < 1.01                                                      # equal estimated cost
+        if world == 8:                                          # a rank holds neighbouring borders, not a bit of each
+            assert max(len(np.unique(border[p])) for p in parts) <= 16
+    assert shard_indices_by_cost(np.zeros(0), 4, 1).size == 0
+    np.testing.assert_array_equal(np.sort(np.concatenate([shard_indices_by_cost(np.full(5, 70.0), 2, r) for r in range(2)])),
+                                  np.arange(5))
 
 
 def test_two_rank_gather_roundtrip():

@@ -79,7 +79,8 @@ def test_config3_dry_run_bench_spawns_its_own_ranks():
     two = run_bench('--gpus', '2', '--steps', '3', '--warmup', '1', '--size', '3000', '--grid', '60', '--no-cpu-baseline')
     assert one['n_gpus'] == 1 and two['n_gpus'] == 2
     assert two['scaling'] == 'strong' and two['config']['points_total'] == one['config']['points_total'] == 3600
-    assert two['config']['points_per_gpu'] == 1800
+    assert sum(two['config']['points_per_gpu_all']) == 3600 and len(two['config']['points_per_gpu_all']) == 2
+    assert two['config']['points_per_gpu'] == two['config']['points_per_gpu_all'][0]
     assert two['parity_check']['ok'] and one['parity_check']['ok']
     assert two['weak_scaling']['points_total'] == 7200
     for d in (one, two):

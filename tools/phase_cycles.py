@@ -13,7 +13,7 @@ rot = rotation_table(angles, 0.0, 34)
 names = ['P0a window', 'P1 sums', 'P0b templates', 'P2 sweep', 'P3 argmax', 'P4 winner', 'P5 hessian']
 with _capi.PMContext(0) as ctx:
     ctx.upload_pair(img1, img2)
-    for b in (20, 35, 50):
+    for b in [int(x) for x in os.environ.get("SID_PHASE_BORDERS", "20,35,50").split(",")]:
         acc = []
         for i in (11, 45, 77, 78):
             d = ctx.debug_point(g['c1'][i], g['r1'][i], g['c2fg'][i], g['r2fg'][i], float(b), 34, 0.0, angles, rot=rot)

@@ -1,0 +1,37 @@
+#!/usr/bin/env python3
+"""What a strong-scaling step costs per rank under different ways of sharding the grid: every rank's shard is timed on
+the one GPU of this box (kernels + fetch, pair resident); the slowest shard is the predicted step time on `world` GPUs
+(before the gather).  Usage: python3 tools/shard_sim.py [world=8]"""
+import json, os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from sea_ice_drift_amd import _capi, dist, synthetic as syn
+from sea_ice_drift_amd.pmlib import rotation_table
+
+world = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+size, grid, s = 10000, 200, 34
+img1, img2 = syn.make_pair(size, size)
+g = syn.make_grid(size, size, grid)
+angles = list(range(-7, 8)); rot = rotation_table(angles, 0.0, s)
+schemes = {'snake deal by border (dist.shard_indices)': lambda r: dist.shard_indices(g['border'], world, r)}
+if hasattr(dist, 'shard_indices_by_cost'):
+    schemes['contiguous chunks of equal estimated cost (dist.shard_indices_by_cost)'] = lambda r: dist.shard_indices_by_cost(g['border'], world, r)
+out = {}
+with _capi.PMContext(0) as ctx:
+    ctx.upload_pair(img1, img2)
+    def timed(idx, steps=30):
+        ctx.set_points(g['c1'][idx], g['r1'][idx], g['c2fg'][idx], g['r2fg'][idx], g['border'][idx], s, 0.0, angles, rot=rot)
+        for _ in range(3):
+            ctx.run(); ctx.fetch(want_ij=False)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            ctx.run(); ctx.fetch(want_ij=False)
+        return (time.perf_counter() - t0) / steps * 1e3
+    full = timed(np.arange(g['c1'].size))
+    for name, fn in schemes.items():
+        shards = [fn(r) for r in range(world)]
+        assert sorted(np.concatenate(shards).tolist()) == list(range(g['c1'].size))
+        ms = [timed(ix) for ix in shards]
+        out[name] = {'points_per_rank': [int(len(ix)) for ix in shards], 'ms_per_rank': [round(x, 3) for x in ms],
+                     'slowest_ms': round(max(ms), 3), 'predicted_speedup_before_gather': round(full / max(ms), 2)}
+print(json.dumps({'world': world, 'full_step_ms_one_gpu': round(full, 3), 'schemes': out}, indent=1))
