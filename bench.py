@@ -64,8 +64,13 @@ def parse_args(argv=None):
                     help='N > 1, grid mode: strong (default) = the same grid sharded; weak = grid rows x N')
     ap.add_argument('--no-weak', action='store_true', help='skip the secondary weak-scaling measurement')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-sample', type=int, default=0, help='points in the B2 CPU sample (0 = auto, ~12 s)')
-    ap.add_argument('--check', type=int, default=64, help='points verified against the oracle after timing')
+    ap.add_argument('--force-collective', action='store_true',
+                    help='N = 1: initialise a one-rank nccl (RCCL) group and run the broadcast, the all_reduce and the gathers '
+                         'of the N-GPU path on it (exercises the RCCL code path on a one-GPU box)')
+    ap.add_argument('--cpu-sample', type=int, default=0,
+                    help='points in the B2 CPU sample (0 = auto: the whole grid when that takes <= ~30 s, else ~12 s worth)')
+    ap.add_argument('--check', type=int, default=64,
+                    help='points verified against the oracle after timing when the CPU baseline (which checks the whole grid) is off')
     args = ap.parse_args(argv)
     if args.steps is None:
         args.steps = 3 if args.mode == 'stream' else 20
@@ -126,13 +131,14 @@ class GridRun(object):
         border = args.border if args.border == 'mixed' else int(args.border)
         self.g = g = syn.make_grid(H, W, (n_rows, args.grid), border=border)
         self.n_total = g['c1'].size
-        self.idx = idx = shard_indices_by_cost(g['border'], world, rank)   # (world 1: all points)
+        self.idx = idx = shard_indices_by_cost(g['border'], world, rank, s, len(angles))   # (world 1: all points)
         self.ctx = _capi.PMContext(local_rank)
         self.ctx.set_stream(torch.cuda.current_stream().cuda_stream)
         self.ctx.bind_pair_tensors(t1, t2)
         self.ctx.set_points(g['c1'][idx], g['r1'][idx], g['c2fg'][idx], g['r2fg'][idx], g['border'][idx], s, 0.0,
                             angles, rot=rot)
-        self.gather = PackedGatherer(self.n_total, idx, dev)
+        self.gather = PackedGatherer(self.n_total, idx, dev, force_collective=args.force_collective,
+                                     timing=world > 1 or args.force_collective)
         out_t, ij_t = self.gather.local_views()
         self.ctx.bind_results_tensors(out_t, ij_t)
         self.info = self.ctx.work_info()
@@ -153,7 +159,7 @@ class GridRun(object):
         self.ctx.close()
 
 
-def timed_steps(torch, dist, world, run, steps, warmup):
+def timed_steps(torch, dist, world, run, steps, warmup, discard_warmup=None):
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
 
     def fence():
@@ -165,6 +171,8 @@ def timed_steps(torch, dist, world, run, steps, warmup):
     for _ in range(warmup):
         run.step()
     fence()
+    if discard_warmup is not None:
+        discard_warmup()
     t0 = time.perf_counter()
     for k in range(steps):
         run.step(ev[k])
@@ -199,7 +207,12 @@ def traffic_from_profile(args, launches):
 
 
 def cpu_baselines(args, img1, img2, g, n_total, angles, rot, s):
-    """B2 (C oracle, OpenMP over points) and B1 (reference-shaped Python/Pool loop) on bounded samples."""
+    """B2 (C oracle, OpenMP over points) and B1 (reference-shaped Python/Pool loop) on bounded samples.
+
+    Returns (cpu_baseline object, oracle results of the B2 sample): the B2 run evaluates every point of the grid
+    whenever that takes at most ~30 s on this box's cores (otherwise an evenly spaced ~12 s sample), and its
+    results - with the peak / runner-up gap of every point - are handed to parity_block, so that the timed GPU
+    output is compared with the oracle on all of them."""
     import numpy as np
     from oracle import b1_baseline, c_oracle
     nthreads = host_cores()
@@ -208,15 +221,18 @@ def cpu_baselines(args, img1, img2, g, n_total, angles, rot, s):
     tc = time.perf_counter()
     c_oracle.pm_batch(img1, img2, *pick(cal), s, 0.0, angles, rot=rot, nthreads=nthreads)
     rate = len(cal) / (time.perf_counter() - tc)
-    n_s = args.cpu_sample or int(min(n_total, max(len(cal), rate * 12.0)))
-    smp = np.linspace(0, n_total - 1, n_s).astype(np.int64)
+    if args.cpu_sample:
+        n_s = min(args.cpu_sample, n_total)
+    else:
+        n_s = n_total if n_total <= rate * 30.0 else int(max(len(cal), rate * 12.0))
+    smp = np.arange(n_total) if n_s >= n_total else np.linspace(0, n_total - 1, n_s).astype(np.int64)
     tc = time.perf_counter()
-    c_oracle.pm_batch(img1, img2, *pick(smp), s, 0.0, angles, rot=rot, nthreads=nthreads)
+    exp, exp_ij, gap = c_oracle.pm_batch(img1, img2, *pick(smp), s, 0.0, angles, rot=rot, nthreads=nthreads, want_gap=True)
     dt = time.perf_counter() - tc
-    out = {'value': n_s / dt, 'unit': 'grid-points/s', 'cores': nthreads, 'kind': 'port',
-           'sample': 'B2: %d evenly spaced points of the same %d-point grid, same pair/angles/borders, '
+    out = {'value': len(smp) / dt, 'unit': 'grid-points/s', 'cores': nthreads, 'kind': 'port',
+           'sample': 'B2: %s of the same %d-point grid, same pair/angles/borders, '
                      'oracle/pm_oracle.c (restated CPU pmlib, exact-integer NCC; not cv2) with OpenMP over points, '
-                     '%.1f s' % (n_s, n_total, dt)}
+                     '%.1f s' % ('ALL points' if len(smp) == n_total else '%d evenly spaced points' % len(smp), n_total, dt)}
     # B1: ~8 s; per-point Python tasks under a fork pool, the reference's own structure (pmlib.py:436-448)
     cal1 = np.linspace(0, n_total - 1, 2 * nthreads).astype(np.int64)
     tc = time.perf_counter()
@@ -231,23 +247,38 @@ def cpu_baselines(args, img1, img2, g, n_total, angles, rot, s):
                  'sample': 'B1: %d points, one Python task per point under multiprocessing.Pool(%d) as pmlib.py:436-448; '
                            'scipy affine_transform templates, float32-FFT correlation standing in for cv2 (absent), '
                            'NumPy Hessian; %.1f s' % (n1, nthreads, dt1)}
-    return out
+    return out, (smp, exp, exp_ij, gap)
 
 
-def parity_block(args, img1, img2, g, n_total, res, res_ij, angles, rot, s):
-    """Spot check against the C oracle + the cv2-flip exposure statistic (checker only, not timed)."""
+def parity_block(args, img1, img2, g, n_total, res, res_ij, angles, rot, s, oracle_run=None):
+    """The timed GPU output against the C oracle + the cv2-flip exposure census (checker only, not timed).
+    oracle_run = (indices, out, ij, gap) of the B2 baseline run (every point of the grid when affordable);
+    without it (--no-cpu-baseline) a random subsample of --check points is evaluated here."""
     import numpy as np
     from oracle import c_oracle
     c_oracle.build()
-    sel = np.random.default_rng(0).choice(n_total, size=min(args.check, n_total), replace=False)
-    exp, exp_ij, gap = c_oracle.pm_batch(img1, img2, g['c1'][sel], g['r1'][sel], g['c2fg'][sel], g['r2fg'][sel],
-                                         g['border'][sel], s, 0.0, angles, rot=rot, nthreads=host_cores(), want_gap=True)
-    ok = (np.array_equal(res_ij[sel], exp_ij) and np.array_equal(res[sel, :4], exp[:, :4], equal_nan=True)
-          and np.allclose(res[sel, 4], exp[:, 4], rtol=1e-5, atol=1e-5, equal_nan=True))
+    if oracle_run is not None:
+        sel, exp, exp_ij, gap = oracle_run
+    else:
+        sel = np.random.default_rng(0).choice(n_total, size=min(args.check, n_total), replace=False)
+        exp, exp_ij, gap = c_oracle.pm_batch(img1, img2, g['c1'][sel], g['r1'][sel], g['c2fg'][sel], g['r2fg'][sel],
+                                             g['border'][sel], s, 0.0, angles, rot=rot, nthreads=host_cores(), want_gap=True)
+    bad_ij = ~np.all(res_ij[sel] == exp_ij, axis=1)
+    a, b = res[sel, :4], exp[:, :4]
+    bad_v = ~np.all((a == b) | (np.isnan(a) & np.isnan(b)), axis=1)
+    bad_h = ~np.isclose(res[sel, 4], exp[:, 4], rtol=1e-5, atol=1e-5, equal_nan=True)
+    ok = not (bad_ij.any() or bad_v.any() or bad_h.any())
     fin = np.isfinite(gap)
-    return {'points': int(len(sel)), 'ok': bool(ok),
+    hd = np.abs(res[sel, 4] - exp[:, 4])
+    return {'points': int(len(sel)), 'of_grid_points': int(n_total), 'ok': bool(ok),
+            'mismatches': {'peak_or_angle_index': int(bad_ij.sum()), 'c2_r2_a_r_bits': int(bad_v.sum()), 'h_beyond_1e-5': int(bad_h.sum())},
+            'nan_points': int(np.isnan(exp[:, 0]).sum()),
+            'max_abs_h_difference': float(np.nanmax(hd)) if np.isfinite(hd).any() else None,
+            'rule': 'peak row/col/angle index, c2, r2, a, r: bit-exact; h: rtol = atol = 1e-5',
             # a float32/DFT matcher such as cv2's carries ~1e-6 noise: peaks this close to the runner-up could flip there
             'cv2_flip_exposure': {'gap_below_1e-6': int(((gap > 0) & (gap < 1e-6) & fin).sum()),
+                                  'gap_below_1e-5': int(((gap > 0) & (gap < 1e-5) & fin).sum()),
+                                  'gap_below_1e-4': int(((gap > 0) & (gap < 1e-4) & fin).sum()),
                                   'exact_ties': int(((gap == 0) & fin).sum()), 'of_points': int(fin.sum()),
                                   'min_positive_gap': float(gap[(gap > 0) & fin].min()) if ((gap > 0) & fin).any() else None}}
 
@@ -269,7 +300,7 @@ def grid_mode(args, torch, dist, dev, world, rank, local_rank):
         img1 = img2 = None
         t1 = torch.empty((H, W), dtype=torch.uint8, device=dev)
         t2 = torch.empty((H, W), dtype=torch.uint8, device=dev)
-    if world > 1:
+    if world > 1 or args.force_collective:
         dist.broadcast(t1, 0)
         dist.broadcast(t2, 0)
     t_gen = time.time() - t_gen
@@ -277,7 +308,9 @@ def grid_mode(args, torch, dist, dev, world, rank, local_rank):
 
     headline_rows = args.grid * world if (args.scaling == 'weak' and world > 1) else args.grid
     run = GridRun(args, dev, world, rank, local_rank, t1, t2, headline_rows, angles, rot)
-    elapsed, kern_ms = timed_steps(torch, dist, world, run, args.steps, args.warmup)
+    run.gather.timings()                                   # (reset: construction and warm-up are not the timed steps)
+    elapsed, kern_ms = timed_steps(torch, dist, world, run, args.steps, args.warmup, discard_warmup=run.gather.timings)
+    exchange = run.gather.timings() if rank == 0 else None
     res, res_ij = run.results() if rank == 0 else (None, None)
     n_total, info, g = run.n_total, run.info, run.g
     from sea_ice_drift_amd.dist import shard_indices_by_cost
@@ -315,7 +348,7 @@ def grid_mode(args, torch, dist, dev, world, rank, local_rank):
                                                              angles[-1], border),
                    'points_total': int(n_total), 'points_per_gpu': int(n_local),
                    # (shards of equal estimated cost are unequal in length: rank 0 holds the largest windows)
-                   'points_per_gpu_all': [int(len(shard_indices_by_cost(run.g['border'], world, r))) for r in range(world)],
+                   'points_per_gpu_all': [int(len(shard_indices_by_cost(run.g['border'], world, r, s, len(angles)))) for r in range(world)],
                    'parallelism': ('single GPU, no collective' if world == 1 else
                                    'points cut into %d runs of equal estimated cost (neighbouring borders per GPU), one RCCL gather of the packed '
                                    'result blocks to rank 0' % world)},
@@ -338,13 +371,21 @@ def grid_mode(args, torch, dist, dev, world, rank, local_rank):
     }
     if weak is not None:
         line['weak_scaling'] = weak
-    if args.check > 0:
-        line['parity_check'] = parity_block(args, img1, img2, g, n_total, res, res_ij, angles, rot, s)
+    if exchange is not None and exchange['steps'] > 0:
+        # where a step of the N-GPU path goes on rank 0: its own kernels, then the exchange step (HIP events on the launch
+        # stream; the gather also holds the wait for the slowest rank), the un-permutation and the copy to the host
+        line['step_breakdown_ms'] = {'kernel_ms': kern_ms, 'gather_ms': exchange['gather_ms'], 'unpermute_ms': exchange['unpermute_ms'],
+                                     'd2h_ms': exchange['d2h_ms'], 'backend': dist.get_backend() if dist.is_initialized() else None,
+                                     'collectives': 'broadcast x2 (pair), all_reduce(MAX) + gather (indices) at set-up, one gather of '
+                                                    'the packed block per step'}
+    oracle_run = None
+    if not args.no_cpu_baseline:
+        line['cpu_baseline'], oracle_run = cpu_baselines(args, img1, img2, g, n_total, angles, rot, s)
+    if args.check > 0 or oracle_run is not None:
+        line['parity_check'] = parity_block(args, img1, img2, g, n_total, res, res_ij, angles, rot, s, oracle_run)
         if not line['parity_check']['ok']:
             print(json.dumps(line))
             raise SystemExit('PARITY FAILURE against the CPU oracle - the number above is invalid')
-    if not args.no_cpu_baseline:
-        line['cpu_baseline'] = cpu_baselines(args, img1, img2, g, n_total, angles, rot, s)
     return line
 
 
@@ -466,8 +507,12 @@ def main(argv=None):
     local_dev = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_dev)
     dev = torch.device('cuda', local_dev)
-    if world > 1:
+    if world > 1 or args.force_collective:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        if world == 1:                                     # --force-collective: a one-rank RCCL group, no launcher
+            os.environ.setdefault('MASTER_PORT', str(free_port()))
+            os.environ.setdefault('RANK', '0')
+            os.environ.setdefault('WORLD_SIZE', '1')
         shared = torch.cuda.device_count() < world
         # RCCL cannot put two ranks on one device: the dry run on a smaller box uses gloo for the collectives
         dist.init_process_group('gloo' if shared else 'nccl', **({} if shared else {'device_id': dev}))
@@ -478,7 +523,7 @@ def main(argv=None):
             line['config']['parallelism'] += ' [DRY RUN: %d ranks share %d device(s), gloo collectives]' % (
                 world, torch.cuda.device_count())
         print(json.dumps(line))
-    if world > 1:
+    if world > 1 or args.force_collective:
         dist.barrier()
         dist.destroy_process_group()
 

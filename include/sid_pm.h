@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define SID_PM_ABI_VERSION 1
+#define SID_PM_ABI_VERSION 2
 
 /* return codes */
 #define SID_PM_OK               0
@@ -143,6 +143,12 @@ int sid_pm_device_results(sid_pm_ctx *ctx, double **d_out, int32_t **d_out_ij);
  *   info[4] = max dynamic LDS bytes per block  info[5] = reserved                           */
 int sid_pm_work_info(sid_pm_ctx *ctx, double info[6]);
 
+/* Estimated cost (nanoseconds on one MI355X) of grid points with the given search borders, derived from what the kernel
+ * executes for each - matrix instructions of the sweep and of the winner's matrix, placements, residency class of the LDS
+ * footprint - for cutting points into shards of equal cost over several GPUs.  Pure host arithmetic (no device needed).
+ * Replaces the role of `threads`-sized chunks of the reference's Pool.map (pmlib.py:442-444).                          */
+int sid_pm_estimate_cost(const double *border, int64_t n, int img_size, int n_angles, double *cost_ns);
+
 /* ---- diagnostics used by the parity tests ---- */
 
 /* Intermediate results of one point: rotated templates [n_angles][s][s] (uint8), the NCC
@@ -153,7 +159,7 @@ int sid_pm_debug_point(sid_pm_ctx *ctx, double c1, double r1, double c2fg, doubl
                        double border, int img_size, double alpha0, const double *angles,
                        const double *rot, int n_angles, uint32_t flags,
                        uint8_t *templates, float *ccm, float *hes, int64_t cap, int32_t rh_rw[2],
-                       double out5[5], int32_t ij3[3], int64_t phase_cycles[16]);
+                       double out5[5], int32_t ij3[3], int64_t phase_cycles[32]);
 
 /* y[i] = 1.0 / sqrt(x[i]) evaluated on the device in IEEE double, the one transcendental
  * step of the NCC specification; lets a test pin device vs host rounding. */
@@ -165,6 +171,11 @@ int sid_pm_debug_rsqrt(sid_pm_ctx *ctx, const double *x, double *y, int64_t n);
  * counts[0] = evaluations done, counts[1] = results that differ (must be 0), counts[2] = evaluations that
  * needed the specification's route. */
 int sid_pm_debug_ncc_selftest(sid_pm_ctx *ctx, uint64_t seed, int64_t evaluations, int img_size, uint64_t counts[3]);
+
+/* The Hessian magnitude hypotf(d2x, d2y) = (float)sqrt((double)x*x + (double)y*y) (NumPy's float32 np.hypot,
+ * pmlib.py:55) is evaluated in the kernel through a shortened square root with a guard; this runs both routes on
+ * `evaluations` pseudo-random float32 pairs on the device: counts[0] = evaluations, counts[1] = results that differ. */
+int sid_pm_debug_hypot_selftest(sid_pm_ctx *ctx, uint64_t seed, int64_t evaluations, uint64_t counts[2]);
 
 #ifdef __cplusplus
 }

@@ -15,7 +15,7 @@ HES_NORM = 1
 HES_SMTH = 2
 MCC_NORM = 4
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 # every symbol include/sid_pm.h declares
 SYMBOLS = (
@@ -23,7 +23,7 @@ SYMBOLS = (
     'sid_pm_batch', 'sid_pm_create', 'sid_pm_destroy', 'sid_pm_set_stream', 'sid_pm_upload_pair',
     'sid_pm_select_pair', 'sid_pm_bind_pair', 'sid_pm_set_points', 'sid_pm_bind_results', 'sid_pm_run', 'sid_pm_sync',
     'sid_pm_fetch', 'sid_pm_device_results', 'sid_pm_work_info', 'sid_pm_debug_point', 'sid_pm_debug_ncc_selftest',
-    'sid_pm_debug_rsqrt',
+    'sid_pm_debug_rsqrt', 'sid_pm_debug_hypot_selftest', 'sid_pm_estimate_cost',
 )
 
 # every symbol include/sid_ft.h declares (feature-tracking matcher, same library)
@@ -98,6 +98,8 @@ def lib():
                                                                       _i32p, _f64p, _i32p, C.POINTER(C.c_int64)]
     L.sid_pm_debug_rsqrt.argtypes = [C.c_void_p, _f64p, _f64p, C.c_int64]
     L.sid_pm_debug_ncc_selftest.argtypes = [C.c_void_p, C.c_uint64, C.c_int64, C.c_int, C.POINTER(C.c_uint64)]
+    L.sid_pm_estimate_cost.argtypes = [_f64p, C.c_int64, C.c_int, C.c_int, _f64p]
+    L.sid_pm_debug_hypot_selftest.argtypes = [C.c_void_p, C.c_uint64, C.c_int64, C.POINTER(C.c_uint64)]
     L.sid_ft_knn2.argtypes = [C.c_int, _u8p, C.c_int64, _u8p, C.c_int64, _i32p, _i32p]
     L.sid_ft_knn2_device.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.sid_ft_workspace_bytes.argtypes = [C.c_int64, C.c_int64]
@@ -156,6 +158,14 @@ def _f64(a):
 
 def _p(a, t):
     return a.ctypes.data_as(t)
+
+
+def estimate_cost(border, img_size=34, n_angles=15):
+    """Estimated nanoseconds per grid point (include/sid_pm.h sid_pm_estimate_cost): host arithmetic of the library."""
+    b = _f64(border).ravel()
+    out = np.empty(b.size, dtype=np.float64)
+    _check(lib().sid_pm_estimate_cost(_p(b, _f64p), b.size, int(img_size), int(n_angles), _p(out, _f64p)))
+    return out
 
 
 def flags_from_kwargs(hes_norm=True, hes_smth=False, mcc_norm=False):
@@ -229,13 +239,16 @@ class PMContext(object):
         fn, h, s = lib().sid_pm_upload_pair, self._h, int(slot)
         args = (h, s, _p(img1, _u8p), img1.shape[0], img1.shape[1], img1.strides[0],
                 _p(img2, _u8p), img2.shape[0], img2.shape[1], img2.strides[0])
-        box = {'rc': None, 'exc': None}
+        box = {'rc': None, 'exc': None, 'msg': None}
         entered = threading.Event()
+        last_error = lib().sid_pm_last_error
 
         def run():
             try:
                 entered.set()                       # the next thing this thread does is the C call (lock released there)
                 box['rc'] = fn(*args)
+                if box['rc'] != 0:                  # the library's error text is thread-local: read it on this thread
+                    box['msg'] = last_error()
             except BaseException as e:              # noqa: handed to the waiting thread
                 box['exc'] = e
 
@@ -249,7 +262,9 @@ class PMContext(object):
                 t.join()
                 if box['exc'] is not None:
                     raise box['exc']
-                _check(box['rc'])
+                if box['rc'] != 0:
+                    msg = box['msg'] or lib().sid_pm_strerror(box['rc'])
+                    raise SidPmError(box['rc'], msg.decode() if isinstance(msg, bytes) else str(msg))
                 ctx.select_pair(s)
         return _Pending()
 
@@ -333,7 +348,7 @@ class PMContext(object):
         shape = np.zeros(2, dtype=np.int32)
         out5 = np.zeros(5, dtype=np.float64)
         ij3 = np.zeros(3, dtype=np.int32)
-        cyc = np.zeros(16, dtype=np.int64)
+        cyc = np.zeros(32, dtype=np.int64)
         _check(lib().sid_pm_debug_point(self._h, float(c1), float(r1), float(c2fg), float(r2fg), float(border), s,
                                         float(alpha0), _p(angles, _f64p), rotp, K, int(flags), _p(tm, _u8p),
                                         _p(ccm, _f32p), _p(hes, _f32p), cap, _p(shape, _i32p), _p(out5, _f64p),
@@ -354,6 +369,12 @@ class PMContext(object):
         counts = (C.c_uint64 * 3)()
         _check(lib().sid_pm_debug_ncc_selftest(self._h, int(seed), int(evaluations), int(img_size), counts))
         return int(counts[0]), int(counts[1]), int(counts[2])
+
+    def debug_hypot_selftest(self, evaluations, seed=1):
+        """(evaluations, mismatches) of the kernel's shortened hypotf against the IEEE route, on the device."""
+        counts = (C.c_uint64 * 2)()
+        _check(lib().sid_pm_debug_hypot_selftest(self._h, int(seed), int(evaluations), counts))
+        return int(counts[0]), int(counts[1])
 
 
 def ft_knn2(desc1, desc2, device=0):

@@ -51,7 +51,7 @@ struct Image {
     int64_t rows = 0, cols = 0, stride = 0;
 };
 
-struct Bucket { int offset, count, lds, band; };   // band: output rows per sweep work item of this launch (4 or 8)
+struct Bucket { int offset, count, lds, band, pitch; };   // band: output rows per sweep work item of this launch (4 or 8); pitch: compile-time window pitch of the row-pair kernel (0: run-time)
 
 template <typename T>
 struct DevBuf {
@@ -229,9 +229,9 @@ bool rp_paired(int K)
     return K <= sid::kPairedMaxAngles && getenv("SID_PM_NO_PAIRED") == nullptr;
 }
 
-int lds_need(bool rp, bool rpp, int wh, int ww, int s, int K, int band = 4)
+int lds_need(bool rp, bool rpp, int wh, int ww, int s, int K, int band = 4, int pitch = 0)
 {
-    if (rp) return sid::rp_lds_layout(wh, ww, s, K <= sid::kRpGroup, rpp ? 8 : band).total;
+    if (rp) return sid::rp_lds_layout(wh, ww, s, K <= sid::kRpGroup, rpp ? 8 : band, pitch).total;
     return sid::mfma_lds_layout(wh, ww, s, band, use_paired(K) && band == 4).total;
 }
 
@@ -287,7 +287,7 @@ int classify_points(sid_pm_ctx *ctx)
     const int s = ctx->img_size, K = ctx->n_angles;
     const int64_t rows2 = ctx->cur[1].rows, cols2 = ctx->cur[1].cols;
     const double *c2fg = ctx->h_c2fg.data(), *r2fg = ctx->h_r2fg.data(), *border = ctx->h_border.data();
-    struct P { int idx; int lds; int cls; double work; int band = 4; bool force1 = false, force2 = false; };
+    struct P { int idx; int lds; int cls; double work; int band = 4; bool force1 = false, force2 = false; int wh = 0, ww = 0, pitch = 0; };
     static const bool no_band8 = getenv("SID_PM_NO_BAND8") != nullptr;                      // A/B runs
     const bool rp = ctx->rp;
     const bool band8_ok = sid::mfma_band8_supported(s) && !no_band8 && (rp ? !ctx->rp_paired : !use_paired(K));   // (classic and row-pair kernels alike)
@@ -313,6 +313,7 @@ int classify_points(sid_pm_ctx *ctx)
                 if (blocks_per_cu(need8) >= 2) { p.lds = need8; p.band = 8; p.force2 = true; }
                 else p.force1 = true;
             }
+            p.wh = wh; p.ww = ww;
             const double rh = wh - s + 1, rw = ww - s + 1;
             p.work = rh * rw;
             macs += (double)K * rh * rw * s * s;
@@ -330,6 +331,33 @@ int classify_points(sid_pm_ctx *ctx)
         if (a.work != b.work) return a.work > b.work;             // then longest first
         return a.idx < b.idx;
     });
+    // Row-pair kernel: one window pitch per launch, a compile-time constant of the kernel instantiation (every LDS offset of
+    // the sweep's and the winner's fragment loops is then an immediate).  The pitch of a launch = the smallest instantiated
+    // pitch that holds the natural pitch of all of its points; points whose footprint with that pitch no longer fits their
+    // residency class keep the run-time pitch for the whole launch (SID_PM_NO_FIXED_PITCH=1: always; A/B runs).
+    static const bool no_fixed_pitch = getenv("SID_PM_NO_FIXED_PITCH") != nullptr;
+    if (rp && !no_fixed_pitch) {
+        for (size_t a = 0; a < pts.size();) {
+            size_t b = a + 1;
+            while (b < pts.size() && pts[b].cls == pts[a].cls && pts[b].band == pts[a].band) ++b;
+            int nat = 0;
+            for (size_t i = a; i < b; ++i)
+                if (pts[i].wh > 0) nat = std::max(nat, sid::rp_lds_layout(pts[i].wh, pts[i].ww, s, K <= sid::kRpGroup, rpp ? 8 : pts[i].band).wpitch);
+            int pitch = nat > 0 ? sid::rp_class_pitch(nat) : 0;
+            if (pitch && !sid::rp_pitch_instantiated(pts[a].band, rpp, pitch)) pitch = 0;
+            if (pitch) {
+                const int per_cu = pts[a].cls;                     // workgroups per CU the class was formed for
+                for (size_t i = a; i < b && pitch; ++i)
+                    if (pts[i].wh > 0 && std::min(8, blocks_per_cu(lds_need(rp, rpp, pts[i].wh, pts[i].ww, s, K, pts[i].band, pitch))) < per_cu) pitch = 0;
+            }
+            if (pitch)
+                for (size_t i = a; i < b; ++i) {
+                    pts[i].pitch = pitch;
+                    if (pts[i].wh > 0) pts[i].lds = lds_need(rp, rpp, pts[i].wh, pts[i].ww, s, K, pts[i].band, pitch);
+                }
+            a = b;
+        }
+    }
     // XCD-aware launch order.  Workgroup j of a launch runs on XCD j mod 8 and every XCD has its own L2, so
     // within a run of points of equal class and work (= equal border: the order there is the caller's, i.e.
     // spatial for a grid) the run is cut into 8 contiguous chunks and chunk c goes to the XCD of slot
@@ -361,7 +389,7 @@ int classify_points(sid_pm_ctx *ctx)
     for (int64_t i = 0; i < n; ++i) {
         order[(size_t)i] = pts[(size_t)i].idx;
         if (ctx->buckets.empty() || pts[(size_t)i].cls != pts[(size_t)(i - 1)].cls || pts[(size_t)i].band != pts[(size_t)(i - 1)].band)
-            ctx->buckets.push_back(Bucket{(int)i, 0, 0, pts[(size_t)i].band});
+            ctx->buckets.push_back(Bucket{(int)i, 0, 0, pts[(size_t)i].band, pts[(size_t)i].pitch});
         Bucket &b = ctx->buckets.back();
         b.count += 1;
         b.lds = std::max(b.lds, pts[(size_t)i].lds);
@@ -608,7 +636,7 @@ SID_EXPORT int sid_pm_run(sid_pm_ctx *ctx)
         const int per_cu = std::max(1, std::min(b.band == 8 ? 2 : 8, blocks_per_cu(b.lds)));
         const int nthreads = b.band == 8 ? 256 : (per_cu == 1 ? 768 : 256);
         const int e = ctx->rp
-                          ? sid::launch_pm_rp(A, lds_launch, nthreads, b.band, ctx->rp_paired, ctx->stream)
+                          ? sid::launch_pm_rp(A, lds_launch, nthreads, b.band, ctx->rp_paired, b.pitch, ctx->stream)
                           : sid::launch_pm_mfma(A, lds_launch, nthreads, b.band, use_paired(ctx->n_angles), ctx->stream);
         if (e != 0) return fail(SID_PM_ERR_HIP, "kernel launch failed: %s", hipGetErrorString((hipError_t)e));
     }
@@ -702,7 +730,7 @@ SID_EXPORT int sid_pm_debug_point(sid_pm_ctx *ctx, double c1, double r1, double 
                                   double border, int img_size, double alpha0, const double *angles,
                                   const double *rot, int n_angles, uint32_t flags,
                                   uint8_t *templates, float *ccm, float *hes, int64_t cap, int32_t rh_rw[2],
-                                  double out5[5], int32_t ij3[3], int64_t phase_cycles[16])
+                                  double out5[5], int32_t ij3[3], int64_t phase_cycles[32])
 {
     if (!ctx) return fail(SID_PM_ERR_ARG, "null ctx");
     if (!ctx->have_pair) return fail(SID_PM_ERR_STATE, "debug_point needs an image pair");
@@ -733,7 +761,7 @@ SID_EXPORT int sid_pm_debug_point(sid_pm_ctx *ctx, double c1, double r1, double 
     if ((rc = dv.reserve(5)) || (rc = dang.reserve((size_t)K)) || (rc = drot.reserve(4 * (size_t)K)) ||
         (rc = dout.reserve(5)) || (rc = dord.reserve(1)) || (rc = dij.reserve(3)) || (rc = dshape.reserve(2)) ||
         (rc = dt.reserve(tcount)) || (rc = dccm.reserve((size_t)std::max<int64_t>(cap, 1))) ||
-        (rc = dhes.reserve((size_t)std::max<int64_t>(cap, 1))) || (rc = dcyc.reserve(16)) ||
+        (rc = dhes.reserve((size_t)std::max<int64_t>(cap, 1))) || (rc = dcyc.reserve(32)) ||
         (rc = dsamp.reserve(sampv.size() + 4))) { cleanup(); return rc; }
     const double v5[5] = {c1, r1, c2fg, r2fg, border};
     const int32_t zero = 0, shape0[2] = {0, 0};
@@ -748,7 +776,7 @@ SID_EXPORT int sid_pm_debug_point(sid_pm_ctx *ctx, double c1, double r1, double 
     if (!sampv.empty()) step(hipMemcpy(dsamp.p, sampv.data(), sizeof(uint16_t) * sampv.size(), hipMemcpyHostToDevice));
     step(hipMemcpy(dshape.p, shape0, sizeof shape0, hipMemcpyHostToDevice));
     step(hipMemset(dt.p, 0, tcount));
-    step(hipMemset(dcyc.p, 0, sizeof(long long) * 16));
+    step(hipMemset(dcyc.p, 0, sizeof(long long) * 32));
     if (cap > 0) { step(hipMemset(dccm.p, 0, sizeof(float) * cap)); step(hipMemset(dhes.p, 0, sizeof(float) * cap)); }
     if (e == hipSuccess) {
         sid::PMArgs A;
@@ -763,7 +791,7 @@ SID_EXPORT int sid_pm_debug_point(sid_pm_ctx *ctx, double c1, double r1, double 
         gauss_taps(A.gauss_w);
         A.samp = sampv.empty() ? nullptr : dsamp.p; A.samp_nflag = nflag;
         A.lds_bytes = lds;
-        step((hipError_t)(rp ? sid::launch_pm_rp(A, lds, 256, 4, rpp, ctx->stream)
+        step((hipError_t)(rp ? sid::launch_pm_rp(A, lds, 256, 4, rpp, 0, ctx->stream)
                                        : sid::launch_pm_mfma(A, lds, 256, 4, use_paired(K), ctx->stream)));
         step(hipStreamSynchronize(ctx->stream));
         if (templates) step(hipMemcpy(templates, dt.p, tcount, hipMemcpyDeviceToHost));
@@ -772,7 +800,7 @@ SID_EXPORT int sid_pm_debug_point(sid_pm_ctx *ctx, double c1, double r1, double 
         if (rh_rw) step(hipMemcpy(rh_rw, dshape.p, sizeof(int32_t) * 2, hipMemcpyDeviceToHost));
         if (out5) step(hipMemcpy(out5, dout.p, sizeof(double) * 5, hipMemcpyDeviceToHost));
         if (ij3) step(hipMemcpy(ij3, dij.p, sizeof(int32_t) * 3, hipMemcpyDeviceToHost));
-        if (phase_cycles) step(hipMemcpy(phase_cycles, dcyc.p, sizeof(long long) * 16, hipMemcpyDeviceToHost));
+        if (phase_cycles) step(hipMemcpy(phase_cycles, dcyc.p, sizeof(long long) * 32, hipMemcpyDeviceToHost));
     }
     cleanup();
     if (e != hipSuccess) return fail(SID_PM_ERR_HIP, "debug_point: %s", hipGetErrorString(e));
@@ -813,5 +841,67 @@ SID_EXPORT int sid_pm_debug_ncc_selftest(sid_pm_ctx *ctx, uint64_t seed, int64_t
     d.release();
     if (e != hipSuccess) return fail(SID_PM_ERR_HIP, "debug_ncc_selftest: %s", hipGetErrorString(e));
     for (int k = 0; k < 3; ++k) counts[k] = h[k];
+    return SID_PM_OK;
+}
+
+SID_EXPORT int sid_pm_debug_hypot_selftest(sid_pm_ctx *ctx, uint64_t seed, int64_t evaluations, uint64_t counts[2])
+{
+    if (!ctx || !counts || evaluations <= 0) return fail(SID_PM_ERR_ARG, "bad argument");
+    Guard g(ctx->device);
+    DevBuf<unsigned long long> d;
+    int rc;
+    if ((rc = d.reserve(2))) return rc;
+    const int per_thread = 256;
+    const int blocks = (int)std::min<int64_t>((evaluations + 256 * per_thread - 1) / (256 * per_thread), 1 << 20);
+    hipError_t e = hipMemsetAsync(d.p, 0, 2 * sizeof(unsigned long long), ctx->stream);
+    if (e == hipSuccess) e = (hipError_t)sid::launch_hypot_selftest(seed, blocks, per_thread, d.p, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    unsigned long long h[2] = {0, 0};
+    if (e == hipSuccess) e = hipMemcpy(h, d.p, sizeof(h), hipMemcpyDeviceToHost);
+    d.release();
+    if (e != hipSuccess) return fail(SID_PM_ERR_HIP, "debug_hypot_selftest: %s", hipGetErrorString(e));
+    counts[0] = h[0]; counts[1] = h[1];
+    return SID_PM_OK;
+}
+
+// Estimated cost of a grid point in nanoseconds of one MI355X, for cutting a set of points into shards of equal cost
+// (sea_ice_drift_amd/dist.py).  Not a table per border: the cost follows what the kernel executes for the point - the
+// matrix instructions of the sweep (bands x placement tiles x template row pairs, per group of angles), those of the
+// winner's NCC matrix, the placements themselves - times a factor for the residency class of its LDS footprint (fewer
+// co-resident workgroups hide less latency).  The six constants were fitted to tools/border_cost.py (template side 34, 15
+// angles, borders 20..50: within 8 % everywhere); what matters to the sharding are the ratios between points.
+SID_EXPORT int sid_pm_estimate_cost(const double *border, int64_t n, int img_size, int n_angles, double *cost_ns)
+{
+    if (n < 0 || (n > 0 && (!border || !cost_ns))) return fail(SID_PM_ERR_ARG, "bad argument");
+    const int s = img_size, K = n_angles;
+    if (!sid::mfma_img_size_supported(s) || K < 1) return fail(SID_PM_ERR_UNSUPPORTED, "img_size / angle count not supported");
+    const bool rp = use_rp(s, K), rpp = rp && rp_paired(K);
+    const int hws = (int)((double)s / 2.0);
+    const int groups = (K + sid::kRpGroup - 1) / sid::kRpGroup;
+    constexpr double kSweep = 4.08e-3, kWinner = 2.05e-2, kPos = 5.09e-3, kFixed = 42.5, kTwoPerCu = 1.26, kOnePerCu = 1.61;
+    for (int64_t i = 0; i < n; ++i) {
+        const double b = border[i];
+        if (!(b >= 0.0 && b < 4096.0)) { cost_ns[i] = kFixed; continue; }      // NaN / absurd: a point that writes NaN at once
+        const int wn = 2 * hws + 2 * (int)b + 1, r = wn - s + 1;
+        if (r < 2) { cost_ns[i] = kFixed; continue; }
+        double sweep, winner, cls_factor;
+        if (rp) {
+            const sid::RpLdsLayout L4 = sid::rp_lds_layout(wn, wn, s, K <= sid::kRpGroup, rpp ? 8 : 4);
+            int per_cu = blocks_per_cu(L4.total), band = 4;
+            if (!rpp && per_cu == 2 && blocks_per_cu(sid::rp_lds_layout(wn, wn, s, K <= sid::kRpGroup, 8).total) >= 2) band = 8;
+            const int rows = rpp ? 8 : band, nb = (r + rows - 1) / rows, tiles = 2 * L4.npair + L4.nsingle;
+            const double per_row_tile = (double)((s + 1) / 2 + s / 2 + 1) / 2.0 + (double)(((s - 32 + 1) / 2) * 2);
+            sweep = groups * ((rpp ? 0.55 : 1.0) * nb * rows * tiles * per_row_tile + 2.0 * nb * tiles);
+            winner = (double)((r + 15) / 16) * (L4.npair * 152.0 + L4.nsingle * 76.0);
+            cls_factor = per_cu >= 3 ? 1.0 : per_cu == 2 ? kTwoPerCu : kOnePerCu;
+        } else {
+            const sid::MfmaLdsLayout L = sid::mfma_lds_layout(wn, wn, s, 4, use_paired(K));
+            const int per_cu = blocks_per_cu(L.total), ntx = (r + 15) / 16;
+            sweep = groups * (double)r * ntx * s * (use_paired(K) ? 0.55 : 1.0) * 1.3;    // one template row per MFMA
+            winner = (double)((r + 15) / 16) * ntx * (16 + s - 1) * 2.0;
+            cls_factor = per_cu >= 3 ? 1.0 : per_cu == 2 ? kTwoPerCu : kOnePerCu;
+        }
+        cost_ns[i] = (kSweep * sweep + kWinner * winner + kPos * (double)r * r + kFixed) * cls_factor;
+    }
     return SID_PM_OK;
 }

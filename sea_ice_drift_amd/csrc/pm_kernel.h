@@ -30,7 +30,7 @@ struct PMArgs {
     int32_t *out_ij;                                // [n_total][3]
     // diagnostics (debug_point only; null in production launches)
     uint8_t *dbg_templates; float *dbg_ccm; float *dbg_hes; int32_t *dbg_shape; int64_t dbg_cap;
-    long long *dbg_cycles;                          // [16] shader-clock stamps at phase boundaries
+    long long *dbg_cycles;                          // [32] shader-clock stamps at phase boundaries
     int32_t *dbg_err;                               // [64] consistency-check counters of debugging builds (SID_DBG_CHECK); null otherwise
 };
 
@@ -129,7 +129,9 @@ __host__ __device__ inline int rp_band_y0(int b, int nbands, int rh, int band)
 }
 
 // band: output rows per sweep work item (4, or 8 for the two-workgroups-per-CU class).
-__host__ __device__ inline RpLdsLayout rp_lds_layout(int wh, int ww, int s, bool one_group, int band = 4)
+// force_pitch: window pitch fixed by the launch class (a compile-time constant of the kernel instantiation: rp_class_pitch);
+// 0 = the natural pitch.  A forced pitch below the natural one is ignored (the kernel then refuses the point).
+__host__ __device__ inline RpLdsLayout rp_lds_layout(int wh, int ww, int s, bool one_group, int band = 4, int force_pitch = 0)
 {
     RpLdsLayout L;
     const int rh = wh - s + 1, rw = ww - s + 1;
@@ -144,6 +146,7 @@ __host__ __device__ inline RpLdsLayout rp_lds_layout(int wh, int ww, int s, bool
     if (L.npair && 32 * (L.npair - 1) + 80 > need) need = 32 * (L.npair - 1) + 80;
     if (L.nsingle && 32 * L.npair + 68 > need) need = 32 * L.npair + 68;
     L.wpitch = round_up(need, 8);
+    if (force_pitch > L.wpitch) L.wpitch = force_pitch;
     // first row of the last band: an 8-row band whose last item would hang over the matrix by more than 4 rows is pulled
     // up instead (it overlaps the one before; rp_band_y0) - fewer zero rows below the window, shorter column-pair rows
     const int y0max = rp_band_y0((rh + band - 1) / band - 1, (rh + band - 1) / band, rh, band);
@@ -182,7 +185,14 @@ __host__ __device__ inline RpLdsLayout rp_lds_layout(int wh, int ww, int s, bool
     return L;
 }
 
-int launch_pm_rp(const PMArgs &args, int lds_bytes, int nthreads, int band, bool paired, void *stream);
+// window pitches the row-pair kernel is instantiated for (besides the run-time pitch): the smallest one that holds
+// `natural`, or 0 (run-time pitch) beyond the largest
+__host__ __device__ inline int rp_class_pitch(int natural)
+{
+    return natural <= 104 ? 104 : natural <= 136 ? 136 : natural <= 168 ? 168 : 0;
+}
+int launch_pm_rp(const PMArgs &args, int lds_bytes, int nthreads, int band, bool paired, int pitch, void *stream);
+bool rp_pitch_instantiated(int band, bool paired, int pitch);
 
 __host__ __device__ inline int samp_pitch(int s) { return round_up(s, 4); }
 constexpr double kSampGuard = 1e-5;   // table entries whose coordinate is this close to k + 1/2 are flagged
@@ -194,6 +204,7 @@ bool mfma_img_size_supported(int s);
 
 int launch_rsqrt(const double *x, double *y, int64_t n, void *stream);
 int launch_ncc_selftest(unsigned long long seed, int blocks, int per_thread, int s, unsigned long long *out, void *stream);
+int launch_hypot_selftest(unsigned long long seed, int blocks, int per_thread, unsigned long long *out, void *stream);
 int max_lds_bytes();
 
 }  // namespace sid

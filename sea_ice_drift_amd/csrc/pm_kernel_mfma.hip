@@ -94,6 +94,7 @@ struct Geo {
     u32 patch_magic, rw_magic;       // same for ppitch/4 and for rw
     int band;                        // output rows per sweep work item (kernel template parameter)
     int wp_off, wp_pitch, wp_rows, strip_off, wrows, npair, nsingle;   // row-pair kernel (RpLdsLayout)
+    int hist_off;                    // 5 KB behind the NCC matrix of the winning angle for ph_hessian_fast (0: none - the general ph_hessian runs)
     long long r0, c0;                // window origin on image 2
     double c1, r1, nd;
 };
@@ -236,13 +237,15 @@ __device__ __forceinline__ float block_median(const float *v, int n, MiscM *m, u
 constexpr int kMedList = 256;
 // The part after the key range [kmin, kmax] is known to every thread.  Expects hist[0..1023] = 0 and m->sel_cle = 0, made
 // visible by a barrier.
-__device__ __forceinline__ float block_median_ranged(const float *v, int n, MiscM *m, u32 *hist, u32 *list, u32 kmin, u32 kmax)
+__device__ __forceinline__ float block_median_ranged(const float *v, int n, MiscM *m, u32 *hist, u32 *list, u32 kmin, u32 kmax,
+                                                     long long *dbg = nullptr)
 {
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const u32 range = kmax - kmin;
     const int shift = range < 1024u ? 0 : 22 - __clz(range);           // (range >> shift) < 1024
     for (int i = tid; i < n; i += kBlockM) atomicAdd(&hist[(f2key(v[i]) - kmin) >> shift], 1u);
     __syncthreads();
+    if (dbg && tid == 0) dbg[21] = (long long)clock64();
     const bool two = !(n & 1);
     const u32 k1 = two ? (u32)(n / 2 - 1) : (u32)(n / 2);
     if (w == 0) {                                                      // 16 buckets per lane + a wavefront prefix sum
@@ -267,6 +270,7 @@ __device__ __forceinline__ float block_median_ranged(const float *v, int n, Misc
         }
     }
     __syncthreads();
+    if (dbg && tid == 0) dbg[22] = (long long)clock64();
     const u32 bin = m->sel_key, before = (u32)m->red_i[14], cnt = (u32)m->red_i[15];
     if (cnt > (u32)kMedList) return block_median(v, n, m, hist);       // block-uniform
     // the second middle value of an even-sized set lies in the same bucket unless the first is the bucket's last
@@ -280,6 +284,7 @@ __device__ __forceinline__ float block_median_ranged(const float *v, int n, Misc
     }
     if (need_above) above = block_min(above, m);                       // (barriers inside: the list is complete)
     else __syncthreads();
+    if (dbg && tid == 0) dbg[23] = (long long)clock64();
     if ((u32)tid < cnt) {
         const u32 mine = list[tid];
         u32 rank = 0;
@@ -288,6 +293,7 @@ __device__ __forceinline__ float block_median_ranged(const float *v, int n, Misc
         if (rank == k1 + 1 - before) m->best_key = (int)mine;
     }
     __syncthreads();
+    if (dbg && tid == 0) dbg[24] = (long long)clock64();
     const u32 key1 = m->sel_key;
     if (!two) return key2f(key1);
     const u32 key2 = need_above ? above : (u32)m->best_key;
@@ -384,6 +390,34 @@ __device__ __forceinline__ float exact_from_sums_fast(int p, int swp, u32 siiv, 
     float out = aq < 1.0 ? (float)q : (aq < 1.125 ? (q > 0.0 ? 1.0f : -1.0f) : 0.0f);
     if (cT) out = 1.0f;
     if (slow && !cT) out = exact_from_sums(p, swp, siiv, nd, sT, rTd, cT);
+    return out;
+}
+
+// Branch-free part of exact_from_sums_fast: the value by the short route and whether the lane must take the spec's route
+// instead.  Callers evaluate a batch of these back to back (independent dependency chains interleave) and handle the rare
+// flagged ones afterwards - a branch around every single value serialises the ~20-deep double-precision chains.
+__device__ __forceinline__ float ncc_fast_nobranch(int p, int swp, u32 siiv, double nd, double sT, double rTd, bool cT, bool &slow)
+{
+    const double swd = (double)swp, siid = (double)siiv;
+    const double dI = nd * siid - swd * swd;                           // exact
+    const double numer = nd * (double)p - swd * sT;                    // exact
+    bool sl = 2.0 * dI <= nd;                                          // the low-variance rule needs a second look
+    const double x = sl ? 1.0 : dI;
+    const double y0 = __builtin_amdgcn_rsq(x);
+    double g = x * y0, h = 0.5 * y0;
+    double r = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, r, g); h = __builtin_fma(h, r, h);
+    r = __builtin_fma(-h, g, 0.5);
+    h = __builtin_fma(h, r, h);                                        // 1 / (2 sqrt(dI))
+    const double q = (numer * h) * (2.0 * rTd);
+    const double aq = fabs(q);
+    const u32 lo29 = (u32)__double2loint(q) & 0x1fffffffu;
+    sl |= (lo29 - (0x10000000u - 64u)) <= 128u;
+    sl |= fabs(aq - 1.0) < 1e-13 || fabs(aq - 1.125) < 1e-13;
+    const float clamp = aq < 1.125 ? (q > 0.0 ? 1.0f : -1.0f) : 0.0f;
+    float out = aq < 1.0 ? (float)q : clamp;
+    out = cT ? 1.0f : out;
+    slow = sl && !cT;
     return out;
 }
 
@@ -1433,6 +1467,7 @@ __device__ __noinline__ void ph_hessian(unsigned flags, int iy, int ix, float be
             emit(y * rw + x, d2(ccm + y * rw, 1, x, rw), d2(ccm + x, rw, y, rh));
         }
     }
+    if (dbg_cycles && tid == 0) dbg_cycles[19] = (long long)clock64();
     __syncthreads();
     if (dbg_ccm || dbg_hes) {
         for (int idx = tid; idx < npos && idx < dbg_cap; idx += kBlockM) {
@@ -1460,12 +1495,230 @@ __device__ __noinline__ void ph_hessian(unsigned flags, int iy, int ix, float be
             kmin = a < kmin ? a : kmin; kmax = b > kmax ? b : kmax;
         }
         const float sd = std_from_sums(tx, txx, npos);
-        const float med = block_median_ranged(hes, npos, m, hist4, medlist, kmin, kmax);
+        if (dbg_cycles && tid == 0) dbg_cycles[20] = (long long)clock64();
+        const float med = block_median_ranged(hes, npos, m, hist4, medlist, kmin, kmax, dbg_cycles);
         h = (h - med) / sd;
     }
     __syncthreads();
     if (tid == 0) { m->red_f[0] = h; m->red_f[1] = rr; }
     __syncthreads();
+}
+
+// hypotf as NumPy's float32 np.hypot evaluates it (glibc: (float)sqrt((double)x * x + (double)y * y)), by a shorter route
+// with the same result: sqrt(hh) from v_rsq_f64 and two coupled Newton steps (within ~1 ulp of the correctly rounded
+// double); (float) of it equals (float) of the IEEE square root unless a float32 rounding boundary - the middle of the 29
+// discarded mantissa bits - lies that close, and those lanes (2.4e-7 of them) take the IEEE route.  Checked on the device
+// against the IEEE route by sid_pm_debug_hypot_selftest.
+__device__ __forceinline__ float hypot_spec(float x, float y)
+{
+    const double hh = (double)x * (double)x + (double)y * (double)y;
+    return (float)sqrt(hh);
+}
+__device__ __forceinline__ float hypot_fast(float x, float y)
+{
+    const double hh = (double)x * (double)x + (double)y * (double)y;
+    const double y0 = __builtin_amdgcn_rsq(hh);
+    double g = hh * y0, h = 0.5 * y0;
+    double r = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, r, g); h = __builtin_fma(h, r, h);
+    r = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, r, g);                                        // sqrt(hh)
+    const u32 lo29 = (u32)__double2loint(g) & 0x1fffffffu;
+    // not (1e-30 < hh < 1e30): zero, NaN, and results near the float32 denormal range (other rounding boundaries)
+    const bool slow = ((lo29 - (0x10000000u - 64u)) <= 128u) || !(hh > 1e-60 && hh < 1e60);
+    float out = (float)g;
+    if (slow) out = (float)sqrt(hh);
+    return out;
+}
+
+// Bucket of a Hessian magnitude (>= 0) in the fixed histogram of ph_hessian_fast: 16 binades 2^-15 .. 2 with 128 buckets
+// each (the top 7 mantissa bits, 0.5 % wide); monotone in the value, smaller / larger values clamp to the first / last
+// bucket.  2048 16-bit counters packed in pairs (a matrix holds fewer than 65536 values).
+constexpr int kHesBuckets = 2048;
+__device__ __forceinline__ u32 hes_bucket(u32 bits)
+{
+    const int b = (int)(bits >> 16) - (112 << 7);
+    return (u32)(b < 0 ? 0 : (b > kHesBuckets - 1 ? kHesBuckets - 1 : b));
+}
+
+// ---------------------------------------------------------------------------------------------
+// Phase 5, short form (hes_norm with neither hes_smth nor mcc_norm - the reference's defaults - and G.hist_off set):
+// same values as ph_hessian with two barriers instead of eight.  The magnitudes go into a FIXED log-spaced histogram
+// (zeroed by the winner's staging) in the pass that computes them, so that no min / max reduction precedes the
+// histogram; every wavefront scans the counters itself (no "wavefront 0 scans, barrier, broadcast"); the elements
+// of the bucket holding the middle rank (and of the next non-empty one when the second middle value lies there) are
+// compacted and ranked by wavefront 0, which also forms the result.  Buckets too full for the list (massive ties, flat
+// matrices, magnitudes below 2^-15) fall back to the radix select.
+// ---------------------------------------------------------------------------------------------
+__device__ __noinline__ void ph_hessian_fast(unsigned flags, int iy, int ix, float best_r, float *dbg_ccm, float *dbg_hes,
+                                             long long dbg_cap, long long *dbg_cycles)
+{
+    SID_PHASE_LOCALS;
+    float *hes = reinterpret_cast<float *>(smem + G.sii_off);
+    const float *ccm = reinterpret_cast<const float *>(smem + G.u_off + 2 * G.trow_bytes);
+    u32 *hist = reinterpret_cast<u32 *>(smem + G.hist_off);            // 2048 16-bit counters, zero on entry; m->sel_cle = 0
+    u32 *list = hist + 1024;                                           // kMedList keys
+    const int rh = G.rh, rw = G.rw, npos = G.npos;
+    const bool norm = (flags & 1u) != 0;
+    double sx = 0.0, sxx = 0.0;
+    {
+        auto d2 = [&](const float *f, int stride, int k, int n) {
+            const int kp = k + 1 < n ? k + 1 : n - 1, km = k > 0 ? k - 1 : 0;
+            const int kpp = kp + 1 < n ? kp + 1 : n - 1, kpm = kp > 0 ? kp - 1 : 0;
+            const int kmp = km + 1 < n ? km + 1 : n - 1, kmm = km > 0 ? km - 1 : 0;
+            const float fa = f[kpp * stride], fb = f[kpm * stride], fc = f[kmp * stride], fd = f[kmm * stride];
+            const float gp = (fa - fb) * ((kp > 0 && kp < n - 1) ? 0.5f : 1.0f);
+            const float gm = (fc - fd) * ((km > 0 && km < n - 1) ? 0.5f : 1.0f);
+            return (gp - gm) * ((k > 0 && k < n - 1) ? 0.5f : 1.0f);
+        };
+        auto emit = [&](int idx, float hv) {
+            hes[idx] = hv;
+            sx += (double)hv; sxx += (double)hv * (double)hv;
+            if (norm) { const u32 b = hes_bucket(__float_as_uint(hv)); atomicAdd(&hist[b >> 1], 1u << (16 * (b & 1u))); }
+        };
+        // interior (five reads, central differences only) and frame exactly as in ph_hessian; the square roots of a
+        // batch are evaluated unconditionally (independent chains interleave), only the stores are predicated
+        constexpr int kHes = 4;
+        const int iw = rw - 4, ih = rh - 4;
+        if (iw > 0 && ih > 0) {
+            const u32 imagic = 0xffffffffu / (u32)iw + 1u;
+            const int nin = iw * ih;
+            for (int base = 0; base < nin; base += kHes * kBlockM) {
+                float d2xv[kHes], d2yv[kHes];
+#pragma unroll
+                for (int u = 0; u < kHes; ++u) {
+                    const int q = base + u * kBlockM + tid;
+                    const int qc = q < nin ? q : 0;
+                    const int yy = (int)__umulhi((u32)qc, imagic), xx = qc - yy * iw;
+                    const float *f = ccm + (yy + 2) * rw + (xx + 2);
+                    const float c = f[0], xr = f[2], xl = f[-2], yd = f[2 * rw], yu = f[-2 * rw];
+                    d2xv[u] = ((xr - c) * 0.5f - (c - xl) * 0.5f) * 0.5f;
+                    d2yv[u] = ((yd - c) * 0.5f - (c - yu) * 0.5f) * 0.5f;
+                }
+                float hvv[kHes];
+#pragma unroll
+                for (int u = 0; u < kHes; ++u) hvv[u] = hypot_fast(d2xv[u], d2yv[u]);
+#pragma unroll
+                for (int u = 0; u < kHes; ++u) {
+                    const int q = base + u * kBlockM + tid;
+                    if (q < nin) { const int yy = (int)__umulhi((u32)q, imagic), xx = q - yy * iw; emit((yy + 2) * rw + xx + 2, hvv[u]); }
+                }
+            }
+        }
+        const bool has_in = iw > 0 && ih > 0;
+        const int nfr = has_in ? 4 * rw + 4 * ih : npos;
+        for (int q0 = 0; q0 < nfr; q0 += 2 * kBlockM) {                // two frame placements per thread in flight
+            float hv2[2]; int idx2[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int qq = q0 + u * kBlockM + tid, q = qq < nfr ? qq : 0;
+                int y, x;
+                if (!has_in) { y = q / rw; x = q - y * rw; }
+                else if (q < 4 * rw) { const int rr = q / rw; x = q - rr * rw; y = rr < 2 ? rr : rh - 4 + rr; }
+                else { const int e = q - 4 * rw; const int yy = e >> 2, cc = e & 3; y = yy + 2; x = cc < 2 ? cc : rw - 4 + cc; }
+                idx2[u] = qq < nfr ? y * rw + x : -1;
+                hv2[u] = hypot_fast(d2(ccm + y * rw, 1, x, rw), d2(ccm + x, rw, y, rh));
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) if (idx2[u] >= 0) emit(idx2[u], hv2[u]);
+        }
+    }
+    if (norm) {
+        const double wsx = wave_sum_dpp_d(sx), wsxx = wave_sum_dpp_d(sxx);
+        if (lane == 0) { m->rot[wv][0] = wsx; m->rot[wv][1] = wsxx; }
+    }
+    if (dbg_cycles && tid == 0) dbg_cycles[19] = (long long)clock64();
+    __syncthreads();                                                   // A: magnitudes, histogram, partial sums
+    if (dbg_ccm || dbg_hes) {
+        for (int idx = tid; idx < npos && idx < dbg_cap; idx += kBlockM) {
+            if (dbg_ccm) dbg_ccm[idx] = ccm[idx];
+            if (dbg_hes) dbg_hes[idx] = hes[idx];
+        }
+    }
+    if (dbg_cycles && tid == 0) dbg_cycles[14] = (long long)clock64();
+    if (!norm) {
+        if (tid == 0) { m->red_f[0] = hes[iy * rw + ix]; m->red_f[1] = best_r; }
+        return;
+    }
+    // ---- every wavefront: the bucket of the middle rank.  Lane l sums the counters of buckets 32 l .. 32 l + 31; the lane
+    //      whose range holds rank k1 hands its 32 counters to lanes 0..31 through a private LDS slot, and a second
+    //      wavefront prefix sum finds the bucket (two short scans instead of a 32-step search in one lane) ----
+    u32 c[16];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const uint4 c4 = *reinterpret_cast<const uint4 *>(hist + 16 * lane + 4 * q);
+        c[4 * q] = c4.x; c[4 * q + 1] = c4.y; c[4 * q + 2] = c4.z; c[4 * q + 3] = c4.w;
+    }
+    u32 tot = 0;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) tot += (c[q] & 0xffffu) + (c[q] >> 16);
+    const u32 inc = wave_scan_dpp(tot), exc = inc - tot;
+    const bool two = !(npos & 1);
+    const u32 k1 = two ? (u32)(npos / 2 - 1) : (u32)(npos / 2);
+    const bool mine = k1 >= exc && k1 < inc;                           // exactly one lane
+    const int L = (int)__builtin_ctzll(__ballot(mine));                // wavefront-uniform
+    u32 *xch = reinterpret_cast<u32 *>(m->rTd) + 16 * wv;             // (1 / sqrt(dT) and sum t' per angle are dead: 1 KB of scratch)
+    if (mine) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) *reinterpret_cast<uint4 *>(xch + 4 * q) = make_uint4(c[4 * q], c[4 * q + 1], c[4 * q + 2], c[4 * q + 3]);
+    }
+    const u32 base_e = (u32)__builtin_amdgcn_readlane((int)exc, L);    // values below bucket 32 L
+    const u32 pk = xch[(lane & 31) >> 1];
+    const u32 cq = lane < 32 ? ((lane & 1) ? pk >> 16 : pk & 0xffffu) : 0u;
+    const u32 inc2 = wave_scan_dpp(cq) + base_e, exc2 = inc2 - cq;
+    const int J = (int)__builtin_ctzll(__ballot(k1 < inc2));           // first bucket whose inclusive count passes k1
+    const u32 bin1 = 32u * (u32)L + (u32)J;
+    const u32 before = (u32)__builtin_amdgcn_readlane((int)exc2, J), cnt1 = (u32)__builtin_amdgcn_readlane((int)cq, J);
+    // the second middle value of an even-sized set lies in the same bucket unless the first is the bucket's last element;
+    // then the next three buckets join the list (the next non-empty one is among them unless the matrix is degenerate)
+    const bool need2 = two && !(k1 + 1 - before < cnt1);
+    const u32 bin_hi = bin1 + (need2 ? 3u : 0u);
+    u32 cnt2 = 0;
+    if (need2) {
+#pragma unroll
+        for (u32 d = 1; d <= 3; ++d) { const u32 bb = bin1 + d; if (bb < (u32)kHesBuckets) cnt2 += (hist[bb >> 1] >> (16 * (bb & 1u))) & 0xffffu; }
+    }
+    const u32 nlist = cnt1 + cnt2;
+    if (dbg_cycles && tid == 0) dbg_cycles[22] = (long long)clock64();
+    if (nlist > (u32)kMedList || (need2 && cnt2 == 0u)) {              // block-uniform: massive ties, gaps -> radix select
+        double tx = 0.0, txx = 0.0;
+        for (int q = 0; q < kWavesM; ++q) { tx += m->rot[q][0]; txx += m->rot[q][1]; }
+        const float h = hes[iy * rw + ix];
+        const float med = block_median(hes, npos, m, hist);
+        if (tid == 0) { m->red_f[0] = (h - med) / std_from_sums(tx, txx, npos); m->red_f[1] = best_r; }
+        return;
+    }
+    for (int i = tid; i < npos; i += kBlockM) {
+        const u32 bits = __float_as_uint(hes[i]), b = hes_bucket(bits);
+        if (b >= bin1 && b <= bin_hi) list[atomicAdd(&m->sel_cle, 1u)] = bits;  // (non-negative floats order like their bits)
+    }
+    __syncthreads();                                                   // B: the list is complete
+    if (dbg_cycles && tid == 0) dbg_cycles[23] = (long long)clock64();
+    if (wv != 0) return;
+    // wavefront 0: rank the list (both buckets together: bucket order = value order), pick the middle value(s), finish
+    double tx = 0.0, txx = 0.0;
+    for (int q = 0; q < kWavesM; ++q) { tx += m->rot[q][0]; txx += m->rot[q][1]; }
+    const float h = hes[iy * rw + ix];
+    const u32 r1 = k1 - before, r2 = r1 + 1;
+    u32 key1 = 0, key2 = 0;
+    for (u32 base = 0; base < nlist; base += 64) {
+        const u32 j = base + (u32)lane;
+        const u32 mv = j < nlist ? list[j] : 0xffffffffu;
+        u32 rank = 0;
+        for (u32 t0 = 0; t0 < nlist; t0 += 4) {                        // (the list region holds kMedList entries: reads past nlist are harmless)
+            const uint4 o = *reinterpret_cast<const uint4 *>(list + t0);
+            rank += (t0 + 0 < nlist && (o.x < mv || (o.x == mv && t0 + 0 < j))) ? 1u : 0u;
+            rank += (t0 + 1 < nlist && (o.y < mv || (o.y == mv && t0 + 1 < j))) ? 1u : 0u;
+            rank += (t0 + 2 < nlist && (o.z < mv || (o.z == mv && t0 + 2 < j))) ? 1u : 0u;
+            rank += (t0 + 3 < nlist && (o.w < mv || (o.w == mv && t0 + 3 < j))) ? 1u : 0u;
+        }
+        const unsigned long long h1 = __ballot(j < nlist && rank == r1), h2 = __ballot(j < nlist && rank == r2);
+        if (h1) key1 = (u32)__builtin_amdgcn_readlane((int)mv, (int)__builtin_ctzll(h1));
+        if (h2) key2 = (u32)__builtin_amdgcn_readlane((int)mv, (int)__builtin_ctzll(h2));
+    }
+    const float med = two ? (__uint_as_float(key1) + __uint_as_float(key2)) / 2.0f : __uint_as_float(key1);
+    if (dbg_cycles && tid == 0) dbg_cycles[24] = (long long)clock64();
+    if (tid == 0) { m->red_f[0] = (h - med) / std_from_sums(tx, txx, npos); m->red_f[1] = best_r; }
 }
 
 // BAND = 4: up to 768 threads, three wavefronts per SIMD (168 VGPRs).  BAND = 8: 256 threads, two per SIMD (the
@@ -1523,6 +1776,7 @@ __global__ __launch_bounds__(BAND == 8 ? 512 : kMaxBlockM, BAND == 8 ? 2 : kOccM
         G->win_magic = 0xffffffffu / (u32)(L.wpitch >> 2) + 1u; G->patch_magic = 0xffffffffu / (u32)(L.ppitch >> 2) + 1u;
         G->rw_magic = 0xffffffffu / (u32)rw + 1u;
         G->r0 = r0; G->c0 = c0; G->c1 = c1; G->r1 = r1; G->nd = (double)(s * s);
+        G->hist_off = 0;
         m->zero_flag = 0; m->gmax_key = 0x007fffffu /* f2key(-inf) */; m->qcount = 0;
         for (int k = 0; k < 5; ++k) m->gw[k] = A.gauss_w[k];
     }
@@ -1646,6 +1900,31 @@ __global__ void ncc_selftest_kernel(unsigned long long seed, int per_thread, int
     if (slow) atomicAdd(&out[2], slow);
 }
 
+// hypot_fast against hypot_spec on pseudo-random float32 pairs of the magnitudes second differences of NCC values take
+// (and, every fourth sample, pairs constructed to land next to a float32 rounding boundary): out = evaluations, mismatches
+__global__ void hypot_selftest_kernel(unsigned long long seed, int per_thread, unsigned long long *out)
+{
+    unsigned long long st = seed ^ (0x9e3779b97f4a7c15ull * (unsigned long long)(blockIdx.x * blockDim.x + threadIdx.x + 1));
+    auto next = [&]() { st ^= st << 13; st ^= st >> 7; st ^= st << 17; return st; };
+    unsigned long long bad = 0;
+    for (int it = 0; it < per_thread; ++it) {
+        const unsigned long long a = next(), b = next();
+        // mantissas uniform, exponents 2^-40 .. 2^1 (and occasionally zero / denormal / huge)
+        const int ea = 127 - (int)(a % 41) + 1, eb = 127 - (int)((a >> 8) % 41) + 1;
+        float x = __uint_as_float(((u32)ea << 23) | (u32)(b & 0x7fffffu)), y = __uint_as_float(((u32)eb << 23) | (u32)((b >> 23) & 0x7fffffu));
+        const u32 kind = (u32)(a >> 60);
+        if (kind == 0) y = 0.0f;                                       // perfect squares: sqrt lands on a float exactly
+        if (kind == 1) { x = 0.0f; y = 0.0f; }
+        if (kind == 2) x = __uint_as_float((u32)(b & 0x7fffffu));      // denormal
+        if (kind == 3) { x = __uint_as_float(0x7e000000u | (u32)(b & 0x7fffffu)); }
+        if (a & (1ull << 40)) x = -x;
+        if (a & (1ull << 41)) y = -y;
+        bad += __float_as_uint(hypot_fast(x, y)) != __float_as_uint(hypot_spec(x, y)) ? 1ull : 0ull;
+    }
+    atomicAdd(&out[0], (unsigned long long)per_thread);
+    if (bad) atomicAdd(&out[1], bad);
+}
+
 __global__ void rsqrt_kernel(const double *x, double *y, int64_t n)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1668,6 +1947,13 @@ int launch_ncc_selftest(unsigned long long seed, int blocks, int per_thread, int
 {
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     hipLaunchKernelGGL(ncc_selftest_kernel, dim3((unsigned)blocks), dim3(256), 0, st, seed, per_thread, s, out);
+    return (int)hipGetLastError();
+}
+
+int launch_hypot_selftest(unsigned long long seed, int blocks, int per_thread, unsigned long long *out, void *stream)
+{
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(hypot_selftest_kernel, dim3((unsigned)blocks), dim3(256), 0, st, seed, per_thread, out);
     return (int)hipGetLastError();
 }
 
@@ -1716,16 +2002,31 @@ int launch_pm_mfma(const PMArgs &args, int lds_bytes, int nthreads, int band, bo
     return (int)hipGetLastError();
 }
 
-int launch_pm_rp(const PMArgs &args, int lds_bytes, int nthreads, int band, bool paired, void *stream)
+template <int S>
+static void (*rp_kernel_for(int band, bool paired, int pitch))(const PMArgs)
+{
+    if (paired) return pitch == 104 ? pm_kernel_rp<S, 4, true, 104> : pitch == 136 ? pm_kernel_rp<S, 4, true, 136>
+                     : pitch == 168 ? pm_kernel_rp<S, 4, true, 168> : pitch == 0 ? pm_kernel_rp<S, 4, true, 0> : nullptr;
+    if (band == 8) return pitch == 136 ? pm_kernel_rp<S, 8, false, 136> : pitch == 0 ? pm_kernel_rp<S, 8, false, 0> : nullptr;
+    return pitch == 104 ? pm_kernel_rp<S, 4, false, 104> : pitch == 136 ? pm_kernel_rp<S, 4, false, 136>
+         : pitch == 168 ? pm_kernel_rp<S, 4, false, 168> : pitch == 0 ? pm_kernel_rp<S, 4, false, 0> : nullptr;
+}
+
+// true when launch_pm_rp carries an instantiation with this compile-time window pitch (0 = run-time pitch: always)
+bool rp_pitch_instantiated(int band, bool paired, int pitch)
+{
+    return rp_kernel_for<34>(band, paired, pitch) != nullptr;
+}
+
+int launch_pm_rp(const PMArgs &args, int lds_bytes, int nthreads, int band, bool paired, int pitch, void *stream)
 {
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (args.n_launch <= 0) return (int)hipSuccess;
     if (!rp_size_supported(args.img_size)) return (int)hipErrorInvalidValue;
     if ((band != 4 && band != 8) || (band == 8 && nthreads != 256)) return (int)hipErrorInvalidValue;
     if (paired && (band != 4 || args.n_angles > kPairedMaxAngles)) return (int)hipErrorInvalidValue;
-    void (*kern)(const PMArgs) = paired ? (args.img_size == 34 ? pm_kernel_rp<34, 4, true> : pm_kernel_rp<35, 4, true>)
-                               : band == 8 ? (args.img_size == 34 ? pm_kernel_rp<34, 8> : pm_kernel_rp<35, 8>)
-                                           : (args.img_size == 34 ? pm_kernel_rp<34> : pm_kernel_rp<35>);
+    void (*kern)(const PMArgs) = args.img_size == 34 ? rp_kernel_for<34>(band, paired, pitch) : rp_kernel_for<35>(band, paired, pitch);
+    if (!kern) return (int)hipErrorInvalidValue;
     const hipError_t e = allow_max_lds(kern);
     if (e != hipSuccess) return (int)e;
     if (lds_bytes > max_lds_bytes() || nthreads < 256 || nthreads > 768 || (nthreads & 63)) return (int)hipErrorInvalidValue;

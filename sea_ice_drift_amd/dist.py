@@ -26,38 +26,31 @@ def shard_indices(border, world_size, rank):
     return np.sort(order[owner == rank])
 
 
-# Nanoseconds per grid point on one MI355X as a function of the search border (tools/border_cost.py: template side 34,
-# 15 angles, 40 000 points of one border each).  The cost is a staircase - it follows the number of placement tiles per
-# output row and the number of workgroups a CU can hold - and the ratios are the same for other angle counts.
-_BORDER_COST_NS = {20: 76.6, 21: 77.2, 22: 79.0, 23: 79.9, 24: 123.8, 25: 124.2, 26: 126.1, 27: 128.0, 28: 128.8, 29: 130.4,
-                   30: 132.1, 31: 133.7, 32: 172.8, 33: 174.3, 34: 176.4, 35: 177.2, 36: 184.6, 37: 246.9, 38: 247.1,
-                   39: 247.6, 40: 275.2, 41: 280.2, 42: 286.5, 43: 286.9, 44: 297.1, 45: 299.0, 46: 300.7, 47: 303.6,
-                   48: 355.1, 49: 359.6, 50: 368.7}
+def point_cost(border, img_size=34, n_angles=15):
+    """Estimated cost of a grid point (nanoseconds on one MI355X; only the ratios matter here).  Computed by the library
+    (include/sid_pm.h ``sid_pm_estimate_cost``, host arithmetic) from what the kernel executes for a point of that search
+    border - matrix instructions of the sweep and of the winner's NCC matrix, placements - and from the residency class of
+    its LDS footprint, for the template side and angle count of the run; it reproduces the staircase that
+    tools/border_cost.py measures (placement tiles per output row, workgroups per CU) within 8 %."""
+    from . import _capi
+    return _capi.estimate_cost(np.asarray(border, dtype=np.float64), img_size, n_angles)
 
 
-def point_cost(border):
-    """Estimated relative cost of a grid point: the measured staircase inside its range, (2 b + 2)^2 scaled to it outside."""
-    b = np.asarray(border, dtype=np.float64)
-    bi = np.clip(np.rint(b), 20, 50).astype(np.int64)
-    table = np.array([_BORDER_COST_NS[k] for k in range(20, 51)])
-    cost = table[bi - 20]
-    outside = (b < 20) | (b > 50)
-    ref = np.where(b < 20, 20.0, 50.0)
-    scale = (2.0 * np.maximum(b, 0.0) + 2.0) ** 2 / (2.0 * ref + 2.0) ** 2
-    return np.where(outside, cost * np.maximum(scale, 0.05), cost)
-
-
-def shard_indices_by_cost(border, world_size, rank):
+def shard_indices_by_cost(border, world_size, rank, img_size=34, n_angles=15):
     """Indices owned by `rank` when the points, ordered by border (largest first, stable), are cut into `world_size`
     contiguous runs of equal estimated cost.  A rank then holds one or two neighbouring border classes instead of an
     eighth of every class, i.e. one or two launches that are eight times longer: at 5 000 points per rank the tails of
-    three short launches cost a quarter of the step."""
+    three short launches cost a quarter of the step.
+
+    Every rank's kernels must finish before the gather can complete, so the step time is the slowest rank's kernel time
+    plus the exchange step; shortening rank 0's shard would not hide the exchange (it starts when the LAST rank is done)."""
     border = np.asarray(border)
     order = np.argsort(-border, kind='stable')
-    cum = np.cumsum(point_cost(border[order]))
+    cost = point_cost(border[order], img_size, n_angles)
+    cum = np.cumsum(cost)
     total = cum[-1] if cum.size else 0.0
     # point k goes to the rank whose cost interval holds the middle of its own
-    mid = cum - 0.5 * point_cost(border[order])
+    mid = cum - 0.5 * cost
     owner = np.minimum((mid * world_size / total).astype(np.int64), world_size - 1) if total > 0 else np.zeros(0, np.int64)
     return np.sort(order[owner == rank])
 
@@ -143,7 +136,10 @@ class PackedGatherer(object):
 
     ROW = 5 * 8 + 3 * 4
 
-    def __init__(self, n_total, idx_local, device, group=None, dst=0):
+    def __init__(self, n_total, idx_local, device, group=None, dst=0, force_collective=False, timing=False):
+        """``force_collective``: run every collective (the all_reduce and the two gathers) even in a group of ONE rank - the
+        RCCL code path of an N-GPU run then executes on a one-GPU box (a world-size-1 ``nccl`` group), where it can be
+        tested.  ``timing``: HIP events around the three stages of the exchange step (``timings()``)."""
         import torch
         import torch.distributed as dist
         self.torch, self.dist, self.group, self.dst = torch, dist, group, dst
@@ -153,9 +149,12 @@ class PackedGatherer(object):
         self.is_dst = self.rank == dst
         self.n_total, self.device = int(n_total), torch.device(device)
         self.n_local = len(idx_local)
+        self.collective = self.distributed and (self.world > 1 or bool(force_collective))
         self.host_staged = self.distributed and dist.get_backend(group) == 'gloo' and self.device.type != 'cpu'
+        self.timing = bool(timing) and self.device.type == 'cuda'
+        self._ev, self._acc, self._n_timed = [], [0.0, 0.0, 0.0], 0
         # rows of the padded block = the largest shard (the shards of shard_indices_by_cost differ in length)
-        if self.world > 1:
+        if self.collective:
             t = torch.tensor([self.n_local], dtype=torch.int64,
                              device='cpu' if dist.get_backend(group) == 'gloo' else self.device)
             dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
@@ -171,7 +170,7 @@ class PackedGatherer(object):
         # one-time index exchange: which original point every row of every rank's block holds
         idx_pad = torch.full((m,), -1, dtype=torch.int64)
         idx_pad[:self.n_local] = torch.as_tensor(np.asarray(idx_local), dtype=torch.int64)
-        if self.world == 1:
+        if not self.collective:
             all_idx = idx_pad[None]
         else:
             gl = [torch.empty_like(idx_pad) for _ in range(self.world)] if self.is_dst else None
@@ -206,7 +205,11 @@ class PackedGatherer(object):
     def gather_to_host(self):
         """The exchange step.  On `dst` the results are in host memory, in original point order, on return."""
         torch, dist, m = self.torch, self.dist, self.m
-        if self.world == 1:
+        ev = None
+        if self.timing and self.is_dst:
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+            ev[0].record()
+        if not self.collective:
             stack = self.block[None]
         elif self.host_staged:
             mine = self.block.cpu()
@@ -217,16 +220,35 @@ class PackedGatherer(object):
             stack = self.stack if self.is_dst else None
         if not self.is_dst:
             return
+        if ev:
+            ev[1].record()
         so = stack[:, :m * 40].reshape(-1).view(torch.float64).view(-1, 5) if stack.shape[0] == 1 else \
             stack[:, :m * 40].contiguous().view(torch.float64).view(-1, 5)
         si = stack[:, m * 40:].reshape(-1).view(torch.int32).view(-1, 3) if stack.shape[0] == 1 else \
             stack[:, m * 40:].contiguous().view(torch.int32).view(-1, 3)
         torch.index_select(so, 0, self.perm, out=self.full_out)
         torch.index_select(si, 0, self.perm, out=self.full_ij)
+        if ev:
+            ev[2].record()
         self.host_out.copy_(self.full_out, non_blocking=True)
         self.host_ij.copy_(self.full_ij, non_blocking=True)
+        if ev:
+            ev[3].record()
         if self.device.type == 'cuda':
             torch.cuda.current_stream(self.device).synchronize()
+        if ev:
+            for k in range(3):
+                self._acc[k] += ev[k].elapsed_time(ev[k + 1])
+            self._n_timed += 1
+
+    def timings(self, reset=True):
+        """Mean milliseconds per exchange step on `dst` since the last reset: the gather (on the launch stream it also
+        holds the wait for the slowest rank's kernels), the un-permutation, the copy to pinned host memory."""
+        n = max(self._n_timed, 1)
+        out = {'gather_ms': self._acc[0] / n, 'unpermute_ms': self._acc[1] / n, 'd2h_ms': self._acc[2] / n, 'steps': self._n_timed}
+        if reset:
+            self._acc, self._n_timed = [0.0, 0.0, 0.0], 0
+        return out
 
     def host_results(self):
         """NumPy copies of the gathered results (`dst` only)."""

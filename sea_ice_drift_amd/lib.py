@@ -22,6 +22,7 @@ except Exception:                         # noqa: BLE001
 
 
 EARTH_RADIUS_KM = 6371  # mean radius the reference's Haversine uses (lib.py:25)
+AVG_EARTH_RADIUS = EARTH_RADIUS_KM  # the reference's name for it
 
 
 def _haversine_km(lon_a, lat_a, lon_b, lat_b):
@@ -44,30 +45,58 @@ def get_displacement_km(n1, x1, y1, n2, x2, y2):
     return great_circle_km(n1, x1, y1, n2, x2, y2)
 
 
+def get_displacement_pix(n1, x1, y1, n2, x2, y2):
+    """Displacement in pixels of the first image (reference lib.py:103-121): the key points of image 2 are carried
+    through lon/lat into the pixel space of image 1; returns (dx, dy) = their offsets from (x1, y1)."""
+    on_n1 = n1.transform_points(*n2.transform_points(x2, y2), 1)
+    return on_n1[0] - x1, on_n1[1] - y1
+
+
 def get_speed_ms(n1, x1, y1, n2, x2, y2):
     """Drift speed in m/s between two time-stamped images (reference lib.py:87-102)."""
     elapsed = abs((n2.time_coverage_start - n1.time_coverage_start).total_seconds())
     return 1000. * great_circle_km(n1, x1, y1, n2, x2, y2) / elapsed
 
 
+def _is_projected(nsr):
+    return nsr is not None and getattr(nsr, 'srs', None) not in (None, '')
+
+
 def get_drift_vectors(n1, x1, y1, n2, x2, y2, nsr=None, **kwargs):
-    """u, v, lon1, lat1, lon2, lat2 of matched points (reference lib.py:375-406).  The reference projects
-    through ``nansat.Domain(nsr, '-te -10 -10 10 10 -tr 1 1')``; for the default ``nsr`` (lon/lat WGS84)
-    that domain maps (lon, lat) to (lon + 10, 10 - lat), so u = lon2 - lon1 and v = lat2 - lat1 in degrees.
-    Any other projection needs the real nansat and is delegated to it."""
+    """u, v, lon1, lat1, lon2, lat2 of matched points (reference lib.py:375-406).
+
+    The reference projects lon/lat through ``nansat.Domain(nsr, '-te -10 -10 10 10 -tr 1 1')`` - a grid with origin
+    (-10, 10) and unit pixels in the units of ``nsr`` - and returns pixel differences: with (X, Y) the coordinates of
+    a point in ``nsr``, its pixel is (X + 10, 10 - Y), so u = (X2 + 10) - (X1 + 10) and v = (10 - Y1) - (10 - Y2).
+    That arithmetic is restated here.  Where (X, Y) come from:
+
+    * default ``nsr`` (lon/lat WGS84): X = lon, Y = lat;
+    * a projected ``nsr`` with nansat installed: the reference's own Domain call;
+    * a projected ``nsr`` without nansat: the images' own ``transform_points(x, y, 0, nsr)`` (pixel -> coordinates
+      in the destination SRS, the call pm_postlude makes for ``srs=``, pmlib.py:473-478; Appendix A of SURVEY.md) -
+      any Nansat-like object that implements it serves; one that does not raises NotImplementedError."""
     lon1, lat1 = n1.transform_points(x1, y1)
     lon2, lat2 = n2.transform_points(x2, y2)
-    if nsr is not None and getattr(nsr, 'srs', None) not in (None, ''):
+    if _is_projected(nsr):
         try:
             from nansat import Domain            # pragma: no cover - not installed in this image
         except Exception:                        # noqa: BLE001
-            raise NotImplementedError('a projected nsr needs nansat; only the default lon/lat is built in')
-        d = Domain(nsr, '-te -10 -10 10 10 -tr 1 1')                      # pragma: no cover
-        x1, y1 = d.transform_points(lon1, lat1, 1)                         # pragma: no cover
-        x2, y2 = d.transform_points(lon2, lat2, 1)                         # pragma: no cover
-        return x2 - x1, y1 - y2, lon1, lat1, lon2, lat2                    # pragma: no cover
-    px1, py1 = lon1 - (-10.0), 10.0 - lat1                                  # Domain('-te -10 -10 10 10 -tr 1 1')
-    px2, py2 = lon2 - (-10.0), 10.0 - lat2
+            Domain = None
+        if Domain is not None:                                                # pragma: no cover
+            d = Domain(nsr, '-te -10 -10 10 10 -tr 1 1')
+            px1, py1 = d.transform_points(lon1, lat1, 1)
+            px2, py2 = d.transform_points(lon2, lat2, 1)
+            return px2 - px1, py1 - py2, lon1, lat1, lon2, lat2
+        try:
+            X1, Y1 = n1.transform_points(x1, y1, 0, nsr)
+            X2, Y2 = n2.transform_points(x2, y2, 0, nsr)
+        except TypeError:
+            raise NotImplementedError('a projected nsr needs nansat, or image objects whose transform_points accepts a '
+                                      'destination SRS (transform_points(x, y, 0, nsr))')
+    else:
+        X1, Y1, X2, Y2 = lon1, lat1, lon2, lat2
+    px1, py1 = X1 - (-10.0), 10.0 - Y1                                        # Domain('-te -10 -10 10 10 -tr 1 1')
+    px2, py2 = X2 - (-10.0), 10.0 - Y2
     return px2 - px1, py1 - py2, lon1, lat1, lon2, lat2
 
 

@@ -19,6 +19,8 @@ The structure is  prelude (host, NumPy)  ->  dispatch (GPU)  ->  postlude (host,
 """
 from __future__ import absolute_import, print_function
 
+import atexit
+import threading
 import time
 
 import numpy as np
@@ -198,14 +200,47 @@ def _sweep_options(kwargs):
     return angles, flags
 
 
-_CONTEXTS = {}                      # one device handle per GPU, created on first use and kept (streams, buffers)
+# One device handle per GPU, created on first use and kept (streams, device buffers, the two pair slots).  A handle
+# carries the state of ONE call at a time (current pair, resident points, results), so every use of a shared handle
+# holds that device's lock from the upload to the fetch: concurrent pattern_matching / pm_dispatch calls on one GPU
+# queue up instead of interleaving (the reference's module globals, pmlib.py:33-34, make it
+# non-re-entrant; here the C ABI is re-entrant per handle and the Python mirror serialises per device).  A caller
+# who wants two calls in flight on one GPU passes its own ``context=`` to each.
+_CONTEXTS = {}
+_CONTEXT_LOCKS = {}
+_REGISTRY_LOCK = threading.Lock()
 
 
 def _shared_context(device):
-    ctx = _CONTEXTS.get(device)
-    if ctx is None:
-        ctx = _CONTEXTS[device] = _capi.PMContext(device)
-    return ctx
+    """(handle, lock) of ``device``."""
+    with _REGISTRY_LOCK:
+        ctx = _CONTEXTS.get(device)
+        if ctx is None:
+            ctx = _CONTEXTS[device] = _capi.PMContext(device)
+            _CONTEXT_LOCKS[device] = threading.RLock()
+        return ctx, _CONTEXT_LOCKS[device]
+
+
+def release_contexts():
+    """Destroy the per-device handles (each keeps two image-pair slots resident in HBM).  Registered with atexit;
+    safe to call at any time no call is in flight - the next call creates a fresh handle."""
+    with _REGISTRY_LOCK:
+        items = list(_CONTEXTS.items())
+        _CONTEXTS.clear()
+    for device, ctx in items:
+        with _CONTEXT_LOCKS[device]:
+            ctx.close()
+
+
+atexit.register(release_contexts)
+
+
+class _NoLock(object):
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
 
 
 def pm_dispatch(img1, img2, c1, r1, c2fg, r2fg, border, img_size, alpha0, device=0, context=None, **kwargs):
@@ -214,17 +249,18 @@ def pm_dispatch(img1, img2, c1, r1, c2fg, r2fg, border, img_size, alpha0, device
     that repeated calls pay neither for streams and events nor for device buffers again."""
     angles, flags = _sweep_options(kwargs)
     rot = rotation_table(angles, alpha0, img_size)
-    ctx = _shared_context(device) if context is None else context
-    if img1 is not None:                    # (None: the caller uploaded the pair to ``context`` already)
-        ctx.upload_pair(img1, img2)         # slot 0, and selected: the handle may have had another pair current
-    try:
-        ctx.set_points(c1, r1, c2fg, r2fg, border, img_size, alpha0, angles, rot=rot, flags=flags)
-    except _capi.SidPmError as e:
-        if e.code == -4:
-            raise NotImplementedError(str(e))
-        raise
-    ctx.run()
-    return ctx.fetch(want_ij=False)
+    ctx, lock = _shared_context(device) if context is None else (context, _NoLock())
+    with lock:
+        if img1 is not None:                # (None: the caller uploaded the pair to ``context`` already)
+            ctx.upload_pair(img1, img2)     # slot 0, and selected: the handle may have had another pair current
+        try:
+            ctx.set_points(c1, r1, c2fg, r2fg, border, img_size, alpha0, angles, rot=rot, flags=flags)
+        except _capi.SidPmError as e:
+            if e.code == -4:
+                raise NotImplementedError(str(e))
+            raise
+        ctx.run()
+        return ctx.fetch(want_ij=False)
 
 
 def use_mcc(c1, r1, c2fg, r2fg, border, img1, img2, img_size, alpha0, **kwargs):
@@ -244,17 +280,18 @@ def pattern_matching(lon_pm1, lat_pm1, n1, c1, r1, n2, c2, r2,
     # The image pair goes to the device while the host works on the first guess (its Delaunay triangulation is the
     # longest step of the prelude): the upload is a C call that does not hold the interpreter lock.
     ctx = kwargs.pop('context', None)
-    ctx = _shared_context(kwargs.get('device', 0)) if ctx is None else ctx
-    upload = ctx.upload_pair_background(img1, img2)
-    try:
-        pre = pm_prelude(lon_pm1, lat_pm1, n1, c1, r1, n2, c2, r2, margin=margin, img_size=img_size, **kwargs)
-    finally:
-        upload.wait()                                                 # (re-raises what the upload raised)
-    gpi = pre['gpi']
-    if gpi.any():
-        results = pm_dispatch(None, None, pre['c1pm1i'][gpi], pre['r1pm1i'][gpi], pre['c2fg'][gpi],
-                              pre['r2fg'][gpi], pre['brd2'][gpi], img_size, pre['alpha0'], context=ctx, **kwargs)
-    else:
-        results = np.zeros((0, 5))
+    ctx, lock = _shared_context(kwargs.get('device', 0)) if ctx is None else (ctx, _NoLock())
+    with lock:                                                        # the handle is this call's from upload to fetch
+        upload = ctx.upload_pair_background(img1, img2)
+        try:
+            pre = pm_prelude(lon_pm1, lat_pm1, n1, c1, r1, n2, c2, r2, margin=margin, img_size=img_size, **kwargs)
+        finally:
+            upload.wait()                                             # (re-raises what the upload raised)
+        gpi = pre['gpi']
+        if gpi.any():
+            results = pm_dispatch(None, None, pre['c1pm1i'][gpi], pre['r1pm1i'][gpi], pre['c2fg'][gpi],
+                                  pre['r2fg'][gpi], pre['brd2'][gpi], img_size, pre['alpha0'], context=ctx, **kwargs)
+        else:
+            results = np.zeros((0, 5))
     print('\n', 'Pattern matching - OK! (%3.0f sec)' % (time.time() - t0))
     return pm_postlude(pre, results, n2, srs=srs)

@@ -1,7 +1,8 @@
 """``SeaIceDrift`` with the reference's public methods (reference seaicedrift.py:23-88).
 
-``get_drift_PM`` is the hot path; ``get_drift_FT`` runs the matcher on the GPU and the reference's
-filters on the host, with ORB detection left to OpenCV (or a ``find_key_points=`` callable).  The
+``get_drift_PM`` is the hot path; ``get_drift_FT`` runs the key-point detector (``sea_ice_drift_amd.orb``, an
+ORB-family detector behind the reference's interface - OpenCV is not used) and the Hamming matcher on the GPU and
+the reference's filters on the host; a ``find_key_points=`` callable replaces the detector.  The
 constructor takes two Nansat-like objects (``sea_ice_drift_amd.domain.ArrayNansat`` or real
 ``nansat.Nansat``); opening Sentinel-1 files (reference lib.get_n, lib.py:256-340) needs nansat/GDAL and
 is outside the scope of this package - passing file names raises with a pointer to what to pass instead.
@@ -26,8 +27,9 @@ class SeaIceDrift(object):
 
     def get_drift_FT(self, **kwargs):
         """Same returns as the reference (seaicedrift.py:42-60): u, v, lon1, lat1, lon2, lat2 of the matched
-        key points.  Matching and filtering run here (GPU matcher); ORB detection needs OpenCV or a
-        ``find_key_points=`` callable (see ``sea_ice_drift_amd.ftlib.feature_tracking``)."""
+        key points.  Detection and matching run on the GPU (``sea_ice_drift_amd.orb``, ``include/sid_ft.h``), the
+        filters on the host; ``find_key_points=`` takes another detector (see ``ftlib.feature_tracking``).  ``nsr=``
+        selects the units of u, v as in the reference (``lib.get_drift_vectors``)."""
         x1, y1, x2, y2 = feature_tracking(self.n1, self.n2, **kwargs)
         kwargs.pop('find_key_points', None)
         return get_drift_vectors(self.n1, x1, y1, self.n2, x2, y2, **kwargs)

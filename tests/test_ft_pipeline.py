@@ -66,6 +66,34 @@ def test_drift_vectors_default_projection():
     assert km.shape == (50,) and (km >= 0).all()
 
 
+def test_drift_vectors_projected_nsr_and_displacement_pix():
+    """lib.py:375-406 with a projected nsr: without nansat the coordinates in the destination SRS come from the
+    images' own transform_points(x, y, 0, nsr) (the call pmlib.py:473-478 makes); lib.py:103-121 for the pixel
+    displacement.  Expected values written out by hand from the affine stand-in."""
+    from sea_ice_drift_amd.domain import ArrayNansat
+    img = np.ones((64, 64), dtype=np.uint8)
+    n1 = ArrayNansat(img, origin=(3.0, 4.0), matrix=((0.5, 0.0), (0.0, -0.25)), dst_scale=1000.0)
+    n2 = ArrayNansat(img, origin=(3.5, 4.5), matrix=((0.5, 0.0), (0.0, -0.25)), dst_scale=1000.0)
+    x1, y1 = np.array([10.0, 20.0]), np.array([8.0, 12.0])
+    x2, y2 = x1 + 3.0, y1 - 2.0
+    u, v, lon1, lat1, lon2, lat2 = lib.get_drift_vectors(n1, x1, y1, n2, x2, y2, nsr=lib.NSR('+proj=stere +lat_0=90'))
+    np.testing.assert_array_equal(lon1, 3.0 + 0.5 * x1)
+    np.testing.assert_array_equal(lat2, 4.5 - 0.25 * y2)
+    # destination units = lon/lat * 1000: (0.5 * 3 + 0.5) * 1000 = 2000 east, (0.25 * 2 + 0.5) * 1000 = 1000 north
+    np.testing.assert_allclose(u, [2000.0, 2000.0], rtol=0, atol=1e-9)
+    np.testing.assert_allclose(v, [1000.0, 1000.0], rtol=0, atol=1e-9)
+    dx, dy = lib.get_displacement_pix(n1, x1, y1, n2, x2, y2)
+    np.testing.assert_allclose(dx, [4.0, 4.0], rtol=0, atol=1e-12)      # 3 px + 0.5 deg / (0.5 deg/px)
+    np.testing.assert_allclose(dy, [-4.0, -4.0], rtol=0, atol=1e-12)    # -2 px + 0.5 deg / (-0.25 deg/px)
+    assert lib.AVG_EARTH_RADIUS == 6371
+
+    class NoDst(object):                       # an image object without the destination-SRS argument
+        def transform_points(self, x, y, DstToSrc=0):
+            return np.asarray(x, dtype=float), np.asarray(y, dtype=float)
+    with pytest.raises(NotImplementedError):
+        lib.get_drift_vectors(NoDst(), x1, y1, NoDst(), x2, y2, nsr=lib.NSR('+proj=stere'))
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize('timed', [False, True])
 def test_feature_tracking_on_gpu_equals_reference(timed):
@@ -83,3 +111,19 @@ def test_feature_tracking_on_gpu_equals_reference(timed):
     u, v, lon1, lat1, lon2, lat2 = SeaIceDrift(n1, n2).get_drift_FT(find_key_points=lambda image, **k: feeds.pop(0),
                                                                    domainMargin=10, ratio_test=0.75, psi=150, **kw)
     assert len(u) == len(got[0]) and np.isfinite(u).all()
+    # u, v, lon, lat of the public call are those of the fixture's matched key points (lib.py:375-406: pixel
+    # differences on the '-te -10 -10 10 10 -tr 1 1' grid of the default lon/lat projection)
+    x1, y1, x2, y2 = [g['%s_%s' % (name, tag)] for name in ('x1', 'y1', 'x2', 'y2')]
+    elon1, elat1 = n1.transform_points(x1, y1)
+    elon2, elat2 = n2.transform_points(x2, y2)
+    for got_v, want in ((lon1, elon1), (lat1, elat1), (lon2, elon2), (lat2, elat2)):
+        np.testing.assert_array_equal(got_v, want)
+    np.testing.assert_array_equal(u, (elon2 + 10.0) - (elon1 + 10.0))
+    np.testing.assert_array_equal(v, (10.0 - elat1) - (10.0 - elat2))
+    # a projected nsr goes through the images' own transform_points(x, y, 0, nsr)
+    up, vp = SeaIceDrift(n1, n2).get_drift_FT(find_key_points=(lambda f: lambda image, **k: f.pop(0))([(xy1, d1), (xy2, d2)]),
+                                              domainMargin=10, ratio_test=0.75, psi=150, nsr=lib.NSR('+proj=stere +lat_0=90'), **kw)[:2]
+    X1, Y1 = n1.transform_points(x1, y1, 0, lib.NSR('+proj=stere +lat_0=90'))
+    X2, Y2 = n2.transform_points(x2, y2, 0, lib.NSR('+proj=stere +lat_0=90'))
+    np.testing.assert_array_equal(up, (X2 + 10.0) - (X1 + 10.0))
+    np.testing.assert_array_equal(vp, (10.0 - Y1) - (10.0 - Y2))

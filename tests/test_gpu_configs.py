@@ -85,6 +85,22 @@ def test_config3_dry_run_bench_spawns_its_own_ranks():
     assert two['weak_scaling']['points_total'] == 7200
     for d in (one, two):
         assert d['roofline']['bound'] == 'mfma' and d['value'] > 0
+    # the N > 1 line says where rank 0's step goes (kernels / gather / un-permutation / copy to the host)
+    bd = two['step_breakdown_ms']
+    assert bd['backend'] == 'gloo' and bd['kernel_ms'] > 0 and bd['gather_ms'] >= 0 and bd['d2h_ms'] >= 0
+
+
+def test_rccl_code_path_runs_on_one_gpu():
+    """The collectives of the N-GPU path on the RCCL backend itself: a one-rank ``nccl`` group (initialised before any other
+    GPU work, no launcher, no re-exec) runs the pair broadcast, the all_reduce(MAX) and the index gather of the set-up and
+    the per-step gather of the packed result block on device tensors (dist.PackedGatherer(force_collective=True)) - the
+    branch that a dry run on one GPU (gloo, two ranks sharing the device) cannot reach.  Results still equal the oracle."""
+    d = run_bench('--gpus', '1', '--force-collective', '--steps', '5', '--warmup', '2', '--size', '3000', '--grid', '60',
+                  '--no-cpu-baseline')
+    bd = d['step_breakdown_ms']
+    assert bd['backend'] == 'nccl'
+    assert bd['kernel_ms'] > 0 and bd['gather_ms'] > 0 and bd['unpermute_ms'] > 0 and bd['d2h_ms'] > 0
+    assert d['parity_check']['ok'] and d['config']['points_total'] == 3600
 
 
 def test_config5_stream_16_pairs_full_size():
@@ -145,3 +161,44 @@ def test_pm_dispatch_on_a_reused_handle_uses_the_uploaded_pair(c_oracle):
         got = my.pm_dispatch(a[0], a[1], g['c1'], g['r1'], g['c2fg'], g['r2fg'], g['border'], 34, 0.0, context=ctx,
                              angles=angles)
         np.testing.assert_array_equal(got[:, :4], exp[:, :4])
+
+
+def test_two_threads_share_the_device_handle_without_mixing_results(c_oracle):
+    """SURVEY.md section 5 "state per call": two threads call pm_dispatch (the shared per-device handle) with two
+    DIFFERENT pairs and point sets at the same time, many times over; every call must return its own pair's
+    results (= the C oracle), never the other thread's.  Without the per-device lock the calls interleave
+    upload_pair / set_points / run on one handle."""
+    import threading
+    cases = []
+    for seed, n_side, angles in ((17, 6, [-3, 0, 3]), (99, 7, list(range(-3, 4)))):
+        img = syn.make_pair(400, 400, seed=seed)
+        g = syn.make_grid(400, 400, n_side, margin=90)
+        exp, _ = c_oracle.pm_batch(img[0], img[1], g['c1'], g['r1'], g['c2fg'], g['r2fg'], g['border'], 34, 0.0, angles,
+                                   rot=my.rotation_table(angles, 0.0, 34), nthreads=4)
+        cases.append((img, g, angles, exp))
+    errors = []
+    start = threading.Barrier(2)
+
+    def worker(k):
+        img, g, angles, exp = cases[k]
+        try:
+            start.wait()
+            for _ in range(25):
+                got = my.pm_dispatch(img[0], img[1], g['c1'], g['r1'], g['c2fg'], g['r2fg'], g['border'], 34, 0.0,
+                                     angles=angles)
+                assert got.shape == exp.shape
+                np.testing.assert_array_equal(got[:, :4], exp[:, :4])
+                np.testing.assert_allclose(got[:, 4], exp[:, 4], rtol=1e-5, atol=1e-5, equal_nan=True)
+        except BaseException as e:                  # noqa: reported by the main thread
+            errors.append((k, e))
+
+    threads = [threading.Thread(target=worker, args=(k,)) for k in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    my.release_contexts()                           # the handles come back on the next call
+    img, g, angles, exp = cases[0]
+    got = my.pm_dispatch(img[0], img[1], g['c1'], g['r1'], g['c2fg'], g['r2fg'], g['border'], 34, 0.0, angles=angles)
+    np.testing.assert_array_equal(got[:, :4], exp[:, :4])

@@ -196,3 +196,13 @@ def test_shortened_normalisation_is_the_specification(pm_ctx, s):
     assert n >= 1 << 27
     assert bad == 0
     assert 0 < slow < n // 20                                          # (the generator over-samples flat windows)
+
+
+@pytest.mark.gpu
+def test_shortened_hypot_is_numpys_float32_hypot(pm_ctx):
+    """ph_hessian_fast takes sqrt(x^2 + y^2) from v_rsq_f64 + Newton steps with a rounding-boundary guard: 2^27
+    pseudo-random float32 pairs (incl. zeros, denormals, huge values, perfect squares) on the device, bit for bit
+    against (float)sqrt((double)x*x + (double)y*y) - what np.hypot does for float32 (pmlib.py:55)."""
+    n, bad = pm_ctx.debug_hypot_selftest(1 << 27, seed=20261002)
+    assert n >= 1 << 27
+    assert bad == 0

@@ -135,3 +135,53 @@ def test_out_of_image_keypoint_raises_like_the_reference_edt():
         my.nearest_keypoint_distance(np.array([10.0]), np.array([-3.0]), [5], [5], shape=(300, 260))
     d = my.nearest_keypoint_distance(np.array([10.9]), np.array([20.2]), [20], [13], shape=(300, 260))
     assert d[0] == 3.0                                              # truncated to pixel (20, 10)
+
+
+def test_shared_handle_is_held_by_one_call_at_a_time(monkeypatch):
+    """The per-device handle carries one call's state (pair, points, results): concurrent pm_dispatch calls must hold
+    it from upload to fetch.  A fake handle records the order of the calls it sees."""
+    import threading
+    import time
+    log = []
+
+    class FakeCtx(object):
+        def __init__(self, device=0):
+            self.tag = None
+
+        def upload_pair(self, img1, img2, slot=0, select=True):
+            self.tag = int(img1[0, 0]); log.append(('upload', self.tag)); time.sleep(0.002)
+
+        def set_points(self, c1, *a, **k):
+            log.append(('set', self.tag)); self.n = len(c1); time.sleep(0.002)
+
+        def run(self):
+            log.append(('run', self.tag)); time.sleep(0.002)
+
+        def fetch(self, want_ij=True):
+            log.append(('fetch', self.tag))
+            return np.full((self.n, 5), float(self.tag))
+
+        def close(self):
+            pass
+
+    my.release_contexts()
+    monkeypatch.setattr(my._capi, 'PMContext', FakeCtx)
+    outs = {}
+
+    def worker(tag):
+        img = np.full((8, 8), tag, dtype=np.uint8)
+        for _ in range(20):
+            out = my.pm_dispatch(img, img, [1.0], [1.0], [1.0], [1.0], [20.0], 34, 0.0)
+            outs.setdefault(tag, []).append(float(out[0, 0]))
+
+    ts = [threading.Thread(target=worker, args=(t,)) for t in (3, 7)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    my.release_contexts()
+    assert all(v == 3.0 for v in outs[3]) and all(v == 7.0 for v in outs[7])
+    assert len(log) == 160
+    for k in range(0, len(log), 4):                       # every call's four steps are contiguous and of one caller
+        steps = log[k:k + 4]
+        assert [s[0] for s in steps] == ['upload', 'set', 'run', 'fetch'] and len({s[1] for s in steps}) == 1

@@ -19,9 +19,12 @@ with _capi.PMContext(0) as ctx:
             d = ctx.debug_point(g['c1'][i], g['r1'][i], g['c2fg'][i], g['r2fg'][i], float(b), 34, 0.0, angles, rot=rot)
             acc.append(np.diff(d['cycles'][:8]))
             c = d['cycles']
+            cy = c
             fine = [c[8] - c[2], c[15] - c[8], c[9] - c[15], c[3] - c[9], c[11] - c[10], c[12] - c[11], c[13] - c[5], c[6] - c[13], c[14] - c[6], c[7] - c[14]]
         acc = np.median(np.array(acc), axis=0)
         print('border %d: total %d cycles' % (b, acc.sum()))
         for n, c in zip(names, acc):
             print('   %-14s %8d  %5.1f %%' % (n, c, 100.0 * c / acc.sum()))
+        f2 = [cy[16] - cy[1], cy[2] - cy[16], cy[17] - cy[13], cy[18] - cy[17], cy[6] - cy[18], cy[19] - cy[6], cy[14] - cy[19], cy[20] - cy[14], cy[21] - cy[20], cy[22] - cy[21], cy[23] - cy[22], cy[24] - cy[23], cy[7] - cy[24]]
+        print('   fine2: wp %d, sums %d | winner item0 mfma %d, norm %d, rest %d | hes compute %d, barrier+dump %d, reduce %d, hist %d, scan %d, compact %d, rank %d, tail %d' % tuple(f2))
         print('   fine: patch+zero %d, sampling(tid0) %d, ones+barrier %d, sums %d | item0 sweep %d, item0 epilogue %d | P4 staging %d, P4 mfma+norm %d | P5 hessian %d, P5 median/std %d' % tuple(fine))
