@@ -18,6 +18,13 @@ touches torch or the GPU (a process that has initialised the GPU is never replac
     (sea_ice_drift_amd/dist.py) - and the weak figure ((200*N)x200 grid, 40 000 points per GPU) is measured
     after it and reported under "weak_scaling"; ``--scaling weak`` makes the weak workload the headline.
 
+--mode ftpm (BASELINE.json configs[3])
+    the public chain on the same pair: SeaIceDrift.get_drift_FT (key-point detector and Hamming matcher on the GPU, the
+    reference's filters on the host) feeding SeaIceDrift.get_drift_PM on the 200x200 grid.  A step = both calls, host
+    arrays in, host grids out (the pair upload included); value = valid grid points / step time; ft_ms / pm_ms, the number
+    of feature-tracking vectors and the share of them within 3 px of the synthetic displacement field are reported, and
+    --check points of the PM result are compared with the C oracle fed with the same FT-derived first guess.
+
 --mode stream (BASELINE.json configs[4])
     a batch of --pairs (16) synthetic 10000x10000 pairs in pinned host memory, dealt round-robin to the ranks;
     every rank streams its pairs through the two device slots of its handle (sid_pm_upload_pair on the copy
@@ -53,7 +60,7 @@ def parse_args(argv=None):
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=None, help='timed steps (default 20; 3 in stream mode)')
     ap.add_argument('--warmup', type=int, default=None, help='untimed steps (default 3; 1 in stream mode)')
-    ap.add_argument('--mode', choices=('grid', 'stream'), default='grid')
+    ap.add_argument('--mode', choices=('grid', 'stream', 'ftpm'), default='grid')
     ap.add_argument('--pairs', type=int, default=16, help='stream mode: pairs in the batch (all ranks together)')
     ap.add_argument('--size', type=int, default=10000, help='image side in pixels')
     ap.add_argument('--grid', type=int, default=200, help='grid points per side')
@@ -73,9 +80,9 @@ def parse_args(argv=None):
                     help='points verified against the oracle after timing when the CPU baseline (which checks the whole grid) is off')
     args = ap.parse_args(argv)
     if args.steps is None:
-        args.steps = 3 if args.mode == 'stream' else 20
+        args.steps = {'stream': 3, 'ftpm': 5}.get(args.mode, 20)
     if args.warmup is None:
-        args.warmup = 1 if args.mode == 'stream' else 3
+        args.warmup = {'stream': 1, 'ftpm': 2}.get(args.mode, 3)
     if args.scaling is None:
         args.scaling = 'strong'
     return args
@@ -488,6 +495,90 @@ def stream_mode(args, torch, dist, dev, world, rank, local_rank):
     return line
 
 
+def ftpm_mode(args, torch, dist, dev, world, rank, local_rank):
+    """BASELINE config 4: feature tracking feeding pattern matching through the public class (one GPU)."""
+    import numpy as np
+    from sea_ice_drift_amd import pmlib as my, synthetic as syn
+    from sea_ice_drift_amd.domain import ArrayNansat
+    from sea_ice_drift_amd.seaicedrift import SeaIceDrift
+    if world != 1:
+        raise SystemExit('--mode ftpm is the one-GPU configuration (BASELINE.json configs[3])')
+    size, grid, s = args.size, args.grid, args.img_size
+    angles = list(range(-args.angles, args.angles + 1))
+    t_gen = time.time()
+    img1, img2 = syn.make_pair(size, size, speckle=0.03)
+    t_gen = time.time() - t_gen
+    scale = 4e-4
+    n1 = ArrayNansat(img1, origin=(10.0, 80.0), matrix=((scale, 0.0), (0.0, -scale)))
+    n2 = ArrayNansat(img2, origin=(10.0, 80.0), matrix=((scale, 0.0), (0.0, -scale)))
+    cg, rg = np.meshgrid(np.rint(np.linspace(100, size - 101, grid)), np.rint(np.linspace(100, size - 101, grid)))
+    lon, lat = n1.transform_points(cg.ravel(), rg.ravel(), 0)
+    lon, lat = lon.reshape(cg.shape), lat.reshape(cg.shape)
+    sid = SeaIceDrift(n1, n2)
+    ft_kw = dict(max_drift=3000.0 * size / 10000.0 + 600.0, nFeatures=100000)
+    pm_kw = dict(img_size=s, angles=angles)
+    t_ft, t_pm = [], []
+    for k in range(args.warmup + args.steps):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        uft, vft, lon1ft, lat1ft, lon2ft, lat2ft = sid.get_drift_FT(**ft_kw)
+        t1 = time.perf_counter()
+        u, v, a, r, h, lon2, lat2 = sid.get_drift_PM(lon, lat, lon1ft, lat1ft, lon2ft, lat2ft, **pm_kw)
+        t2 = time.perf_counter()
+        if k >= args.warmup:
+            t_ft.append(t1 - t0)
+            t_pm.append(t2 - t1)
+    ft_s, pm_s = float(np.mean(t_ft)), float(np.mean(t_pm))
+    ok = np.isfinite(u)
+    # feature-tracking vectors against the synthetic displacement field
+    x1, y1 = n1.transform_points(lon1ft, lat1ft, 1)
+    x2, y2 = n2.transform_points(lon2ft, lat2ft, 1)
+    fdc, fdr = syn.true_displacement(x1, y1)
+    fterr = np.hypot(x2 - x1 - fdc, y2 - y1 - fdr)
+    tdc, tdr = syn.true_displacement(cg, rg)
+    err = np.hypot(u[ok] / scale - tdc[ok], -v[ok] / scale - tdr[ok])
+    line = {
+        'metric': 'PM grid-points/sec (10000x10000 px pair, 34px template)', 'value': float(ok.sum()) / (ft_s + pm_s),
+        'unit': 'grid-points/s', 'n_gpus': 1, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': (ft_s + pm_s) * 1e3,
+        'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None, 'dtype': 'u8', 'data': 'synthetic',
+        'config': {'workload': 'FT+PM end to end through SeaIceDrift.get_drift_FT -> get_drift_PM: %dx%d synthetic uint8 pair (host '
+                               'arrays in, host grids out), %dx%d grid, template %d px, %d angles; first guess and search border from '
+                               'the feature-tracking vectors' % (size, size, grid, grid, s, len(angles)),
+                   'parallelism': 'single GPU, no collective'},
+        'ft_ms': ft_s * 1e3, 'pm_ms': pm_s * 1e3, 'ft_vectors': int(len(uft)),
+        'ft_vectors_within_3px_of_truth': float((fterr < 3.0).mean()) if len(fterr) else 0.0,
+        'valid_grid_points': int(ok.sum()), 'median_abs_drift_error_px': float(np.median(err)) if ok.any() else None,
+        'detector': 'sea_ice_drift_amd.orb (own ORB-family specification behind the reference interface; OpenCV parity unpinned)',
+        'setup_s': {'generate_pair': t_gen},
+    }
+    if args.check > 0:
+        # PM on the FT-derived first guess against the C oracle: the same prelude (first guess, search border, validity
+        # mask) feeds both; compared are a, r (bit-exact), h (1e-5) and the destination lon/lat (bit-exact)
+        from oracle import c_oracle
+        c_oracle.build()
+        xk1, yk1 = n1.transform_points(lon1ft, lat1ft, 1)
+        xk2, yk2 = n2.transform_points(lon2ft, lat2ft, 1)
+        pre = my.pm_prelude(lon, lat, n1, xk1, yk1, n2, xk2, yk2, **pm_kw)
+        gpi = pre['gpi']
+        pos = np.flatnonzero(gpi.ravel())
+        sel = np.sort(np.random.default_rng(3).choice(pos.size, size=min(args.check, pos.size), replace=False))
+        exp, _ = c_oracle.pm_batch(img1, img2, pre['c1pm1i'][gpi][sel], pre['r1pm1i'][gpi][sel], pre['c2fg'][gpi][sel],
+                                   pre['r2fg'][gpi][sel], pre['brd2'][gpi][sel], s, pre['alpha0'], angles,
+                                   rot=my.rotation_table(angles, pre['alpha0'], s), nthreads=host_cores())
+        flat = pos[sel]
+        dci, dri = (pre['c2pm1'] - pre['c2pm1i'])[gpi][sel], (pre['r2pm1'] - pre['r2pm1i'])[gpi][sel]
+        elon, elat = n2.transform_points(exp[:, 0] + dci, exp[:, 1] + dri, 0)
+        same = lambda got, want: bool(np.all((got == want) | (np.isnan(got) & np.isnan(want))))
+        okp = (same(a.ravel()[flat], exp[:, 2]) and same(r.ravel()[flat], exp[:, 3]) and same(lon2.ravel()[flat], elon)
+               and same(lat2.ravel()[flat], elat) and bool(np.allclose(h.ravel()[flat], exp[:, 4], rtol=1e-5, atol=1e-5, equal_nan=True)))
+        line['parity_check'] = {'points': int(len(sel)), 'ok': okp, 'valid_points_total': int(gpi.sum()),
+                                'rule': 'a, r, lon2, lat2 bit-exact, h to 1e-5, against oracle/pm_oracle.c on the FT-derived first guess'}
+        if not okp:
+            print(json.dumps(line))
+            raise SystemExit('PARITY FAILURE against the CPU oracle - the number above is invalid')
+    return line
+
+
 def main(argv=None):
     argv = sys.argv[1:] if argv is None else argv
     args = parse_args(argv)
@@ -516,8 +607,18 @@ def main(argv=None):
         shared = torch.cuda.device_count() < world
         # RCCL cannot put two ranks on one device: the dry run on a smaller box uses gloo for the collectives
         dist.init_process_group('gloo' if shared else 'nccl', **({} if shared else {'device_id': dev}))
-    fn = stream_mode if args.mode == 'stream' else grid_mode
-    line = fn(args, torch, dist, dev, world, rank, local_dev)
+    fn = {'stream': stream_mode, 'ftpm': ftpm_mode}.get(args.mode, grid_mode)
+    # stdout carries ONE JSON line: whatever libraries print there meanwhile (RCCL's version banner at the first
+    # collective, progress lines of host code) is sent to stderr
+    sys.stdout.flush()
+    saved_stdout = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        line = fn(args, torch, dist, dev, world, rank, local_dev)
+    finally:
+        sys.stdout.flush()
+        os.dup2(saved_stdout, 1)
+        os.close(saved_stdout)
     if rank == 0 and line is not None:
         if world > 1 and dist.get_backend() == 'gloo':
             line['config']['parallelism'] += ' [DRY RUN: %d ranks share %d device(s), gloo collectives]' % (

@@ -287,73 +287,95 @@ int classify_points(sid_pm_ctx *ctx)
     const int s = ctx->img_size, K = ctx->n_angles;
     const int64_t rows2 = ctx->cur[1].rows, cols2 = ctx->cur[1].cols;
     const double *c2fg = ctx->h_c2fg.data(), *r2fg = ctx->h_r2fg.data(), *border = ctx->h_border.data();
-    struct P { int idx; int lds; int cls; double work; int band = 4; bool force1 = false, force2 = false; int wh = 0, ww = 0, pitch = 0; };
     static const bool no_band8 = getenv("SID_PM_NO_BAND8") != nullptr;                      // A/B runs
-    const bool rp = ctx->rp;
+    const bool rp = ctx->rp, rpp = ctx->rp_paired;
     const bool band8_ok = sid::mfma_band8_supported(s) && !no_band8 && (rp ? !ctx->rp_paired : !use_paired(K));   // (classic and row-pair kernels alike)
-    std::vector<P> pts((size_t)n);
-    const bool rpp = ctx->rp_paired;
+    // Everything the launch needs to know about a point follows from the SHAPE of its search window, and a run has a few
+    // dozen shapes (one per border): the LDS layouts are evaluated per shape, the points are only binned.
+    struct Shape { int wh, ww, lds, band, cls, nat_pitch, pitch; double work; std::vector<int32_t> idx; };
+    std::vector<Shape> shapes;
+    std::vector<int32_t> slot_of((size_t)1 << 16, -1);                // (wh, ww) -> shape, direct-mapped on a hash of the pair
+    auto find_shape = [&](int wh, int ww) -> int {
+        uint32_t h = ((uint32_t)wh * 2654435761u ^ (uint32_t)ww * 40503u) & 0xffffu;
+        for (;; h = (h + 1) & 0xffffu) {
+            const int k = slot_of[h];
+            if (k < 0) { slot_of[h] = (int32_t)shapes.size(); return -1 - (int)h; }
+            if (shapes[(size_t)k].wh == wh && shapes[(size_t)k].ww == ww) return k;
+        }
+    };
     const int lds_min = lds_need(rp, rpp, s + 1, s + 1, s, K);
+    {   // shape 0: points whose window does not lie inside image 2 (they write NaN at once; minimal footprint)
+        Shape z{0, 0, lds_min, 4, std::min(8, blocks_per_cu(lds_min)), 0, 0, 0.0, {}};
+        shapes.push_back(z);
+    }
     double macs = 0, bytes = 0, valid = 0;
-    int lds_max = 0;
+    int lds_max = lds_min;
     for (int64_t i = 0; i < n; ++i) {
         int wh = 0, ww = 0;
-        P p; p.idx = (int)i; p.lds = lds_min; p.cls = 0; p.work = 0.0;
-        if (window_dims(c2fg[i], r2fg[i], border[i], s, rows2, cols2, wh, ww)) {
+        if (!window_dims(c2fg[i], r2fg[i], border[i], s, rows2, cols2, wh, ww)) { shapes[0].idx.push_back((int32_t)i); continue; }
+        int k = find_shape(wh, ww);
+        if (k < 0) {
+            Shape sh{wh, ww, 0, 4, 0, 0, 0, 0.0, {}};
             const int need = lds_need(rp, rpp, wh, ww, s, K);
             if (need > sid::max_lds_bytes())
                 return fail(SID_PM_ERR_UNSUPPORTED, "point %lld: search window %dx%d needs %d bytes of LDS (> %d)",
                             (long long)i, wh, ww, need, sid::max_lds_bytes());
-            p.lds = need;
+            sh.lds = need;
+            bool force1 = false, force2 = false;
             // the two-per-CU class runs the 8-row-band kernel (two wavefronts per SIMD leave it 256 VGPRs); its
             // window carries a few more zero rows, and a point that then no longer fits twice joins the one-per-CU
             // class (a launch of their own for the few points in between costs more than it saves)
             if (band8_ok && blocks_per_cu(need) == 2) {
                 const int need8 = lds_need(rp, rpp, wh, ww, s, K, 8);
-                if (blocks_per_cu(need8) >= 2) { p.lds = need8; p.band = 8; p.force2 = true; }
-                else p.force1 = true;
+                if (blocks_per_cu(need8) >= 2) { sh.lds = need8; sh.band = 8; force2 = true; }
+                else force1 = true;
             }
-            p.wh = wh; p.ww = ww;
-            const double rh = wh - s + 1, rw = ww - s + 1;
-            p.work = rh * rw;
-            macs += (double)K * rh * rw * s * s;
-            // window + bounding box of the rotated template + 5 inputs + outputs
-            bytes += (double)wh * ww + 51.0 * 51.0 + 40.0 + 52.0;
-            valid += 1;
+            sh.cls = force1 ? 1 : (force2 ? 2 : std::min(8, blocks_per_cu(sh.lds)));
+            sh.work = (double)(wh - s + 1) * (double)(ww - s + 1);
+            if (rp) sh.nat_pitch = sid::rp_lds_layout(wh, ww, s, K <= sid::kRpGroup, rpp ? 8 : sh.band).wpitch;
+            k = (int)shapes.size();
+            shapes.push_back(sh);
         }
-        p.cls = p.force1 ? 1 : (p.force2 ? 2 : std::min(8, blocks_per_cu(p.lds)));
-        lds_max = std::max(lds_max, p.lds);
-        pts[(size_t)i] = p;
+        Shape &sh = shapes[(size_t)k];
+        sh.idx.push_back((int32_t)i);
+        macs += (double)K * sh.work * s * s;
+        // window + bounding box of the rotated template + 5 inputs + outputs
+        bytes += (double)wh * ww + 51.0 * 51.0 + 40.0 + 52.0;
+        valid += 1;
     }
-    std::sort(pts.begin(), pts.end(), [](const P &a, const P &b) {
-        if (a.cls != b.cls) return a.cls < b.cls;                 // biggest footprints first
-        if (a.band != b.band) return a.band < b.band;             // one launch per (class, band)
-        if (a.work != b.work) return a.work > b.work;             // then longest first
-        return a.idx < b.idx;
+    // launch order of the shapes: biggest footprints (fewest workgroups per CU) first, one launch per (class, band), longest first
+    std::vector<int> ord;
+    for (size_t k = 0; k < shapes.size(); ++k) if (!shapes[k].idx.empty()) ord.push_back((int)k);
+    std::sort(ord.begin(), ord.end(), [&](int a, int b) {
+        const Shape &x = shapes[(size_t)a], &y = shapes[(size_t)b];
+        if (x.cls != y.cls) return x.cls < y.cls;
+        if (x.band != y.band) return x.band < y.band;
+        if (x.work != y.work) return x.work > y.work;
+        return x.idx[0] < y.idx[0];
     });
     // Row-pair kernel: one window pitch per launch, a compile-time constant of the kernel instantiation (every LDS offset of
     // the sweep's and the winner's fragment loops is then an immediate).  The pitch of a launch = the smallest instantiated
-    // pitch that holds the natural pitch of all of its points; points whose footprint with that pitch no longer fits their
-    // residency class keep the run-time pitch for the whole launch (SID_PM_NO_FIXED_PITCH=1: always; A/B runs).
+    // pitch that holds the natural pitch of all of its points; if a footprint with that pitch no longer fits its residency
+    // class, the whole launch keeps the run-time pitch (SID_PM_NO_FIXED_PITCH=1: always; A/B runs).
     static const bool no_fixed_pitch = getenv("SID_PM_NO_FIXED_PITCH") != nullptr;
     if (rp && !no_fixed_pitch) {
-        for (size_t a = 0; a < pts.size();) {
+        for (size_t a = 0; a < ord.size();) {
             size_t b = a + 1;
-            while (b < pts.size() && pts[b].cls == pts[a].cls && pts[b].band == pts[a].band) ++b;
+            const Shape &first = shapes[(size_t)ord[a]];
+            while (b < ord.size() && shapes[(size_t)ord[b]].cls == first.cls && shapes[(size_t)ord[b]].band == first.band) ++b;
             int nat = 0;
-            for (size_t i = a; i < b; ++i)
-                if (pts[i].wh > 0) nat = std::max(nat, sid::rp_lds_layout(pts[i].wh, pts[i].ww, s, K <= sid::kRpGroup, rpp ? 8 : pts[i].band).wpitch);
+            for (size_t i = a; i < b; ++i) nat = std::max(nat, shapes[(size_t)ord[i]].nat_pitch);
             int pitch = nat > 0 ? sid::rp_class_pitch(nat) : 0;
-            if (pitch && !sid::rp_pitch_instantiated(pts[a].band, rpp, pitch)) pitch = 0;
-            if (pitch) {
-                const int per_cu = pts[a].cls;                     // workgroups per CU the class was formed for
-                for (size_t i = a; i < b && pitch; ++i)
-                    if (pts[i].wh > 0 && std::min(8, blocks_per_cu(lds_need(rp, rpp, pts[i].wh, pts[i].ww, s, K, pts[i].band, pitch))) < per_cu) pitch = 0;
+            if (pitch && !sid::rp_pitch_instantiated(first.band, rpp, pitch)) pitch = 0;
+            for (size_t i = a; i < b && pitch; ++i) {
+                const Shape &sh = shapes[(size_t)ord[i]];
+                if (sh.wh > 0 && std::min(8, blocks_per_cu(lds_need(rp, rpp, sh.wh, sh.ww, s, K, sh.band, pitch))) < first.cls) pitch = 0;
             }
             if (pitch)
                 for (size_t i = a; i < b; ++i) {
-                    pts[i].pitch = pitch;
-                    if (pts[i].wh > 0) pts[i].lds = lds_need(rp, rpp, pts[i].wh, pts[i].ww, s, K, pts[i].band, pitch);
+                    Shape &sh = shapes[(size_t)ord[i]];
+                    sh.pitch = pitch;
+                    if (sh.wh > 0) sh.lds = lds_need(rp, rpp, sh.wh, sh.ww, s, K, sh.band, pitch);
                 }
             a = b;
         }
@@ -364,35 +386,43 @@ int classify_points(sid_pm_ctx *ctx)
     // (start + c) mod 8: neighbouring points - whose search windows overlap - meet in the same L2.
     // Runs keep their place in the launch (long first), so the load balance across XCDs is unchanged.
     static const bool no_xcd = getenv("SID_PM_NO_XCD_ORDER") != nullptr;                         // A/B runs
-    if (!no_xcd) {
-        constexpr int kXcd = 8;
-        std::vector<P> tmp;
-        for (int64_t a = 0; a < n;) {
-            int64_t b = a + 1;
-            while (b < n && pts[(size_t)b].cls == pts[(size_t)a].cls && pts[(size_t)b].band == pts[(size_t)a].band &&
-                   pts[(size_t)b].work == pts[(size_t)a].work) ++b;
-            const int64_t L = b - a, m = (L + kXcd - 1) / kXcd;
-            if (L >= 4 * kXcd) {
-                tmp.assign(pts.begin() + a, pts.begin() + b);
-                int64_t w = a;
-                for (int64_t p = 0; p < m; ++p)                       // slot t = p * 8 + c takes element c * m + p
-                    for (int c = 0; c < kXcd; ++c) {
-                        const int64_t e = (int64_t)c * m + p;
-                        if (e < L) pts[(size_t)w++] = tmp[(size_t)e];
-                    }
-            }
-            a = b;
-        }
-    }
-    std::vector<int32_t> order((size_t)n);
+    std::vector<int32_t> order;
+    order.reserve((size_t)n);
     ctx->buckets.clear();
-    for (int64_t i = 0; i < n; ++i) {
-        order[(size_t)i] = pts[(size_t)i].idx;
-        if (ctx->buckets.empty() || pts[(size_t)i].cls != pts[(size_t)(i - 1)].cls || pts[(size_t)i].band != pts[(size_t)(i - 1)].band)
-            ctx->buckets.push_back(Bucket{(int)i, 0, 0, pts[(size_t)i].band, pts[(size_t)i].pitch});
-        Bucket &b = ctx->buckets.back();
-        b.count += 1;
-        b.lds = std::max(b.lds, pts[(size_t)i].lds);
+    std::vector<int32_t> run;
+    for (size_t a = 0; a < ord.size();) {
+        // a run = the shapes of equal (class, band, work): their points in the caller's order
+        size_t b = a + 1;
+        const Shape &first = shapes[(size_t)ord[a]];
+        while (b < ord.size() && shapes[(size_t)ord[b]].cls == first.cls && shapes[(size_t)ord[b]].band == first.band &&
+               shapes[(size_t)ord[b]].work == first.work) ++b;
+        const std::vector<int32_t> *src = &first.idx;
+        if (b - a > 1) {
+            run.clear();
+            for (size_t i = a; i < b; ++i) run.insert(run.end(), shapes[(size_t)ord[i]].idx.begin(), shapes[(size_t)ord[i]].idx.end());
+            std::sort(run.begin(), run.end());
+            src = &run;
+        }
+        int lds_run = 0;
+        for (size_t i = a; i < b; ++i) lds_run = std::max(lds_run, shapes[(size_t)ord[i]].lds);
+        lds_max = std::max(lds_max, lds_run);
+        if (ctx->buckets.empty() || ctx->buckets.back().band != first.band || ctx->buckets.back().pitch != first.pitch ||
+            ctx->info[5] != (double)first.cls)
+            ctx->buckets.push_back(Bucket{(int)order.size(), 0, 0, first.band, first.pitch});
+        ctx->info[5] = (double)first.cls;                             // (class of the bucket being filled)
+        Bucket &bk = ctx->buckets.back();
+        bk.count += (int)src->size();
+        bk.lds = std::max(bk.lds, lds_run);
+        constexpr int64_t kXcd = 8;
+        const int64_t L = (int64_t)src->size(), m = (L + kXcd - 1) / kXcd;
+        if (!no_xcd && L >= 4 * kXcd) {
+            for (int64_t p = 0; p < m; ++p)                           // slot t = p * 8 + c takes element c * m + p
+                for (int64_t c = 0; c < kXcd; ++c) {
+                    const int64_t e = c * m + p;
+                    if (e < L) order.push_back((*src)[(size_t)e]);
+                }
+        } else order.insert(order.end(), src->begin(), src->end());
+        a = b;
     }
     if (n > 0) {
         HIP_TRY(hipMemcpyAsync(ctx->d_order, order.data(), sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));

@@ -103,6 +103,17 @@ def test_rccl_code_path_runs_on_one_gpu():
     assert d['parity_check']['ok'] and d['config']['points_total'] == 3600
 
 
+def test_config4_ft_feeding_pm_on_the_full_size_pair():
+    """BASELINE config 4 (ftlib.py:236-281 feeding seaicedrift.py:62-88): get_drift_FT with the GPU detector and matcher ->
+    get_drift_PM on the 10000x10000 pair.  >= 99 % of the feature-tracking vectors lie within 3 px of the synthetic
+    displacement field, and the PM result on the FT-derived first guess equals the C oracle on a 400-point subsample."""
+    d = run_bench('--mode', 'ftpm', '--steps', '2', '--warmup', '1', '--check', '400', timeout=2400)
+    assert d['ft_vectors'] > 10000 and d['ft_vectors_within_3px_of_truth'] >= 0.99
+    assert d['parity_check']['ok'] and d['parity_check']['points'] == 400
+    assert d['valid_grid_points'] > 35000 and d['median_abs_drift_error_px'] < 4.0
+    assert d['ft_ms'] > 0 and d['pm_ms'] > 0 and d['value'] > 0
+
+
 def test_config5_stream_16_pairs_full_size():
     """16 pairs of 10000x10000 px streamed through the two device slots; 3 pairs checked against the oracle."""
     d = run_bench('--mode', 'stream', '--pairs', '16', '--steps', '1', '--warmup', '1', '--check', '32', timeout=2400)
