@@ -15,9 +15,12 @@
  * Arithmetic of the interpolation: per simplex the 2x2 system of the barycentric transform is solved by LU with
  * partial pivoting, c = Tinv (x - r), c2 = 1 - c0 - c1, value = c0 v0 + c1 v1 + c2 v2 accumulated in vertex order
  * (scipy.spatial.Delaunay.transform / LinearNDInterpolator); a point belongs to the first simplex (lowest index)
- * with all c >= -eps, eps = 100 * DBL_EPSILON.  SciPy reaches a simplex by a directed walk and its BLAS may round
- * the 2x2 solve differently, so values can differ from SciPy's in the last bits (<= 1e-12 relative; the reference
- * rounds them to integer pixels next, pmlib.py:285-288).
+ * with all c >= -eps, eps = 100 * DBL_EPSILON.  SciPy reaches a simplex by a directed walk, so for a query ON an edge,
+ * a vertex or the hull it may pick another simplex (or none); and its BLAS may round the 2x2 solve differently in the
+ * last bit.  Neither may change what the reference computes next (np.round of the first guess, pmlib.py:285-288), so
+ * every query for which that cannot be excluded is FLAGGED in doubt[] - smallest barycentric coordinate within 1e-9 of
+ * zero in some simplex, or a value within 1e-6 of a half-integer - and the caller evaluates those with SciPy itself
+ * (sea_ice_drift_amd/lib.py interpolation_near).  Every unflagged query lies strictly inside exactly one simplex.
  * Host buffers in / host buffers out; 0 on success, a negative SID_PM_ERR_* code otherwise (sid_pm.h).
  */
 #ifndef SID_FG_H
@@ -29,9 +32,10 @@
 extern "C" {
 #endif
 
-/* pts [n_pts][2], simplices [n_simp][3] (indices into pts), values [n_pts][2], q [n_q][2] -> out [n_q][2] */
+/* pts [n_pts][2], simplices [n_simp][3] (indices into pts), values [n_pts][2], q [n_q][2] -> out [n_q][2];
+ * optional (may be NULL): simplex [n_q] = index of the simplex a query was located in (-1: none), doubt [n_q] (above) */
 int sid_fg_interp_linear(int device, const double *pts, int64_t n_pts, const int32_t *simplices, int64_t n_simp,
-                         const double *values, const double *q, int64_t n_q, double *out);
+                         const double *values, const double *q, int64_t n_q, double *out, int32_t *simplex, int32_t *doubt);
 
 /* seeds [n_seeds][2], q [n_q][2] -> dist [n_q] = min over seeds of the Euclidean distance */
 int sid_fg_nearest_dist(int device, const double *seeds, int64_t n_seeds, const double *q, int64_t n_q, double *dist);

@@ -119,7 +119,7 @@ def lib():
     L.sid_orb_detect.argtypes = [C.c_int, _u8p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.POINTER(C.c_int8), _i32p,
                                  _f32p, _i32p, C.POINTER(C.c_int64), _u8p, C.c_int64, C.POINTER(C.c_int64)]
     L.sid_orb_last_error.restype = C.c_char_p
-    L.sid_fg_interp_linear.argtypes = [C.c_int, _f64p, C.c_int64, _i32p, C.c_int64, _f64p, _f64p, C.c_int64, _f64p]
+    L.sid_fg_interp_linear.argtypes = [C.c_int, _f64p, C.c_int64, _i32p, C.c_int64, _f64p, _f64p, C.c_int64, _f64p, _i32p, _i32p]
     L.sid_fg_nearest_dist.argtypes = [C.c_int, _f64p, C.c_int64, _f64p, C.c_int64, _f64p]
     L.sid_fg_last_error.restype = C.c_char_p
     for name in SYMBOLS:
@@ -446,18 +446,22 @@ def stage_scale_u8(ptr, rows, cols, stride, vmin, denom, out_ptr, out_stride, st
                                           C.c_void_p(int(out_ptr)), out_stride, C.c_void_p(int(stream))))
 
 
-def fg_interp_linear(pts, simplices, values, q, device=0):
+def fg_interp_linear(pts, simplices, values, q, device=0, details=False):
     """Piecewise-linear interpolation of two value columns at the points q in a given triangulation
-    (include/sid_fg.h sid_fg_interp_linear): pts [n,2], simplices [m,3], values [n,2], q [k,2] -> [k,2] (NaN outside)."""
+    (include/sid_fg.h sid_fg_interp_linear): pts [n,2], simplices [m,3], values [n,2], q [k,2] -> [k,2] (NaN outside).
+    details=True: also the simplex index per query (-1: none) and the doubt flags (queries on an edge, a vertex, the hull,
+    or with a value next to a half-integer: to be evaluated with SciPy by the caller)."""
     pts, values, q = _f64(pts), _f64(values), _f64(q)
     simp = np.ascontiguousarray(simplices, dtype=np.int32)
     out = np.empty((len(q), 2), dtype=np.float64)
+    sx = np.empty(len(q), dtype=np.int32)
+    dbt = np.empty(len(q), dtype=np.int32)
     L = lib()
     rc = L.sid_fg_interp_linear(int(device), _p(pts, _f64p), len(pts), simp.ctypes.data_as(_i32p), len(simp), _p(values, _f64p),
-                                _p(q, _f64p), len(q), _p(out, _f64p))
+                                _p(q, _f64p), len(q), _p(out, _f64p), sx.ctypes.data_as(_i32p), dbt.ctypes.data_as(_i32p))
     if rc != 0:
         raise SidPmError(rc, L.sid_fg_last_error().decode())
-    return out
+    return (out, sx, dbt.astype(bool)) if details else out
 
 
 def fg_nearest_dist(seeds, q, device=0):

@@ -8,6 +8,7 @@
 #include <stdarg.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <mutex>
 
 #include "../../include/sid_fg.h"
 #include "../../include/sid_pm.h"
@@ -59,14 +60,19 @@ __global__ void k_transform(const double *pts, const int32_t *simp, int64_t ns, 
 // would have found.  Chunking the simplices puts ~8x more wavefronts on the device than one thread per query alone
 // (40 000 queries are only 625 wavefronts).
 constexpr int kTile = 256;
-__global__ __launch_bounds__(256) void k_locate(const Simp *simp, int64_t ns, int64_t chunk, const double *q, int64_t nq, int32_t *loc)
+// kTol: a query whose smallest barycentric coordinate in some simplex lies in [-kTol, kTol) sits on (or within rounding
+// of) an edge, a vertex or the hull: which simplex - or whether any - SciPy's directed walk assigns to it cannot be told
+// from here.  Such queries are FLAGGED (near[]: unlocated ones, here; located ones in k_eval) and the caller evaluates
+// them with SciPy itself; every other query lies strictly inside exactly one simplex.
+constexpr double kTol = 1e-9;
+__global__ __launch_bounds__(256) void k_locate(const Simp *simp, int64_t ns, int64_t chunk, const double *q, int64_t nq, int32_t *loc, int32_t *near)
 {
     __shared__ Simp tile[kTile];
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const double x = i < nq ? q[2 * i] : 0.0, y = i < nq ? q[2 * i + 1] : 0.0;
     const double eps = 100.0 * DBL_EPSILON;
     const int64_t k0 = (int64_t)blockIdx.y * chunk, k1 = k0 + chunk < ns ? k0 + chunk : ns;
-    bool found = false;
+    bool found = false, close = false;
     for (int64_t base = k0; base < k1; base += kTile) {
         __syncthreads();
         if (base + (int64_t)threadIdx.x < k1) tile[threadIdx.x] = simp[base + threadIdx.x];
@@ -78,18 +84,25 @@ __global__ __launch_bounds__(256) void k_locate(const Simp *simp, int64_t ns, in
                 const double dx = x - s.rx, dy = y - s.ry;
                 const double c0 = s.t00 * dx + s.t01 * dy, c1 = s.t10 * dx + s.t11 * dy;
                 const double c2 = 1.0 - c0 - c1;
-                if (s.ok && c0 >= -eps && c1 >= -eps && c2 >= -eps) { atomicMin(&loc[i], (int32_t)(base + k)); found = true; break; }
+                const double mc = fmin(c0, fmin(c1, c2));
+                if (s.ok && mc >= -eps) { atomicMin(&loc[i], (int32_t)(base + k)); found = true; break; }
+                close = close || (s.ok && mc >= -kTol);
             }
         }
     }
+    if (i < nq && !found && close) atomicOr(&near[i], 1);               // (ignored by k_eval when another chunk located the query)
 }
 
-__global__ void k_eval(const Simp *simp, const int32_t *loc, const double *values, const double *q, int64_t nq, double *out)
+// doubt[i] = 1: the caller must not trust out[i] / simplex[i] (see kTol); also set when a value comes within 1e-6 of a
+// half-integer (the reference rounds the first guess next, pmlib.py:285-288: a last-bit difference could tip it)
+__global__ void k_eval(const Simp *simp, const int32_t *loc, const int32_t *near, const double *values, const double *q, int64_t nq,
+                       double *out, int32_t *simplex, int32_t *doubt)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nq) return;
     double o0 = NAN, o1 = NAN;
     const int32_t k = loc[i];
+    int32_t dbt = (k == 0x7f7f7f7f) ? near[i] : 0;
     if (k != 0x7f7f7f7f) {
         const Simp s = simp[k];
         const double dx = q[2 * i] - s.rx, dy = q[2 * i + 1] - s.ry;
@@ -98,8 +111,12 @@ __global__ void k_eval(const Simp *simp, const int32_t *loc, const double *value
         const double *v0 = values + 2 * (int64_t)s.v0, *v1 = values + 2 * (int64_t)s.v1, *v2 = values + 2 * (int64_t)s.v2;
         o0 = c0 * v0[0]; o0 += c1 * v1[0]; o0 += c2 * v2[0];
         o1 = c0 * v0[1]; o1 += c1 * v1[1]; o1 += c2 * v2[1];
+        const double h0 = fabs(o0 - floor(o0) - 0.5), h1 = fabs(o1 - floor(o1) - 0.5);
+        dbt = (fmin(c0, fmin(c1, c2)) < kTol || h0 < 1e-6 || h1 < 1e-6 || !(fabs(o0) < 1e15) || !(fabs(o1) < 1e15)) ? 1 : 0;
     }
     out[2 * i] = o0; out[2 * i + 1] = o1;
+    if (simplex) simplex[i] = k == 0x7f7f7f7f ? -1 : k;
+    if (doubt) doubt[i] = dbt;
 }
 
 __global__ __launch_bounds__(256) void k_nearest(const double *seeds, int64_t ns, const double *q, int64_t nq, double *dist)
@@ -124,6 +141,34 @@ __global__ __launch_bounds__(256) void k_nearest(const double *seeds, int64_t ns
 
 #define HIP_TRY(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { rc = fail(SID_PM_ERR_HIP, "%s: %s", #x, hipGetErrorString(e_)); goto done; } } while (0)
 
+// Device scratch of the two entry points: one grow-only block per device, carved per call (no hipMalloc / hipFree per
+// call - seven and three of them cost about as much as the kernels).  Calls are serialised by the pool's mutex.
+struct Pool { unsigned char *p = nullptr; size_t cap = 0; };
+std::mutex g_pool_mu;
+Pool g_pool[16];
+
+struct Carver {
+    unsigned char *base; size_t off = 0;
+    explicit Carver(unsigned char *b) : base(b) {}
+    template <typename T> T *take(size_t n) { T *r = reinterpret_cast<T *>(base + off); off += (n * sizeof(T) + 255) / 256 * 256; return r; }
+};
+
+int pool_reserve(int device, size_t bytes, unsigned char **out)
+{
+    if (device < 0 || device >= 16) return fail(SID_PM_ERR_ARG, "device index out of range");
+    Pool &pl = g_pool[device];
+    if (pl.cap < bytes) {
+        if (pl.p) (void)hipFree(pl.p);
+        pl.p = nullptr; pl.cap = 0;
+        const size_t want = bytes + bytes / 4;
+        hipError_t e = hipMalloc(reinterpret_cast<void **>(&pl.p), want);
+        if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? SID_PM_ERR_NOMEM : SID_PM_ERR_HIP, "hipMalloc(%zu): %s", want, hipGetErrorString(e));
+        pl.cap = want;
+    }
+    *out = pl.p;
+    return SID_PM_OK;
+}
+
 int pick_device(int device, int &prev)
 {
     int n = 0;
@@ -137,25 +182,30 @@ int pick_device(int device, int &prev)
 SID_EXPORT const char *sid_fg_last_error(void) { return g_err; }
 
 SID_EXPORT int sid_fg_interp_linear(int device, const double *pts, int64_t n_pts, const int32_t *simplices, int64_t n_simp,
-                                    const double *values, const double *q, int64_t n_q, double *out)
+                                    const double *values, const double *q, int64_t n_q, double *out, int32_t *simplex, int32_t *doubt)
 {
     if (n_q == 0) return SID_PM_OK;
     if (!pts || !simplices || !values || !q || !out || n_pts < 3 || n_simp < 1 || n_q < 0 || n_simp >= 0x7f7f7f7f) return fail(SID_PM_ERR_ARG, "bad argument");
     int prev = 0;
     if (int rc0 = pick_device(device, prev)) return rc0;
     int rc = SID_PM_OK;
-    double *d_pts = nullptr, *d_val = nullptr, *d_q = nullptr, *d_out = nullptr; int32_t *d_simp = nullptr, *d_loc = nullptr; Simp *d_t = nullptr;
-    HIP_TRY(hipMalloc(&d_pts, sizeof(double) * 2 * n_pts));
-    HIP_TRY(hipMalloc(&d_val, sizeof(double) * 2 * n_pts));
-    HIP_TRY(hipMalloc(&d_q, sizeof(double) * 2 * n_q));
-    HIP_TRY(hipMalloc(&d_out, sizeof(double) * 2 * n_q));
-    HIP_TRY(hipMalloc(&d_simp, sizeof(int32_t) * 3 * n_simp));
-    HIP_TRY(hipMalloc(&d_t, sizeof(Simp) * n_simp));
-    HIP_TRY(hipMalloc(&d_loc, sizeof(int32_t) * n_q));
-    HIP_TRY(hipMemcpy(d_pts, pts, sizeof(double) * 2 * n_pts, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(d_val, values, sizeof(double) * 2 * n_pts, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(d_q, q, sizeof(double) * 2 * n_q, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(d_simp, simplices, sizeof(int32_t) * 3 * n_simp, hipMemcpyHostToDevice));
+    std::lock_guard<std::mutex> lock(g_pool_mu);
+    auto up = [](size_t b) { return (b + 255) / 256 * 256; };
+    const size_t need = up(sizeof(double) * 2 * n_pts) * 2 + up(sizeof(double) * 2 * n_q) * 2 + up(sizeof(int32_t) * 3 * n_simp) +
+                        up(sizeof(Simp) * n_simp) + up(sizeof(int32_t) * n_q) * 4;
+    unsigned char *blk = nullptr;
+    double *d_pts = nullptr, *d_val = nullptr, *d_q = nullptr, *d_out = nullptr; int32_t *d_simp = nullptr, *d_loc = nullptr, *d_near = nullptr, *d_sx = nullptr, *d_dbt = nullptr; Simp *d_t = nullptr;
+    if ((rc = pool_reserve(device, need, &blk))) { (void)hipSetDevice(prev); return rc; }
+    {
+        Carver cv(blk);
+        d_pts = cv.take<double>(2 * n_pts); d_val = cv.take<double>(2 * n_pts); d_q = cv.take<double>(2 * n_q); d_out = cv.take<double>(2 * n_q);
+        d_simp = cv.take<int32_t>(3 * n_simp); d_t = cv.take<Simp>(n_simp); d_loc = cv.take<int32_t>(n_q);
+        d_near = cv.take<int32_t>(n_q); d_sx = cv.take<int32_t>(n_q); d_dbt = cv.take<int32_t>(n_q);
+    }
+    HIP_TRY(hipMemcpyAsync(d_pts, pts, sizeof(double) * 2 * n_pts, hipMemcpyHostToDevice, 0));
+    HIP_TRY(hipMemcpyAsync(d_val, values, sizeof(double) * 2 * n_pts, hipMemcpyHostToDevice, 0));
+    HIP_TRY(hipMemcpyAsync(d_q, q, sizeof(double) * 2 * n_q, hipMemcpyHostToDevice, 0));
+    HIP_TRY(hipMemcpyAsync(d_simp, simplices, sizeof(int32_t) * 3 * n_simp, hipMemcpyHostToDevice, 0));
     hipLaunchKernelGGL(k_transform, dim3((unsigned)((n_simp + 255) / 256)), dim3(256), 0, 0, d_pts, d_simp, n_simp, d_t);
     {
         const unsigned qb = (unsigned)((n_q + 255) / 256);
@@ -164,14 +214,17 @@ SID_EXPORT int sid_fg_interp_linear(int device, const double *pts, int64_t n_pts
         if ((int64_t)ychunks > tiles) ychunks = (unsigned)tiles;
         const int64_t chunk = ((tiles + ychunks - 1) / ychunks) * kTile;
         ychunks = (unsigned)((n_simp + chunk - 1) / chunk);
-        HIP_TRY(hipMemset(d_loc, 0x7f, sizeof(int32_t) * n_q));                         // 0x7f7f7f7f: above any index
-        hipLaunchKernelGGL(k_locate, dim3(qb, ychunks), dim3(256), 0, 0, d_t, n_simp, chunk, d_q, n_q, d_loc);
-        hipLaunchKernelGGL(k_eval, dim3(qb), dim3(256), 0, 0, d_t, d_loc, d_val, d_q, n_q, d_out);
+        HIP_TRY(hipMemsetAsync(d_loc, 0x7f, sizeof(int32_t) * n_q, 0));                 // 0x7f7f7f7f: above any index
+        HIP_TRY(hipMemsetAsync(d_near, 0, sizeof(int32_t) * n_q, 0));
+        hipLaunchKernelGGL(k_locate, dim3(qb, ychunks), dim3(256), 0, 0, d_t, n_simp, chunk, d_q, n_q, d_loc, d_near);
+        hipLaunchKernelGGL(k_eval, dim3(qb), dim3(256), 0, 0, d_t, d_loc, d_near, d_val, d_q, n_q, d_out, d_sx, d_dbt);
     }
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpy(out, d_out, sizeof(double) * 2 * n_q, hipMemcpyDeviceToHost));
+    if (simplex) HIP_TRY(hipMemcpyAsync(simplex, d_sx, sizeof(int32_t) * n_q, hipMemcpyDeviceToHost, 0));
+    if (doubt) HIP_TRY(hipMemcpyAsync(doubt, d_dbt, sizeof(int32_t) * n_q, hipMemcpyDeviceToHost, 0));
+    HIP_TRY(hipMemcpy(out, d_out, sizeof(double) * 2 * n_q, hipMemcpyDeviceToHost));    // (synchronous: the host arrays are the caller's)
+    HIP_TRY(hipStreamSynchronize(0));
 done:
-    (void)hipFree(d_pts); (void)hipFree(d_val); (void)hipFree(d_q); (void)hipFree(d_out); (void)hipFree(d_simp); (void)hipFree(d_t); (void)hipFree(d_loc);
     (void)hipSetDevice(prev);
     return rc;
 }
@@ -183,17 +236,21 @@ SID_EXPORT int sid_fg_nearest_dist(int device, const double *seeds, int64_t n_se
     int prev = 0;
     if (int rc0 = pick_device(device, prev)) return rc0;
     int rc = SID_PM_OK;
+    std::lock_guard<std::mutex> lock(g_pool_mu);
+    auto up = [](size_t b) { return (b + 255) / 256 * 256; };
+    unsigned char *blk = nullptr;
     double *d_s = nullptr, *d_q = nullptr, *d_d = nullptr;
-    HIP_TRY(hipMalloc(&d_s, sizeof(double) * 2 * n_seeds));
-    HIP_TRY(hipMalloc(&d_q, sizeof(double) * 2 * n_q));
-    HIP_TRY(hipMalloc(&d_d, sizeof(double) * n_q));
-    HIP_TRY(hipMemcpy(d_s, seeds, sizeof(double) * 2 * n_seeds, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(d_q, q, sizeof(double) * 2 * n_q, hipMemcpyHostToDevice));
+    if ((rc = pool_reserve(device, up(sizeof(double) * 2 * n_seeds) + up(sizeof(double) * 2 * n_q) + up(sizeof(double) * n_q), &blk))) { (void)hipSetDevice(prev); return rc; }
+    {
+        Carver cv(blk);
+        d_s = cv.take<double>(2 * n_seeds); d_q = cv.take<double>(2 * n_q); d_d = cv.take<double>(n_q);
+    }
+    HIP_TRY(hipMemcpyAsync(d_s, seeds, sizeof(double) * 2 * n_seeds, hipMemcpyHostToDevice, 0));
+    HIP_TRY(hipMemcpyAsync(d_q, q, sizeof(double) * 2 * n_q, hipMemcpyHostToDevice, 0));
     hipLaunchKernelGGL(k_nearest, dim3((unsigned)((n_q + 255) / 256)), dim3(256), 0, 0, d_s, n_seeds, d_q, n_q, d_d);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpy(dist, d_d, sizeof(double) * n_q, hipMemcpyDeviceToHost));
 done:
-    (void)hipFree(d_s); (void)hipFree(d_q); (void)hipFree(d_d);
     (void)hipSetDevice(prev);
     return rc;
 }

@@ -161,6 +161,14 @@ struct sid_stage_ws {
 
 namespace {
 
+// the workspace's buffers (and the images handed to it) live on ws->device: every entry point runs there, whatever the
+// calling thread's current device is, and puts the previous device back
+struct DeviceGuard {
+    int prev = -1;
+    explicit DeviceGuard(int dev) { (void)hipGetDevice(&prev); if (prev != dev) (void)hipSetDevice(dev); else prev = -1; }
+    ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+
 int run_hist(sid_stage_ws *ws, const HistStates &S, uint32_t mask, int shift, int nbins, bool agg)
 {
     hipStream_t st = ws->stream;
@@ -208,6 +216,7 @@ SID_EXPORT int sid_stage_create(int device, sid_stage_ws **out)
 SID_EXPORT void sid_stage_destroy(sid_stage_ws *ws)
 {
     if (!ws) return;
+    DeviceGuard guard(ws->device);
     (void)hipFree(ws->d_hist);
     if (ws->h_hist) (void)hipHostFree(ws->h_hist);
     delete ws;
@@ -219,6 +228,12 @@ SID_EXPORT int sid_stage_begin(sid_stage_ws *ws, const float *d_img, int64_t row
     if (!ws) return fail(SID_PM_ERR_ARG, "null workspace");
     if (int rc = check_img(d_img, rows, cols, stride)) return rc;
     if (!n_valid) return fail(SID_PM_ERR_ARG, "null output");
+    DeviceGuard guard(ws->device);
+    {   // an image on another device than the workspace's is a caller error, not something to launch on
+        hipPointerAttribute_t at;
+        if (hipPointerGetAttributes(&at, d_img) == hipSuccess && at.type == hipMemoryTypeDevice && at.device != ws->device)
+            return fail(SID_PM_ERR_ARG, "image lives on device %d, the workspace on device %d", at.device, ws->device);
+    }
     ws->img = d_img; ws->rows = rows; ws->cols = cols; ws->stride = stride; ws->stream = reinterpret_cast<hipStream_t>(hip_stream);
     ws->have = false;
     HistStates S; S.n = 1; S.prefix[0] = 0;
@@ -235,6 +250,7 @@ SID_EXPORT int sid_stage_order_stats_ws(sid_stage_ws *ws, const int64_t *ranks, 
     if (!ws || !ws->have) return fail(SID_PM_ERR_STATE, "order_stats_ws needs sid_stage_begin on the image first");
     if (n_ranks < 0 || (n_ranks > 0 && (!ranks || !values))) return fail(SID_PM_ERR_ARG, "bad rank list");
     for (int q = 0; q < n_ranks; ++q) if (ranks[q] < 0) return fail(SID_PM_ERR_ARG, "negative rank");
+    DeviceGuard guard(ws->device);
     // up to kMaxStates ranks per sweep; ranks that still share all chosen digits share a histogram (neighbouring
     // order statistics usually part only in the last digit)
     for (int q0 = 0; q0 < n_ranks; q0 += kMaxStates) {
@@ -299,6 +315,13 @@ SID_EXPORT int sid_stage_scale_u8(const float *d_img, int64_t rows, int64_t cols
 {
     if (int rc = check_img(d_img, rows, cols, stride)) return rc;
     if (!d_out || out_stride < cols) return fail(SID_PM_ERR_ARG, "bad output buffer");
+    int dev = -1;
+    {   // launch on the device that holds the image (the null stream belongs to the CURRENT device)
+        hipPointerAttribute_t at;
+        if (hipPointerGetAttributes(&at, d_img) == hipSuccess && at.type == hipMemoryTypeDevice) dev = at.device;
+    }
+    int cur = 0; (void)hipGetDevice(&cur);
+    DeviceGuard guard(dev >= 0 ? dev : cur);
     hipStream_t st = reinterpret_cast<hipStream_t>(hip_stream);
     const bool vec = vec_ok(d_img, cols, stride) && (reinterpret_cast<uintptr_t>(d_out) & 3) == 0 && (out_stride & 3) == 0;
     if (vec) hipLaunchKernelGGL(scale_kernel<true>, dim3(grid_rows(rows)), dim3(kThreads), 0, st, d_img, rows, cols, stride, vmin, denom, d_out, out_stride);

@@ -151,8 +151,16 @@ def interpolation_near(x1, y1, x2, y2, x1grd, y1grd, method='linear', first_gues
         tri = Delaunay(src)
         vals = np.array([x2, y2], dtype=np.float64).T
         if first_guess_device is not None:
+            # Point location and barycentric evaluation on the GPU.  Queries whose result could depend on SciPy's own choice
+            # of simplex (on an edge, a vertex or the hull) or on the last bit of its arithmetic (value next to a
+            # half-integer, which the caller rounds) come back flagged and are evaluated by SciPy itself, so that the
+            # ROUNDED first guess is the reference's in every case (include/sid_fg.h).
             from . import _capi
-            both = _capi.fg_interp_linear(tri.points, tri.simplices, vals, dst.reshape(-1, 2), device=first_guess_device)
+            flat = dst.reshape(-1, 2)
+            both, _, doubt = _capi.fg_interp_linear(tri.points, tri.simplices, vals, flat, device=first_guess_device, details=True)
+            if doubt.any():
+                from scipy.interpolate import LinearNDInterpolator
+                both[doubt] = LinearNDInterpolator(tri, vals)(flat[doubt])
             both = both.reshape(dst.shape[:-1] + (2,))
         else:
             from scipy.interpolate import LinearNDInterpolator

@@ -124,7 +124,8 @@ def prepare_first_guess(c2pm1, r2pm1, n1, c1, r1, n2, c2, r2, img_size,
         border[inside] = nearest_keypoint_distance(c2, r2, rq, cq, shape=n2_shape, device=fg_dev)
     else:
         c2t, r2t = interpolation_poly(c1n2, r1n2, c2, r2, c1n2, r1n2, **kwargs)
-        c2d, r2d = interpolation_near(c1n2, r1n2, c2 - c2t, r2 - r2t, c2pm1, r2pm1, first_guess_device=fg_dev, **kwargs)
+        # (these values are not rounded but go through hypot and floor: SciPy's own evaluation, so that no last bit differs)
+        c2d, r2d = interpolation_near(c1n2, r1n2, c2 - c2t, r2 - r2t, c2pm1, r2pm1, first_guess_device=None, **kwargs)
         border = np.hypot(c2d, r2d)
 
     border[border < min_border] = min_border

@@ -12,20 +12,57 @@ pytestmark = pytest.mark.gpu
 
 
 def test_interpolation_in_scipys_triangulation():
+    """Located simplices and values against SciPy's own find_simplex / LinearNDInterpolator on a triangulation with queries
+    inside, outside, ON vertices and ON edge midpoints.  Every query the device does not flag must sit in the simplex SciPy
+    finds and round to the same integer (what the reference does next, pmlib.py:288); wherever the simplex agrees the
+    values are compared bit for bit (the 2x2 LU restates LAPACK's) and the share is asserted; flagged queries are the ones
+    on edges / vertices / the hull, and the product evaluates them with SciPy (lib.interpolation_near)."""
     rng = np.random.default_rng(8)
     src = rng.uniform(0, 5000, (6000, 2))
     vals = np.stack([src[:, 1] * 1.01 + 3 + rng.normal(0, 2, 6000), src[:, 0] * 0.99 - 2 + rng.normal(0, 2, 6000)], axis=1)
     q = np.concatenate([rng.uniform(-200, 5200, (20000, 2)), src[:500], (src[:300] + src[300:600]) / 2])   # incl. vertices, outside points
     tri = Delaunay(src)
     exp = LinearNDInterpolator(tri, vals)(q)
-    got = _capi.fg_interp_linear(tri.points, tri.simplices, vals, q)
-    nan = np.isnan(exp[:, 0])
-    # hull membership may differ for points within rounding of the hull's boundary only
-    diff = np.isnan(got[:, 0]) != nan
-    assert diff.sum() <= 2
-    ok = ~nan & ~np.isnan(got[:, 0])
-    np.testing.assert_allclose(got[ok], exp[ok], rtol=1e-11, atol=1e-9)
-    assert (np.round(got[ok]) == np.round(exp[ok])).mean() > 0.9999      # what the reference does next (pmlib.py:288)
+    exp_sx = tri.find_simplex(q)
+    got, sx, doubt = _capi.fg_interp_linear(tri.points, tri.simplices, vals, q, details=True)
+    clear = ~doubt
+    assert doubt[20000:20500].all()                                       # queries on vertices are flagged
+    assert clear[:20000].mean() > 0.999                                   # random queries are not
+    # unflagged: SciPy's simplex, SciPy's hull membership, the same integer after rounding
+    np.testing.assert_array_equal(sx[clear], exp_sx[clear])
+    np.testing.assert_array_equal(np.isnan(got[clear, 0]), np.isnan(exp[clear, 0]))
+    inside = clear & (exp_sx >= 0)
+    np.testing.assert_array_equal(np.round(got[inside]), np.round(exp[inside]))
+    np.testing.assert_allclose(got[inside], exp[inside], rtol=1e-11, atol=1e-9)
+    # bit equality wherever the simplex is SciPy's (all unflagged inside queries): counted, and nearly all of them
+    same_bits = (got[inside] == exp[inside]).all(axis=1)
+    assert same_bits.mean() > 0.99, 'only %.4f of the values are bit-identical to SciPy' % same_bits.mean()
+    # the product's interpolation_near (flagged queries through SciPy): the rounded first guess equals SciPy's everywhere
+    xg, yg = lib.interpolation_near(src[:, 1], src[:, 0], vals[:, 0], vals[:, 1], q[:, 1], q[:, 0], first_guess_device=0)
+    both = np.stack([xg, yg], axis=1)
+    np.testing.assert_array_equal(np.isnan(both[:, 0]), np.isnan(exp[:, 0]))
+    fin = ~np.isnan(exp[:, 0])
+    np.testing.assert_array_equal(np.round(both[fin]), np.round(exp[fin]))
+
+
+def test_lattice_keypoints_take_the_flagged_route():
+    """Key points on the integer lattice (what a detector delivers at pyramid level 0) and integer grid queries: queries that
+    coincide with key points or lie on axis-parallel edges are flagged and still come out as SciPy evaluates them."""
+    rng = np.random.default_rng(18)
+    src = np.unique(np.floor(rng.uniform(0, 300, (4000, 2))), axis=0)
+    vals = np.stack([src[:, 1] + rng.normal(0, 3, len(src)), src[:, 0] + rng.normal(0, 3, len(src))], axis=1)
+    qx, qy = np.meshgrid(np.arange(5.0, 295.0, 3.0), np.arange(5.0, 295.0, 3.0))
+    q = np.stack([qy.ravel(), qx.ravel()], axis=1)
+    tri = Delaunay(src)
+    exp = LinearNDInterpolator(tri, vals)(q)
+    got, sx, doubt = _capi.fg_interp_linear(tri.points, tri.simplices, vals, q, details=True)
+    assert doubt.sum() > 50                                               # coincidences do occur on a lattice
+    clear = ~doubt & ~np.isnan(exp[:, 0])
+    np.testing.assert_array_equal(np.round(got[clear]), np.round(exp[clear]))
+    xg, yg = lib.interpolation_near(src[:, 1], src[:, 0], vals[:, 0], vals[:, 1], q[:, 1], q[:, 0], first_guess_device=0)
+    fin = ~np.isnan(exp[:, 0])
+    np.testing.assert_array_equal(np.isnan(xg), np.isnan(exp[:, 0]))
+    np.testing.assert_array_equal(np.round(np.stack([xg, yg], axis=1)[fin]), np.round(exp[fin]))
 
 
 def test_nearest_keypoint_distance_is_exact():
