@@ -91,7 +91,8 @@ struct sid_pm_ctx {
     int32_t *d_order = nullptr;
     double *d_angles = nullptr, *d_rot = nullptr;
     uint16_t *d_samp = nullptr;         // sampling table of the kernel (make_samp)
-    bool rp = false, rp_paired = false; // the resident points run the row-pair kernel (decided at set_points: use_rp), with paired slots
+    bool rp = false;                    // the resident points run the row-pair kernel (decided at set_points: use_rp) ...
+    int rp_paired = 0;                  // ... with slot groups: 0 none, 1 two groups (<= 7 angles), 2 four groups (<= 3 angles)
     bool have_samp = false;             // SID_PM_NO_SAMP_TABLE=1 keeps the on-the-fly sampling (tests of the general sampler)
     int samp_nflag = 0;
     // host copies of what the classification needs: the launch classes depend on the shape of image 2, so a
@@ -224,14 +225,18 @@ bool use_rp(int s, int K)
 
 // row-pair kernel with at most 7 angles: paired slots (8 output rows per item with the 4-row kernel's registers; the LDS
 // layout is that of an 8-row band)
-bool rp_paired(int K)
+int rp_paired(int K)
 {
-    return K <= sid::kPairedMaxAngles && getenv("SID_PM_NO_PAIRED") == nullptr;
+    if (K > sid::kPairedMaxAngles || getenv("SID_PM_NO_PAIRED") != nullptr) return 0;
+    return (K <= sid::kQuadMaxAngles && getenv("SID_PM_NO_QUAD") == nullptr) ? 2 : 1;   // (SID_PM_NO_QUAD: two groups also for <= 3 angles; A/B runs)
 }
 
-int lds_need(bool rp, bool rpp, int wh, int ww, int s, int K, int band = 4, int pitch = 0)
+// band argument of rp_lds_layout: output rows per sweep work item
+int rp_rows(int rpp, int band) { return rpp == 2 ? 16 : rpp == 1 ? 8 : band; }
+
+int lds_need(bool rp, int rpp, int wh, int ww, int s, int K, int band = 4, int pitch = 0)
 {
-    if (rp) return sid::rp_lds_layout(wh, ww, s, K <= sid::kRpGroup, rpp ? 8 : band, pitch).total;
+    if (rp) return sid::rp_lds_layout(wh, ww, s, K <= sid::kRpGroup, rp_rows(rpp, band), pitch).total;
     return sid::mfma_lds_layout(wh, ww, s, band, use_paired(K) && band == 4).total;
 }
 
@@ -288,7 +293,8 @@ int classify_points(sid_pm_ctx *ctx)
     const int64_t rows2 = ctx->cur[1].rows, cols2 = ctx->cur[1].cols;
     const double *c2fg = ctx->h_c2fg.data(), *r2fg = ctx->h_r2fg.data(), *border = ctx->h_border.data();
     static const bool no_band8 = getenv("SID_PM_NO_BAND8") != nullptr;                      // A/B runs
-    const bool rp = ctx->rp, rpp = ctx->rp_paired;
+    const bool rp = ctx->rp;
+    const int rpp = ctx->rp_paired;
     const bool band8_ok = sid::mfma_band8_supported(s) && !no_band8 && (rp ? !ctx->rp_paired : !use_paired(K));   // (classic and row-pair kernels alike)
     // Everything the launch needs to know about a point follows from the SHAPE of its search window, and a run has a few
     // dozen shapes (one per border): the LDS layouts are evaluated per shape, the points are only binned.
@@ -332,7 +338,7 @@ int classify_points(sid_pm_ctx *ctx)
             }
             sh.cls = force1 ? 1 : (force2 ? 2 : std::min(8, blocks_per_cu(sh.lds)));
             sh.work = (double)(wh - s + 1) * (double)(ww - s + 1);
-            if (rp) sh.nat_pitch = sid::rp_lds_layout(wh, ww, s, K <= sid::kRpGroup, rpp ? 8 : sh.band).wpitch;
+            if (rp) sh.nat_pitch = sid::rp_lds_layout(wh, ww, s, K <= sid::kRpGroup, rp_rows(rpp, sh.band)).wpitch;
             k = (int)shapes.size();
             shapes.push_back(sh);
         }
@@ -623,7 +629,7 @@ SID_EXPORT int sid_pm_set_points(sid_pm_ctx *ctx, const double *c1, const double
     ctx->h_c2fg.assign(c2fg, c2fg + n); ctx->h_r2fg.assign(r2fg, r2fg + n); ctx->h_border.assign(border, border + n);
 
     ctx->user_out = nullptr; ctx->user_ij = nullptr;
-    ctx->n = n; ctx->img_size = s; ctx->n_angles = K; ctx->flags = flags; ctx->rp = use_rp(s, K); ctx->rp_paired = ctx->rp && rp_paired(K);
+    ctx->n = n; ctx->img_size = s; ctx->n_angles = K; ctx->flags = flags; ctx->rp = use_rp(s, K); ctx->rp_paired = ctx->rp ? rp_paired(K) : 0;
     ctx->have_points = false;
     if (int rc = classify_points(ctx)) return rc;
     ctx->have_points = true;
@@ -767,7 +773,8 @@ SID_EXPORT int sid_pm_debug_point(sid_pm_ctx *ctx, double c1, double r1, double 
     if (int rc = check_sweep(img_size, angles, n_angles, flags)) return rc;
     Guard g(ctx->device);
     const int s = img_size, K = n_angles;
-    const bool rp = use_rp(s, K), rpp = rp && rp_paired(K);
+    const bool rp = use_rp(s, K);
+    const int rpp = rp ? rp_paired(K) : 0;
     int wh = 0, ww = 0, lds = lds_need(rp, rpp, s + 1, s + 1, s, K);
     if (window_dims(c2fg, r2fg, border, s, ctx->cur[1].rows, ctx->cur[1].cols, wh, ww))
         lds = lds_need(rp, rpp, wh, ww, s, K);
@@ -905,7 +912,8 @@ SID_EXPORT int sid_pm_estimate_cost(const double *border, int64_t n, int img_siz
     if (n < 0 || (n > 0 && (!border || !cost_ns))) return fail(SID_PM_ERR_ARG, "bad argument");
     const int s = img_size, K = n_angles;
     if (!sid::mfma_img_size_supported(s) || K < 1) return fail(SID_PM_ERR_UNSUPPORTED, "img_size / angle count not supported");
-    const bool rp = use_rp(s, K), rpp = rp && rp_paired(K);
+    const bool rp = use_rp(s, K);
+    const int rpp = rp ? rp_paired(K) : 0;
     const int hws = (int)((double)s / 2.0);
     const int groups = (K + sid::kRpGroup - 1) / sid::kRpGroup;
     constexpr double kSweep = 4.08e-3, kWinner = 2.05e-2, kPos = 5.09e-3, kFixed = 42.5, kTwoPerCu = 1.26, kOnePerCu = 1.61;
@@ -916,12 +924,12 @@ SID_EXPORT int sid_pm_estimate_cost(const double *border, int64_t n, int img_siz
         if (r < 2) { cost_ns[i] = kFixed; continue; }
         double sweep, winner, cls_factor;
         if (rp) {
-            const sid::RpLdsLayout L4 = sid::rp_lds_layout(wn, wn, s, K <= sid::kRpGroup, rpp ? 8 : 4);
+            const sid::RpLdsLayout L4 = sid::rp_lds_layout(wn, wn, s, K <= sid::kRpGroup, rp_rows(rpp, 4));
             int per_cu = blocks_per_cu(L4.total), band = 4;
             if (!rpp && per_cu == 2 && blocks_per_cu(sid::rp_lds_layout(wn, wn, s, K <= sid::kRpGroup, 8).total) >= 2) band = 8;
-            const int rows = rpp ? 8 : band, nb = (r + rows - 1) / rows, tiles = 2 * L4.npair + L4.nsingle;
+            const int rows = rp_rows(rpp, band), nb = (r + rows - 1) / rows, tiles = 2 * L4.npair + L4.nsingle;
             const double per_row_tile = (double)((s + 1) / 2 + s / 2 + 1) / 2.0 + (double)(((s - 32 + 1) / 2) * 2);
-            sweep = groups * ((rpp ? 0.55 : 1.0) * nb * rows * tiles * per_row_tile + 2.0 * nb * tiles);
+            sweep = groups * ((rpp == 2 ? 0.33 : rpp == 1 ? 0.55 : 1.0) * nb * rows * tiles * per_row_tile + 2.0 * nb * tiles);
             winner = (double)((r + 15) / 16) * (L4.npair * 152.0 + L4.nsingle * 76.0);
             cls_factor = per_cu >= 3 ? 1.0 : per_cu == 2 ? kTwoPerCu : kOnePerCu;
         } else {

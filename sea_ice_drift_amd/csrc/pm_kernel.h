@@ -121,8 +121,8 @@ __host__ __device__ inline bool rp_size_supported(int s) { return s == 34 || s =
 __host__ __device__ inline int rp_band_y0(int b, int nbands, int rh, int band)
 {
     int y0 = b * band;
-    if (band == 8 && b == nbands - 1 && nbands > 1) {
-        const int up = round_up(rh - 8, 4);
+    if (band >= 8 && b == nbands - 1 && nbands > 1) {
+        const int up = round_up(rh - band, 4);
         if (up < y0) y0 = up;
     }
     return y0;
@@ -191,14 +191,16 @@ __host__ __device__ inline int rp_class_pitch(int natural)
 {
     return natural <= 104 ? 104 : natural <= 136 ? 136 : natural <= 168 ? 168 : 0;
 }
-int launch_pm_rp(const PMArgs &args, int lds_bytes, int nthreads, int band, bool paired, int pitch, void *stream);
-bool rp_pitch_instantiated(int band, bool paired, int pitch);
+// paired: 0 = one group of 16 slots, 1 = two groups (at most 7 angles), 2 = four groups (at most 3 angles)
+int launch_pm_rp(const PMArgs &args, int lds_bytes, int nthreads, int band, int paired, int pitch, void *stream);
+bool rp_pitch_instantiated(int band, int paired, int pitch);
 
 __host__ __device__ inline int samp_pitch(int s) { return round_up(s, 4); }
 constexpr double kSampGuard = 1e-5;   // table entries whose coordinate is this close to k + 1/2 are flagged
 
 int launch_pm_mfma(const PMArgs &args, int lds_bytes, int nthreads, int band, bool paired, void *stream);
 constexpr int kPairedMaxAngles = 7;   // angle sets this small run the paired sweep
+constexpr int kQuadMaxAngles = 3;     // ... and these four slot groups (row-pair kernel)
 bool mfma_band8_supported(int s);
 bool mfma_img_size_supported(int s);
 

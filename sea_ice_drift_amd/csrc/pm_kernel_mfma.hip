@@ -2003,28 +2003,30 @@ int launch_pm_mfma(const PMArgs &args, int lds_bytes, int nthreads, int band, bo
 }
 
 template <int S>
-static void (*rp_kernel_for(int band, bool paired, int pitch))(const PMArgs)
+static void (*rp_kernel_for(int band, int paired, int pitch))(const PMArgs)
 {
-    if (paired) return pitch == 104 ? pm_kernel_rp<S, 4, true, 104> : pitch == 136 ? pm_kernel_rp<S, 4, true, 136>
-                     : pitch == 168 ? pm_kernel_rp<S, 4, true, 168> : pitch == 0 ? pm_kernel_rp<S, 4, true, 0> : nullptr;
-    if (band == 8) return pitch == 136 ? pm_kernel_rp<S, 8, false, 136> : pitch == 0 ? pm_kernel_rp<S, 8, false, 0> : nullptr;
-    return pitch == 104 ? pm_kernel_rp<S, 4, false, 104> : pitch == 136 ? pm_kernel_rp<S, 4, false, 136>
-         : pitch == 168 ? pm_kernel_rp<S, 4, false, 168> : pitch == 0 ? pm_kernel_rp<S, 4, false, 0> : nullptr;
+    if (paired == 2) return pitch == 104 ? pm_kernel_rp<S, 4, 2, 104> : pitch == 136 ? pm_kernel_rp<S, 4, 2, 136>
+                          : pitch == 168 ? pm_kernel_rp<S, 4, 2, 168> : pitch == 0 ? pm_kernel_rp<S, 4, 2, 0> : nullptr;
+    if (paired == 1) return pitch == 104 ? pm_kernel_rp<S, 4, 1, 104> : pitch == 136 ? pm_kernel_rp<S, 4, 1, 136>
+                          : pitch == 168 ? pm_kernel_rp<S, 4, 1, 168> : pitch == 0 ? pm_kernel_rp<S, 4, 1, 0> : nullptr;
+    if (band == 8) return pitch == 136 ? pm_kernel_rp<S, 8, 0, 136> : pitch == 0 ? pm_kernel_rp<S, 8, 0, 0> : nullptr;
+    return pitch == 104 ? pm_kernel_rp<S, 4, 0, 104> : pitch == 136 ? pm_kernel_rp<S, 4, 0, 136>
+         : pitch == 168 ? pm_kernel_rp<S, 4, 0, 168> : pitch == 0 ? pm_kernel_rp<S, 4, 0, 0> : nullptr;
 }
 
 // true when launch_pm_rp carries an instantiation with this compile-time window pitch (0 = run-time pitch: always)
-bool rp_pitch_instantiated(int band, bool paired, int pitch)
+bool rp_pitch_instantiated(int band, int paired, int pitch)
 {
     return rp_kernel_for<34>(band, paired, pitch) != nullptr;
 }
 
-int launch_pm_rp(const PMArgs &args, int lds_bytes, int nthreads, int band, bool paired, int pitch, void *stream)
+int launch_pm_rp(const PMArgs &args, int lds_bytes, int nthreads, int band, int paired, int pitch, void *stream)
 {
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (args.n_launch <= 0) return (int)hipSuccess;
     if (!rp_size_supported(args.img_size)) return (int)hipErrorInvalidValue;
     if ((band != 4 && band != 8) || (band == 8 && nthreads != 256)) return (int)hipErrorInvalidValue;
-    if (paired && (band != 4 || args.n_angles > kPairedMaxAngles)) return (int)hipErrorInvalidValue;
+    if (paired && (band != 4 || args.n_angles > (paired == 2 ? kQuadMaxAngles : kPairedMaxAngles))) return (int)hipErrorInvalidValue;
     void (*kern)(const PMArgs) = args.img_size == 34 ? rp_kernel_for<34>(band, paired, pitch) : rp_kernel_for<35>(band, paired, pitch);
     if (!kern) return (int)hipErrorInvalidValue;
     const hipError_t e = allow_max_lds(kern);

@@ -79,6 +79,28 @@ __global__ __launch_bounds__(kThreads) void hist_kernel(const float *img, int64_
     for (int i = threadIdx.x; i < S.n * kBins; i += kThreads) h_raw[i] = 0;
     __syncthreads();
     const uint32_t nm1 = (uint32_t)nbins - 1u;
+    const float nan = __int_as_float(0x7fc00000);
+    if (VEC && stride == cols) {
+        // contiguous image: one flat array of 16-byte words, kUnroll of them in flight per lane before any is binned
+        // (every workgroup streams whole chunks: no row granularity, no tail of partly idle workgroups)
+        constexpr int kUnroll = 4;
+        const float4 *p4 = reinterpret_cast<const float4 *>(img);
+        const int64_t n4 = (rows * cols) >> 2, step = (int64_t)gridDim.x * kThreads * kUnroll;
+        const int64_t n4r = (n4 + step - 1) / step * step;                 // (all lanes stay in the loop: wavefront ballots)
+        for (int64_t base = (int64_t)blockIdx.x * kThreads * kUnroll; base < n4r; base += step) {
+            float4 v[kUnroll];
+#pragma unroll
+            for (int u = 0; u < kUnroll; ++u) {
+                const int64_t x = base + u * kThreads + threadIdx.x;
+                v[u] = x < n4 ? p4[x] : make_float4(nan, nan, nan, nan);
+            }
+#pragma unroll
+            for (int u = 0; u < kUnroll; ++u) {
+                bin_pixel<AGG>(v[u].x, S, mask, shift, nm1, h); bin_pixel<AGG>(v[u].y, S, mask, shift, nm1, h);
+                bin_pixel<AGG>(v[u].z, S, mask, shift, nm1, h); bin_pixel<AGG>(v[u].w, S, mask, shift, nm1, h);
+            }
+        }
+    } else
     for (int64_t r = blockIdx.x; r < rows; r += gridDim.x) {
         const float *row = img + r * stride;
         if (VEC) {
@@ -87,14 +109,13 @@ __global__ __launch_bounds__(kThreads) void hist_kernel(const float *img, int64_
             for (int64_t x = threadIdx.x; x < ((n4 + kThreads - 1) / kThreads) * kThreads; x += kThreads) {
                 // (all lanes stay in the loop: the aggregation uses wavefront ballots)
                 const bool in = x < n4;
-                const float nan = __int_as_float(0x7fc00000);
                 const float4 v = in ? row4[x] : make_float4(nan, nan, nan, nan);
                 bin_pixel<AGG>(v.x, S, mask, shift, nm1, h); bin_pixel<AGG>(v.y, S, mask, shift, nm1, h);
                 bin_pixel<AGG>(v.z, S, mask, shift, nm1, h); bin_pixel<AGG>(v.w, S, mask, shift, nm1, h);
             }
         } else {
             for (int64_t x = threadIdx.x; x < ((cols + kThreads - 1) / kThreads) * kThreads; x += kThreads)
-                bin_pixel<AGG>(x < cols ? row[x] : __int_as_float(0x7fc00000), S, mask, shift, nm1, h);
+                bin_pixel<AGG>(x < cols ? row[x] : nan, S, mask, shift, nm1, h);
         }
     }
     __syncthreads();
@@ -116,6 +137,26 @@ __global__ __launch_bounds__(kThreads) void scale_kernel(const float *img, int64
         const bool finite = fabsf(x) <= 3.402823466e38f;     // false for NaN and +-inf (lib.py:57)
         return (finite && t == t) ? (uint32_t)(uint8_t)t : 0u;
     };
+    if (VEC && stride == cols && out_stride == cols) {       // contiguous in and out: flat, four 16-byte loads in flight per lane
+        constexpr int kUnroll = 4;
+        const float4 *p4 = reinterpret_cast<const float4 *>(img);
+        uint32_t *o4 = reinterpret_cast<uint32_t *>(out);
+        const int64_t n4 = (rows * cols) >> 2, step = (int64_t)gridDim.x * kThreads * kUnroll;
+        for (int64_t base = (int64_t)blockIdx.x * kThreads * kUnroll; base < n4; base += step) {
+            float4 v[kUnroll];
+#pragma unroll
+            for (int u = 0; u < kUnroll; ++u) {
+                const int64_t x = base + u * kThreads + threadIdx.x;
+                v[u] = x < n4 ? p4[x] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int u = 0; u < kUnroll; ++u) {
+                const int64_t x = base + u * kThreads + threadIdx.x;
+                if (x < n4) o4[x] = one(v[u].x) | (one(v[u].y) << 8) | (one(v[u].z) << 16) | (one(v[u].w) << 24);
+            }
+        }
+        return;
+    }
     for (int64_t r = blockIdx.x; r < rows; r += gridDim.x) {
         const float *row = img + r * stride;
         uint8_t *orow = out + r * out_stride;

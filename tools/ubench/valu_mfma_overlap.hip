@@ -9,7 +9,7 @@
 #include <stdint.h>
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef float v2f __attribute__((ext_vector_type(2)));
-#define ITER 2048
+#define ITER 8192
 
 __device__ __forceinline__ void mfma_loop(int *out, int seed, int iters)
 {
@@ -58,6 +58,21 @@ __device__ __forceinline__ void valu_loop(int *out, int seed, int iters)
         } else if (KIND == 5) {
 #pragma unroll
             for (int i = 0; i < 32; ++i) f[i] = __int_as_float(__builtin_amdgcn_alignbyte(__float_as_int(f[i]), __float_as_int(f[(i + 1) & 31]), 1));
+        } else if (KIND == 6) {                                         // v_add_u32 with a run-time operand
+#pragma unroll
+            for (int i = 0; i < 32; ++i) f[i] = __int_as_float(__float_as_int(f[i]) + __float_as_int(x) + i);
+        } else if (KIND == 7) {                                         // v_mad_i32_i24
+#pragma unroll
+            for (int i = 0; i < 32; ++i) f[i] = __int_as_float(__mul24(__float_as_int(f[i]), __float_as_int(x)) + i);
+        } else if (KIND == 8) {                                         // v_cvt_f32_i32
+#pragma unroll
+            for (int i = 0; i < 32; ++i) f[i] = (float)(__float_as_int(f[i]) ^ i);
+        } else if (KIND == 9) {                                         // v_max_f32 / v_cndmask
+#pragma unroll
+            for (int i = 0; i < 32; ++i) f[i] = fmaxf(f[i], x) > 2.0f ? x : f[i];
+        } else if (KIND == 10) {                                        // v_mul_f32
+#pragma unroll
+            for (int i = 0; i < 32; ++i) f[i] = f[i] * x;
         }
     }
     float r = 0;
@@ -111,5 +126,11 @@ int main()
     run<3>("v_pk_fma_f32", out, blocks);
     run<4>("cvt f64<->i32/f32 + add", out, blocks);
     run<5>("v_alignbyte_b32", out, blocks);
+    run<6>("v_add_u32 (x2)", out, blocks);
+    run<7>("v_mad_i32_i24", out, blocks);
+    run<8>("v_xor + v_cvt_f32_i32", out, blocks);
+    run<9>("v_max + v_cmp + v_cndmask", out, blocks);
+    run<10>("v_mul_f32", out, blocks);
+    run<0>("v_fma_f32 (again)", out, blocks);
     return 0;
 }
