@@ -1576,32 +1576,41 @@ __device__ __noinline__ void ph_hessian_fast(unsigned flags, int iy, int ix, flo
             sx += (double)hv; sxx += (double)hv * (double)hv;
             if (norm) { const u32 b = hes_bucket(__float_as_uint(hv)); atomicAdd(&hist[b >> 1], 1u << (16 * (b & 1u))); }
         };
-        // interior (five reads, central differences only) and frame exactly as in ph_hessian; the square roots of a
-        // batch are evaluated unconditionally (independent chains interleave), only the stores are predicated
-        constexpr int kHes = 4;
+        // Interior placements (two or more away from every edge): g(k+1) = (f[k+2] - f[k]) / 2 and g(k-1) = (f[k] - f[k-2]) / 2
+        // are central differences themselves, d2 = (g(k+1) - g(k-1)) / 2 - the float32 operations np.gradient performs there.
+        // A thread owns one column and a run of rows and slides down it: the rows y-2 .. y+1 of its column stay in registers
+        // (one new vertical read per placement + the two horizontal neighbours) and nothing is divided to find a position.
+        // Four placements are in flight (their square-root chains interleave); only the stores are predicated.
         const int iw = rw - 4, ih = rh - 4;
         if (iw > 0 && ih > 0) {
-            const u32 imagic = 0xffffffffu / (u32)iw + 1u;
-            const int nin = iw * ih;
-            for (int base = 0; base < nin; base += kHes * kBlockM) {
-                float d2xv[kHes], d2yv[kHes];
+            int nseg = kBlockM / iw; nseg = nseg < 1 ? 1 : (nseg > ih ? ih : nseg);
+            const int per = (ih + nseg - 1) / nseg;
+            constexpr int kB = 4;
+            for (int task = tid; task < iw * nseg; task += kBlockM) {  // (one pass unless the matrix is wider than the workgroup)
+                const int seg = task / iw, xx = task - seg * iw;
+                const int ya = 2 + seg * per, yb = (ya + per < rh - 2) ? ya + per : rh - 2;
+                if (ya >= yb) continue;
+                const float *col = ccm + xx + 2;                       // column x = xx + 2
+                float ra = col[(ya - 2) * rw], rb = col[(ya - 1) * rw], rc = col[ya * rw], rd = col[(ya + 1) * rw];
+                for (int y = ya; y < yb; y += kB) {
+                    float e[kB], xl[kB], xr[kB], hvv[kB];
 #pragma unroll
-                for (int u = 0; u < kHes; ++u) {
-                    const int q = base + u * kBlockM + tid;
-                    const int qc = q < nin ? q : 0;
-                    const int yy = (int)__umulhi((u32)qc, imagic), xx = qc - yy * iw;
-                    const float *f = ccm + (yy + 2) * rw + (xx + 2);
-                    const float c = f[0], xr = f[2], xl = f[-2], yd = f[2 * rw], yu = f[-2 * rw];
-                    d2xv[u] = ((xr - c) * 0.5f - (c - xl) * 0.5f) * 0.5f;
-                    d2yv[u] = ((yd - c) * 0.5f - (c - yu) * 0.5f) * 0.5f;
-                }
-                float hvv[kHes];
+                    for (int u = 0; u < kB; ++u) {
+                        const int yr = (y + u < rh - 3) ? y + u : rh - 3;   // (rows past the run are read where legal and dropped)
+                        const float *f = col + yr * rw;
+                        e[u] = f[2 * rw]; xl[u] = f[-2]; xr[u] = f[2];
+                    }
+                    const float cc[kB] = {rc, rd, e[0], e[1]}, uu[kB] = {ra, rb, rc, rd};
 #pragma unroll
-                for (int u = 0; u < kHes; ++u) hvv[u] = hypot_fast(d2xv[u], d2yv[u]);
+                    for (int u = 0; u < kB; ++u) {
+                        const float d2x = ((xr[u] - cc[u]) * 0.5f - (cc[u] - xl[u]) * 0.5f) * 0.5f;
+                        const float d2y = ((e[u] - cc[u]) * 0.5f - (cc[u] - uu[u]) * 0.5f) * 0.5f;
+                        hvv[u] = hypot_fast(d2x, d2y);
+                    }
 #pragma unroll
-                for (int u = 0; u < kHes; ++u) {
-                    const int q = base + u * kBlockM + tid;
-                    if (q < nin) { const int yy = (int)__umulhi((u32)q, imagic), xx = q - yy * iw; emit((yy + 2) * rw + xx + 2, hvv[u]); }
+                    for (int u = 0; u < kB; ++u)
+                        if (y + u < yb) emit((y + u) * rw + xx + 2, hvv[u]);
+                    ra = e[0]; rb = e[1]; rc = e[2]; rd = e[3];
                 }
             }
         }
