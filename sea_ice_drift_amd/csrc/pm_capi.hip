@@ -906,7 +906,7 @@ SID_EXPORT int sid_pm_debug_hypot_selftest(sid_pm_ctx *ctx, uint64_t seed, int64
 // matrix instructions of the sweep (bands x placement tiles x template row pairs, per group of angles), those of the
 // winner's NCC matrix, the placements themselves - times a factor for the residency class of its LDS footprint (fewer
 // co-resident workgroups hide less latency).  The six constants were fitted to tools/border_cost.py (template side 34, 15
-// angles, borders 20..50: within 8 % everywhere); what matters to the sharding are the ratios between points.
+// angles, borders 20..50: within 4 % everywhere); what matters to the sharding are the ratios between points.
 SID_EXPORT int sid_pm_estimate_cost(const double *border, int64_t n, int img_size, int n_angles, double *cost_ns)
 {
     if (n < 0 || (n > 0 && (!border || !cost_ns))) return fail(SID_PM_ERR_ARG, "bad argument");
@@ -916,7 +916,7 @@ SID_EXPORT int sid_pm_estimate_cost(const double *border, int64_t n, int img_siz
     const int rpp = rp ? rp_paired(K) : 0;
     const int hws = (int)((double)s / 2.0);
     const int groups = (K + sid::kRpGroup - 1) / sid::kRpGroup;
-    constexpr double kSweep = 4.08e-3, kWinner = 2.05e-2, kPos = 5.09e-3, kFixed = 42.5, kTwoPerCu = 1.26, kOnePerCu = 1.61;
+    constexpr double kSweep = 7.06e-3, kWinner = 8.64e-3, kPos = 3.28e-3, kFixed = 43.3, kTwoPerCu = 1.32, kOnePerCu = 1.69;
     for (int64_t i = 0; i < n; ++i) {
         const double b = border[i];
         if (!(b >= 0.0 && b < 4096.0)) { cost_ns[i] = kFixed; continue; }      // NaN / absurd: a point that writes NaN at once
@@ -929,8 +929,11 @@ SID_EXPORT int sid_pm_estimate_cost(const double *border, int64_t n, int img_siz
             if (!rpp && per_cu == 2 && blocks_per_cu(sid::rp_lds_layout(wn, wn, s, K <= sid::kRpGroup, 8).total) >= 2) band = 8;
             const int rows = rp_rows(rpp, band), nb = (r + rows - 1) / rows, tiles = 2 * L4.npair + L4.nsingle;
             const double per_row_tile = (double)((s + 1) / 2 + s / 2 + 1) / 2.0 + (double)(((s - 32 + 1) / 2) * 2);
-            sweep = groups * ((rpp == 2 ? 0.33 : rpp == 1 ? 0.55 : 1.0) * nb * rows * tiles * per_row_tile + 2.0 * nb * tiles);
-            winner = (double)((r + 15) / 16) * (L4.npair * 152.0 + L4.nsingle * 76.0);
+            // work items are dealt to the wavefronts of the workgroup: the busiest wavefront sets the pace
+            const int nwaves = per_cu == 1 ? 12 : 4;
+            const int units = ((nb * tiles + nwaves - 1) / nwaves) * nwaves, wunits = ((((r + 15) / 16) * tiles + nwaves - 1) / nwaves) * nwaves;
+            sweep = groups * (rpp == 2 ? 0.33 : rpp == 1 ? 0.55 : 1.0) * units * (rows * per_row_tile + 2.0);
+            winner = wunits * 76.0;
             cls_factor = per_cu >= 3 ? 1.0 : per_cu == 2 ? kTwoPerCu : kOnePerCu;
         } else {
             const sid::MfmaLdsLayout L = sid::mfma_lds_layout(wn, wn, s, 4, use_paired(K));

@@ -31,7 +31,7 @@ def point_cost(border, img_size=34, n_angles=15):
     (include/sid_pm.h ``sid_pm_estimate_cost``, host arithmetic) from what the kernel executes for a point of that search
     border - matrix instructions of the sweep and of the winner's NCC matrix, placements - and from the residency class of
     its LDS footprint, for the template side and angle count of the run; it reproduces the staircase that
-    tools/border_cost.py measures (placement tiles per output row, workgroups per CU) within 8 %."""
+    tools/border_cost.py measures (placement tiles per output row, work items per wavefront, workgroups per CU) within 4 %."""
     from . import _capi
     return _capi.estimate_cost(np.asarray(border, dtype=np.float64), img_size, n_angles)
 
