@@ -18,9 +18,12 @@
  * with all c >= -eps, eps = 100 * DBL_EPSILON.  SciPy reaches a simplex by a directed walk, so for a query ON an edge,
  * a vertex or the hull it may pick another simplex (or none); and its BLAS may round the 2x2 solve differently in the
  * last bit.  Neither may change what the reference computes next (np.round of the first guess, pmlib.py:285-288), so
- * every query for which that cannot be excluded is FLAGGED in doubt[] - smallest barycentric coordinate within 1e-9 of
- * zero in some simplex, or a value within 1e-6 of a half-integer - and the caller evaluates those with SciPy itself
- * (sea_ice_drift_amd/lib.py interpolation_near).  Every unflagged query lies strictly inside exactly one simplex.
+ * every query for which that cannot be excluded is FLAGGED in doubt[] and the caller evaluates those with SciPy itself
+ * (sea_ice_drift_amd/lib.py interpolation_near).  A query whose smallest barycentric coordinate in some simplex lies
+ * within 1e-9 of zero (on an edge, a vertex, the hull) is looked at against every simplex: it stays flagged unless hull
+ * membership is clear (no smallest coordinate within 4e-15 of SciPy's threshold -2.2e-14), all containing simplices round to the same
+ * integers and no value lies within 1e-6 of a half-integer; every other query lies strictly inside exactly one simplex
+ * (flagged only when its value is that close to a half-integer).
  * Host buffers in / host buffers out; 0 on success, a negative SID_PM_ERR_* code otherwise (sid_pm.h).
  */
 #ifndef SID_FG_H

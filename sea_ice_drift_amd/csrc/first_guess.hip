@@ -119,6 +119,48 @@ __global__ void k_eval(const Simp *simp, const int32_t *loc, const int32_t *near
     if (doubt) doubt[i] = dbt;
 }
 
+// Second look at the flagged queries (k_eval: on an edge, a vertex or the hull), against EVERY simplex, no early exit.  A
+// flagged query is RESOLVED - the caller need not ask SciPy - when whatever simplex SciPy's walk ends in, the ROUNDED result
+// is the same: (a) hull membership is clear - the best smallest barycentric coordinate over all simplices is not within
+// 4e-15 of SciPy's threshold -eps = -2.2e-14; (b) every simplex that contains the query (min c >= -eps) rounds to the same pair of
+// integers (a shared vertex or edge interpolates to the same value from either side, up to the last bits); (c) no such
+// value lies within 1e-6 of a half-integer.  Resolved queries get the values of the lowest-index containing simplex (or
+// NaN); the others keep their flag.
+__global__ __launch_bounds__(256) void k_resolve(const Simp *simp, int64_t ns, const double *values, const double *q, int64_t nq,
+                                                 double *out, int32_t *simplex, int32_t *doubt)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nq || !doubt[i]) return;
+    const double x = q[2 * i], y = q[2 * i + 1];
+    const double eps = 100.0 * DBL_EPSILON;
+    bool hull_unclear = false, disagree = false, near_half = false, any = false;
+    double R0 = 0.0, R1 = 0.0, V0 = NAN, V1 = NAN;
+    int32_t K = -1;
+    for (int64_t k = 0; k < ns; ++k) {
+        const Simp s = simp[k];
+        if (!s.ok) continue;
+        const double dx = x - s.rx, dy = y - s.ry;
+        const double c0 = s.t00 * dx + s.t01 * dy, c1 = s.t10 * dx + s.t11 * dy;
+        const double c2 = 1.0 - c0 - c1;
+        const double mc = fmin(c0, fmin(c1, c2));
+        if (!(mc >= -kTol)) continue;
+        if (fabs(mc + eps) < 4e-15) hull_unclear = true;               // (eps itself is 2.2e-14; a coordinate carries ~1e-16 of rounding)
+        if (mc >= -eps) {
+            const double *v0 = values + 2 * (int64_t)s.v0, *v1 = values + 2 * (int64_t)s.v1, *v2 = values + 2 * (int64_t)s.v2;
+            double o0 = c0 * v0[0]; o0 += c1 * v1[0]; o0 += c2 * v2[0];
+            double o1 = c0 * v0[1]; o1 += c1 * v1[1]; o1 += c2 * v2[1];
+            const double r0 = rint(o0), r1 = rint(o1);                 // half to even, as np.round
+            near_half = near_half || fabs(o0 - floor(o0) - 0.5) < 1e-6 || fabs(o1 - floor(o1) - 0.5) < 1e-6 || !(fabs(o0) < 1e15) || !(fabs(o1) < 1e15);
+            if (!any) { any = true; R0 = r0; R1 = r1; V0 = o0; V1 = o1; K = (int32_t)k; }
+            else if (r0 != R0 || r1 != R1) disagree = true;
+        }
+    }
+    if (hull_unclear || disagree || near_half) return;                  // stays flagged
+    out[2 * i] = V0; out[2 * i + 1] = V1;
+    if (simplex) simplex[i] = K;
+    doubt[i] = 0;
+}
+
 __global__ __launch_bounds__(256) void k_nearest(const double *seeds, int64_t ns, const double *q, int64_t nq, double *dist)
 {
     __shared__ double sx[1024], sy[1024];
@@ -218,6 +260,7 @@ SID_EXPORT int sid_fg_interp_linear(int device, const double *pts, int64_t n_pts
         HIP_TRY(hipMemsetAsync(d_near, 0, sizeof(int32_t) * n_q, 0));
         hipLaunchKernelGGL(k_locate, dim3(qb, ychunks), dim3(256), 0, 0, d_t, n_simp, chunk, d_q, n_q, d_loc, d_near);
         hipLaunchKernelGGL(k_eval, dim3(qb), dim3(256), 0, 0, d_t, d_loc, d_near, d_val, d_q, n_q, d_out, d_sx, d_dbt);
+        hipLaunchKernelGGL(k_resolve, dim3(qb), dim3(256), 0, 0, d_t, n_simp, d_val, d_q, n_q, d_out, d_sx, d_dbt);
     }
     HIP_TRY(hipGetLastError());
     if (simplex) HIP_TRY(hipMemcpyAsync(simplex, d_sx, sizeof(int32_t) * n_q, hipMemcpyDeviceToHost, 0));

@@ -158,6 +158,10 @@ def interpolation_near(x1, y1, x2, y2, x1grd, y1grd, method='linear', first_gues
             from . import _capi
             flat = dst.reshape(-1, 2)
             both, _, doubt = _capi.fg_interp_linear(tri.points, tri.simplices, vals, flat, device=first_guess_device, details=True)
+            # (SciPy rejects a query outside the bounding box of the points before it looks at any simplex: queries on the
+            # box, where that absolute test and the barycentric one could part, go to SciPy as well)
+            lo, hi = tri.points.min(axis=0), tri.points.max(axis=0)
+            doubt |= (np.abs(flat - lo) < 1e-9).any(axis=1) | (np.abs(flat - hi) < 1e-9).any(axis=1)
             if doubt.any():
                 from scipy.interpolate import LinearNDInterpolator
                 both[doubt] = LinearNDInterpolator(tri, vals)(flat[doubt])
