@@ -67,9 +67,27 @@ __device__ __forceinline__ void bin_pixel(float v, const HistStates &S, uint32_t
     }
 }
 
+// Digit passes after the first: a pixel takes part only when its key matches one of NS prefixes - one in ~10 at best,
+// mostly none - so the four pixels of a 16-byte word are tested without a branch (NS compile-time: the prefixes stay in
+// scalar registers) and only a lane that holds a match goes on to the atomics.
+template <int NS>
+__device__ __forceinline__ void bin_word(const float4 v, const HistStates &S, uint32_t mask, int shift, uint32_t nbins_m1,
+                                         uint32_t (*h)[kBins])
+{
+    const uint32_t k0 = f2key(v.x) & mask, k1 = f2key(v.y) & mask, k2 = f2key(v.z) & mask, k3 = f2key(v.w) & mask;
+    bool any = false;
+#pragma unroll
+    for (int q = 0; q < NS; ++q) any |= (k0 == S.prefix[q]) | (k1 == S.prefix[q]) | (k2 == S.prefix[q]) | (k3 == S.prefix[q]);
+    if (any) {
+        bin_pixel<false>(v.x, S, mask, shift, nbins_m1, h); bin_pixel<false>(v.y, S, mask, shift, nbins_m1, h);
+        bin_pixel<false>(v.z, S, mask, shift, nbins_m1, h); bin_pixel<false>(v.w, S, mask, shift, nbins_m1, h);
+    }
+}
+
 // For every state q: histogram of digit (key >> shift) & (nbins - 1) over the non-NaN pixels whose key matches
 // prefix[q] under `mask`.  hist: [n][kBins] (64-bit, global).  VEC: rows are 16-byte aligned and cols % 4 == 0.
-template <bool AGG, bool VEC>
+// NS: number of states when known at compile time (contiguous vector path of the later passes), else 0
+template <bool AGG, bool VEC, int NS = 0>
 __global__ __launch_bounds__(kThreads) void hist_kernel(const float *img, int64_t rows, int64_t cols, int64_t stride,
                                                         HistStates S, uint32_t mask, int shift, int nbins,
                                                         unsigned long long *hist)
@@ -96,6 +114,7 @@ __global__ __launch_bounds__(kThreads) void hist_kernel(const float *img, int64_
             }
 #pragma unroll
             for (int u = 0; u < kUnroll; ++u) {
+                if (NS > 0) { bin_word<NS>(v[u], S, mask, shift, nm1, h); continue; }
                 bin_pixel<AGG>(v[u].x, S, mask, shift, nm1, h); bin_pixel<AGG>(v[u].y, S, mask, shift, nm1, h);
                 bin_pixel<AGG>(v[u].z, S, mask, shift, nm1, h); bin_pixel<AGG>(v[u].w, S, mask, shift, nm1, h);
             }
@@ -221,6 +240,9 @@ int run_hist(sid_stage_ws *ws, const HistStates &S, uint32_t mask, int shift, in
         const bool vec = vec_ok(ws->img, ws->cols, ws->stride);
         if (agg && vec) hipLaunchKernelGGL((hist_kernel<true, true>), grid, block, lds, st, ws->img, ws->rows, ws->cols, ws->stride, S, mask, shift, nbins, ws->d_hist);
         else if (agg) hipLaunchKernelGGL((hist_kernel<true, false>), grid, block, lds, st, ws->img, ws->rows, ws->cols, ws->stride, S, mask, shift, nbins, ws->d_hist);
+        else if (vec && ws->stride == ws->cols && S.n == 1) hipLaunchKernelGGL((hist_kernel<false, true, 1>), grid, block, lds, st, ws->img, ws->rows, ws->cols, ws->stride, S, mask, shift, nbins, ws->d_hist);
+        else if (vec && ws->stride == ws->cols && S.n == 2) hipLaunchKernelGGL((hist_kernel<false, true, 2>), grid, block, lds, st, ws->img, ws->rows, ws->cols, ws->stride, S, mask, shift, nbins, ws->d_hist);
+        else if (vec && ws->stride == ws->cols && S.n <= 4) hipLaunchKernelGGL((hist_kernel<false, true, 4>), grid, block, lds, st, ws->img, ws->rows, ws->cols, ws->stride, S, mask, shift, nbins, ws->d_hist);
         else if (vec) hipLaunchKernelGGL((hist_kernel<false, true>), grid, block, lds, st, ws->img, ws->rows, ws->cols, ws->stride, S, mask, shift, nbins, ws->d_hist);
         else hipLaunchKernelGGL((hist_kernel<false, false>), grid, block, lds, st, ws->img, ws->rows, ws->cols, ws->stride, S, mask, shift, nbins, ws->d_hist);
         e = hipGetLastError();
@@ -317,6 +339,7 @@ SID_EXPORT int sid_stage_order_stats_ws(sid_stage_ws *ws, const int64_t *ranks, 
                 if (f < 0) { f = S.n; S.prefix[S.n++] = prefix[q]; }
                 state_of[q] = f;
             }
+            for (int t = S.n; t < kMaxStates; ++t) S.prefix[t] = S.prefix[0];     // (the compile-time state counts test up to 4)
             if (int rc = run_hist(ws, S, mask, shifts[pass], nb[pass], false)) return rc;
             for (int q = 0; q < nr; ++q) if (int rc = pick(q, ws->h_hist + (size_t)state_of[q] * kBins, nb[pass], shifts[pass])) return rc;
             mask |= (uint32_t)(nb[pass] - 1) << shifts[pass];
