@@ -176,6 +176,10 @@ int make_samp(const std::vector<double> &rot, int K, int s, std::vector<uint16_t
 // window geometry of one point, the same arithmetic as the kernel (pmlib.py:200-202)
 // Workgroups of `lds` bytes that fit one CU.  gfx950 hands LDS out in 1280-byte granules (160 KB / 128;
 // measured with tools/ubench/lds_granule.hip: 53760 B -> 3 per CU, 53761 B -> 2).
+// workgroups of four wavefronts a CU takes at the kernels' register budget (3 wavefronts per SIMD): launch classes beyond
+// this differ in nothing
+constexpr int kMaxPerCu = 3;
+
 int blocks_per_cu(int lds)
 {
     constexpr int kLdsGranule = 1280;
@@ -236,7 +240,7 @@ int rp_rows(int rpp, int band) { return rpp == 2 ? 16 : rpp == 1 ? 8 : band; }
 
 int lds_need(bool rp, int rpp, int wh, int ww, int s, int K, int band = 4, int pitch = 0)
 {
-    if (rp) return sid::rp_lds_layout(wh, ww, s, K <= sid::kRpGroup, rp_rows(rpp, band), pitch).total;
+    if (rp) return sid::rp_lds_layout(wh, ww, s, K <= sid::kRpGroup, rp_rows(rpp, band), pitch, sid::rp_tab_pitch(rpp)).total;
     return sid::mfma_lds_layout(wh, ww, s, band, use_paired(K) && band == 4).total;
 }
 
@@ -311,7 +315,7 @@ int classify_points(sid_pm_ctx *ctx)
     };
     const int lds_min = lds_need(rp, rpp, s + 1, s + 1, s, K);
     {   // shape 0: points whose window does not lie inside image 2 (they write NaN at once; minimal footprint)
-        Shape z{0, 0, lds_min, 4, std::min(8, blocks_per_cu(lds_min)), 0, 0, 0.0, {}};
+        Shape z{0, 0, lds_min, 4, std::min(kMaxPerCu, blocks_per_cu(lds_min)), 0, 0, 0.0, {}};
         shapes.push_back(z);
     }
     double macs = 0, bytes = 0, valid = 0;
@@ -336,9 +340,9 @@ int classify_points(sid_pm_ctx *ctx)
                 if (blocks_per_cu(need8) >= 2) { sh.lds = need8; sh.band = 8; force2 = true; }
                 else force1 = true;
             }
-            sh.cls = force1 ? 1 : (force2 ? 2 : std::min(8, blocks_per_cu(sh.lds)));
+            sh.cls = force1 ? 1 : (force2 ? 2 : std::min(kMaxPerCu, blocks_per_cu(sh.lds)));
             sh.work = (double)(wh - s + 1) * (double)(ww - s + 1);
-            if (rp) sh.nat_pitch = sid::rp_lds_layout(wh, ww, s, K <= sid::kRpGroup, rp_rows(rpp, sh.band)).wpitch;
+            if (rp) sh.nat_pitch = sid::rp_lds_layout(wh, ww, s, K <= sid::kRpGroup, rp_rows(rpp, sh.band), 0, sid::rp_tab_pitch(rpp)).wpitch;
             k = (int)shapes.size();
             shapes.push_back(sh);
         }
@@ -375,7 +379,7 @@ int classify_points(sid_pm_ctx *ctx)
             if (pitch && !sid::rp_pitch_instantiated(first.band, rpp, pitch)) pitch = 0;
             for (size_t i = a; i < b && pitch; ++i) {
                 const Shape &sh = shapes[(size_t)ord[i]];
-                if (sh.wh > 0 && std::min(8, blocks_per_cu(lds_need(rp, rpp, sh.wh, sh.ww, s, K, sh.band, pitch))) < first.cls) pitch = 0;
+                if (sh.wh > 0 && std::min(kMaxPerCu, blocks_per_cu(lds_need(rp, rpp, sh.wh, sh.ww, s, K, sh.band, pitch))) < first.cls) pitch = 0;
             }
             if (pitch)
                 for (size_t i = a; i < b; ++i) {
@@ -434,6 +438,10 @@ int classify_points(sid_pm_ctx *ctx)
         HIP_TRY(hipMemcpyAsync(ctx->d_order, order.data(), sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
         HIP_TRY(hipStreamSynchronize(ctx->stream));               // `order` is a local
     }
+    if (getenv("SID_PM_VERBOSE") != nullptr)                          // the launches of a step, one line each
+        for (const Bucket &b : ctx->buckets)
+            fprintf(stderr, "sid_pm: launch of %d points, %d B of LDS (%d per CU), band %d, window pitch %d\n", b.count, b.lds,
+                    blocks_per_cu(b.lds), b.band, b.pitch);
     ctx->cls_rows2 = rows2; ctx->cls_cols2 = cols2;
     const double img_bytes = (double)ctx->cur[0].rows * ctx->cur[0].cols + (double)rows2 * cols2;
     ctx->info[0] = (double)ctx->buckets.size();
@@ -924,7 +932,7 @@ SID_EXPORT int sid_pm_estimate_cost(const double *border, int64_t n, int img_siz
         if (r < 2) { cost_ns[i] = kFixed; continue; }
         double sweep, winner, cls_factor;
         if (rp) {
-            const sid::RpLdsLayout L4 = sid::rp_lds_layout(wn, wn, s, K <= sid::kRpGroup, rp_rows(rpp, 4));
+            const sid::RpLdsLayout L4 = sid::rp_lds_layout(wn, wn, s, K <= sid::kRpGroup, rp_rows(rpp, 4), 0, sid::rp_tab_pitch(rpp));
             int per_cu = blocks_per_cu(L4.total), band = 4;
             if (!rpp && per_cu == 2 && blocks_per_cu(sid::rp_lds_layout(wn, wn, s, K <= sid::kRpGroup, 8).total) >= 2) band = 8;
             const int rows = rp_rows(rpp, band), nb = (r + rows - 1) / rows, tiles = 2 * L4.npair + L4.nsingle;

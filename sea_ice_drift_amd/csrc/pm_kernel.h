@@ -106,7 +106,7 @@ struct RpLdsLayout {
     int win_off, sii_off;
     int wp_off, wp_pitch, wp_rows, wp_len;   // column-pair copy: wp_rows rows (u = 32 + row) of wp_len entries (2 B each)
     int u_off;                  // union: column sums | table + strip + patch + queue | winner operands + NCC matrix
-    int tab_rows;               // s + 3 rows of 512 B
+    int tab_rows, tab_pitch;    // s + 3 rows of tab_pitch bytes (32 per stored slot)
     int strip_off, ncp, nrg;    // strip operand fragments: ncp column pairs x nrg row groups, 1 KB each
     int patch_off, ppitch, pdim, pradius, queue_off, trow_bytes;
     int npair, nsingle;         // x tiling of a band: npair items of 32 placements, then nsingle (0/1) of 16
@@ -131,7 +131,15 @@ __host__ __device__ inline int rp_band_y0(int b, int nbands, int rh, int band)
 // band: output rows per sweep work item (4, or 8 for the two-workgroups-per-CU class).
 // force_pitch: window pitch fixed by the launch class (a compile-time constant of the kernel instantiation: rp_class_pitch);
 // 0 = the natural pitch.  A forced pitch below the natural one is ignored (the kernel then refuses the point).
-__host__ __device__ inline RpLdsLayout rp_lds_layout(int wh, int ww, int s, bool one_group, int band = 4, int force_pitch = 0)
+// largest LDS footprint with the same number of workgroups per CU as `lds_bytes` (1280-byte granules of the 160 KB:
+// 42 granules each for three - the register budget allows no more -, 64 for two)
+__host__ __device__ constexpr int rp_class_limit(int lds_bytes) { return lds_bytes <= 42 * 1280 ? 42 * 1280 : lds_bytes <= 64 * 1280 ? 64 * 1280 : 128 * 1280; }
+// tab_pitch: bytes per operand-table row = 32 x (slots that hold distinct operands): 512, or rp_tab_pitch(paired) with slot
+// groups - the lanes of the later groups read the first group's operands at a lagging address, so only those are stored
+__host__ __device__ constexpr int rp_tab_pitch(int paired) { return paired == 2 ? 128 : paired == 1 ? 256 : 512; }
+__host__ __device__ constexpr int rp_tab_shift(int paired) { return paired == 2 ? 7 : paired == 1 ? 8 : 9; }
+__host__ __device__ inline RpLdsLayout rp_lds_layout(int wh, int ww, int s, bool one_group, int band = 4, int force_pitch = 0,
+                                                     int tab_pitch = 512)
 {
     RpLdsLayout L;
     const int rh = wh - s + 1, rw = ww - s + 1;
@@ -162,26 +170,43 @@ __host__ __device__ inline RpLdsLayout rp_lds_layout(int wh, int ww, int s, bool
     L.wp_pitch = round_up(2 * L.wp_len, 8);
     if (!((L.wp_pitch / 8) & 1)) L.wp_pitch += 8;    // 8 x odd: at most two-way bank conflicts for the lane-private rows
     L.tab_rows = s + 3;
-    L.strip_off = L.u_off + L.tab_rows * 512;
+    L.tab_pitch = tab_pitch;
+    L.strip_off = L.u_off + L.tab_rows * tab_pitch;
     const int tc = s / 2 + 1;
     int r = 0;
     while (r * r < 2 * tc * tc) ++r;
     L.pradius = r + 1;
     L.pdim = 2 * L.pradius + 2;
     L.ppitch = round_up(L.pdim, 4);
-    L.patch_off = L.strip_off + L.ncp * L.nrg * 1024 + 16;      // + 16 scratch bytes
-    const int patch_end = round_up(L.patch_off + L.pdim * L.ppitch + 1, 16);
-    L.queue_off = one_group ? round_up(L.patch_off, 16) : patch_end;
     L.trow_bytes = 4096;                            // half of the 8 KB the row-pair winner's operands take (rp_winner_stage)
-    // the column-pair copy only lives during the sweep: behind the queue, inside the union (built after the
-    // column sums are dead, overwritten by the winner's NCC matrix)
-    L.wp_off = round_up(L.queue_off + kQueueCap * 16, 16);
-    if (L.wp_off < patch_end) L.wp_off = patch_end;              // (the column-pair copy is built while the patch is live)
-    int u = rh * ww * 4;
-    const int sweep = L.wp_off + L.wp_rows * L.wp_pitch - L.u_off;
-    if (u < sweep) u = sweep;
-    if (u < 2 * L.trow_bytes + rh * rw * 4) u = 2 * L.trow_bytes + rh * rw * 4;
-    L.total = round_up(L.u_off + u, 16);
+    // Everything behind the strip operands, for a given patch offset.  The image-1 patch (and the column-pair copy) can be
+    // loaded together with the window only where they do not lie on the column sums (pm_kernel_rp: patch_early); with a
+    // short operand table (slot groups) the natural place does, so the patch is moved up behind the column sums - unless
+    // the larger footprint would cost a workgroup per CU.
+    auto place = [&](int patch_off) {
+        L.patch_off = patch_off;
+        const int patch_end = round_up(L.patch_off + L.pdim * L.ppitch + 1, 16);
+        L.queue_off = one_group ? round_up(L.patch_off, 16) : patch_end;
+        // the column-pair copy only lives during the sweep: behind the queue, inside the union (built after the
+        // column sums are dead, overwritten by the winner's NCC matrix)
+        L.wp_off = round_up(L.queue_off + kQueueCap * 16, 16);
+        if (L.wp_off < patch_end) L.wp_off = patch_end;          // (the column-pair copy is built while the patch is live)
+        int u = rh * ww * 4;
+        const int sweep = L.wp_off + L.wp_rows * L.wp_pitch - L.u_off;
+        if (u < sweep) u = sweep;
+        // winner: operands + NCC matrix, and (one group of angles: the fused Hessian, pm_kernel_rp prologue) 5 KB of
+        // histogram and key list behind them
+        const int winner = 2 * L.trow_bytes + round_up(rh * rw * 4, 16) + (one_group ? 5120 : 0);
+        if (u < winner) u = winner;
+        L.total = round_up(L.u_off + u, 16);
+    };
+    const int natural = L.strip_off + L.ncp * L.nrg * 1024 + 16, clear = round_up(L.u_off + rh * ww * 4, 16);   // (+ 16 scratch bytes)
+    place(natural);
+    if (tab_pitch < 512 && clear > natural) {                    // (full table: measured no gain at the borders it would change)
+        const int limit = rp_class_limit(L.total);
+        place(clear);
+        if (L.total > limit) place(natural);
+    }
     return L;
 }
 

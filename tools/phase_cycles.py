@@ -8,7 +8,8 @@ from sea_ice_drift_amd.pmlib import rotation_table
 
 img1, img2 = syn.make_pair(1000, 1000)
 g = syn.make_grid(1000, 1000, 10, border=20)
-angles = list(range(-7, 8))
+_A = int(os.environ.get('SID_PHASE_ANGLES', '7'))
+angles = list(range(-_A, _A + 1))
 rot = rotation_table(angles, 0.0, 34)
 names = ['P0a window', 'P1 sums', 'P0b templates', 'P2 sweep', 'P3 argmax', 'P4 winner', 'P5 hessian']
 with _capi.PMContext(0) as ctx:
