@@ -51,7 +51,7 @@ struct Image {
     int64_t rows = 0, cols = 0, stride = 0;
 };
 
-struct Bucket { int offset, count, lds, band, pitch; };   // band: output rows per sweep work item of this launch (4 or 8); pitch: compile-time window pitch of the row-pair kernel (0: run-time)
+struct Bucket { int offset, count, lds, band, pitch, occ; };   // occ: wavefronts per SIMD of the kernel build (3; 4: the four-per-CU class of the slot-group layouts); band: output rows per sweep work item of this launch (4 or 8); pitch: compile-time window pitch of the row-pair kernel (0: run-time)
 
 template <typename T>
 struct DevBuf {
@@ -177,8 +177,10 @@ int make_samp(const std::vector<double> &rot, int K, int s, std::vector<uint16_t
 // Workgroups of `lds` bytes that fit one CU.  gfx950 hands LDS out in 1280-byte granules (160 KB / 128;
 // measured with tools/ubench/lds_granule.hip: 53760 B -> 3 per CU, 53761 B -> 2).
 // workgroups of four wavefronts a CU takes at the kernels' register budget (3 wavefronts per SIMD): launch classes beyond
-// this differ in nothing
+// this differ in nothing.  The row-pair kernel's slot-group layouts (<= 7 angles) have a 128-VGPR build as well, for the
+// borders whose LDS footprint fits four times (SID_PM_NO_OCC4=1: off; A/B runs).
 constexpr int kMaxPerCu = 3;
+int max_per_cu(bool rp, int rpp) { return (rp && rpp > 0 && getenv("SID_PM_NO_OCC4") == nullptr) ? 4 : kMaxPerCu; }
 
 int blocks_per_cu(int lds)
 {
@@ -315,7 +317,7 @@ int classify_points(sid_pm_ctx *ctx)
     };
     const int lds_min = lds_need(rp, rpp, s + 1, s + 1, s, K);
     {   // shape 0: points whose window does not lie inside image 2 (they write NaN at once; minimal footprint)
-        Shape z{0, 0, lds_min, 4, std::min(kMaxPerCu, blocks_per_cu(lds_min)), 0, 0, 0.0, {}};
+        Shape z{0, 0, lds_min, 4, std::min(kMaxPerCu, blocks_per_cu(lds_min)), 0, 0, 0.0, {}};   // (NaN writers: any class)
         shapes.push_back(z);
     }
     double macs = 0, bytes = 0, valid = 0;
@@ -340,7 +342,7 @@ int classify_points(sid_pm_ctx *ctx)
                 if (blocks_per_cu(need8) >= 2) { sh.lds = need8; sh.band = 8; force2 = true; }
                 else force1 = true;
             }
-            sh.cls = force1 ? 1 : (force2 ? 2 : std::min(kMaxPerCu, blocks_per_cu(sh.lds)));
+            sh.cls = force1 ? 1 : (force2 ? 2 : std::min(max_per_cu(rp, rpp), blocks_per_cu(sh.lds)));
             sh.work = (double)(wh - s + 1) * (double)(ww - s + 1);
             if (rp) sh.nat_pitch = sid::rp_lds_layout(wh, ww, s, K <= sid::kRpGroup, rp_rows(rpp, sh.band), 0, sid::rp_tab_pitch(rpp)).wpitch;
             k = (int)shapes.size();
@@ -379,7 +381,7 @@ int classify_points(sid_pm_ctx *ctx)
             if (pitch && !sid::rp_pitch_instantiated(first.band, rpp, pitch)) pitch = 0;
             for (size_t i = a; i < b && pitch; ++i) {
                 const Shape &sh = shapes[(size_t)ord[i]];
-                if (sh.wh > 0 && std::min(kMaxPerCu, blocks_per_cu(lds_need(rp, rpp, sh.wh, sh.ww, s, K, sh.band, pitch))) < first.cls) pitch = 0;
+                if (sh.wh > 0 && std::min(max_per_cu(rp, rpp), blocks_per_cu(lds_need(rp, rpp, sh.wh, sh.ww, s, K, sh.band, pitch))) < first.cls) pitch = 0;
             }
             if (pitch)
                 for (size_t i = a; i < b; ++i) {
@@ -418,7 +420,8 @@ int classify_points(sid_pm_ctx *ctx)
         lds_max = std::max(lds_max, lds_run);
         if (ctx->buckets.empty() || ctx->buckets.back().band != first.band || ctx->buckets.back().pitch != first.pitch ||
             ctx->info[5] != (double)first.cls)
-            ctx->buckets.push_back(Bucket{(int)order.size(), 0, 0, first.band, first.pitch});
+            ctx->buckets.push_back(Bucket{(int)order.size(), 0, 0, first.band, first.pitch,
+                                          (rp && first.cls >= 4 && sid::rp_pitch_instantiated(first.band, rpp, first.pitch, 4)) ? 4 : 3});
         ctx->info[5] = (double)first.cls;                             // (class of the bucket being filled)
         Bucket &bk = ctx->buckets.back();
         bk.count += (int)src->size();
@@ -440,8 +443,8 @@ int classify_points(sid_pm_ctx *ctx)
     }
     if (getenv("SID_PM_VERBOSE") != nullptr)                          // the launches of a step, one line each
         for (const Bucket &b : ctx->buckets)
-            fprintf(stderr, "sid_pm: launch of %d points, %d B of LDS (%d per CU), band %d, window pitch %d\n", b.count, b.lds,
-                    blocks_per_cu(b.lds), b.band, b.pitch);
+            fprintf(stderr, "sid_pm: launch of %d points, %d B of LDS (%d per CU), band %d, window pitch %d, %d wavefronts per SIMD\n",
+                    b.count, b.lds, std::min(b.occ, blocks_per_cu(b.lds)), b.band, b.pitch, b.occ);
     ctx->cls_rows2 = rows2; ctx->cls_cols2 = cols2;
     const double img_bytes = (double)ctx->cur[0].rows * ctx->cur[0].cols + (double)rows2 * cols2;
     ctx->info[0] = (double)ctx->buckets.size();
@@ -680,7 +683,7 @@ SID_EXPORT int sid_pm_run(sid_pm_ctx *ctx)
         const int per_cu = std::max(1, std::min(b.band == 8 ? 2 : 8, blocks_per_cu(b.lds)));
         const int nthreads = b.band == 8 ? 256 : (per_cu == 1 ? 768 : 256);
         const int e = ctx->rp
-                          ? sid::launch_pm_rp(A, lds_launch, nthreads, b.band, ctx->rp_paired, b.pitch, ctx->stream)
+                          ? sid::launch_pm_rp(A, lds_launch, nthreads, b.band, ctx->rp_paired, b.pitch, b.occ, ctx->stream)
                           : sid::launch_pm_mfma(A, lds_launch, nthreads, b.band, use_paired(ctx->n_angles), ctx->stream);
         if (e != 0) return fail(SID_PM_ERR_HIP, "kernel launch failed: %s", hipGetErrorString((hipError_t)e));
     }
@@ -836,7 +839,7 @@ SID_EXPORT int sid_pm_debug_point(sid_pm_ctx *ctx, double c1, double r1, double 
         gauss_taps(A.gauss_w);
         A.samp = sampv.empty() ? nullptr : dsamp.p; A.samp_nflag = nflag;
         A.lds_bytes = lds;
-        step((hipError_t)(rp ? sid::launch_pm_rp(A, lds, 256, 4, rpp, 0, ctx->stream)
+        step((hipError_t)(rp ? sid::launch_pm_rp(A, lds, 256, 4, rpp, 0, 3, ctx->stream)
                                        : sid::launch_pm_mfma(A, lds, 256, 4, use_paired(K), ctx->stream)));
         step(hipStreamSynchronize(ctx->stream));
         if (templates) step(hipMemcpy(templates, dt.p, tcount, hipMemcpyDeviceToHost));
@@ -924,7 +927,7 @@ SID_EXPORT int sid_pm_estimate_cost(const double *border, int64_t n, int img_siz
     const int rpp = rp ? rp_paired(K) : 0;
     const int hws = (int)((double)s / 2.0);
     const int groups = (K + sid::kRpGroup - 1) / sid::kRpGroup;
-    constexpr double kSweep = 7.06e-3, kWinner = 8.64e-3, kPos = 3.28e-3, kFixed = 43.3, kTwoPerCu = 1.32, kOnePerCu = 1.69;
+    constexpr double kSweep = 7.06e-3, kWinner = 8.64e-3, kPos = 3.28e-3, kFixed = 43.3, kTwoPerCu = 1.32, kOnePerCu = 1.69, kFourPerCu = 0.93;
     for (int64_t i = 0; i < n; ++i) {
         const double b = border[i];
         if (!(b >= 0.0 && b < 4096.0)) { cost_ns[i] = kFixed; continue; }      // NaN / absurd: a point that writes NaN at once
@@ -942,7 +945,7 @@ SID_EXPORT int sid_pm_estimate_cost(const double *border, int64_t n, int img_siz
             const int units = ((nb * tiles + nwaves - 1) / nwaves) * nwaves, wunits = ((((r + 15) / 16) * tiles + nwaves - 1) / nwaves) * nwaves;
             sweep = groups * (rpp == 2 ? 0.33 : rpp == 1 ? 0.55 : 1.0) * units * (rows * per_row_tile + 2.0);
             winner = wunits * 76.0;
-            cls_factor = per_cu >= 3 ? 1.0 : per_cu == 2 ? kTwoPerCu : kOnePerCu;
+            cls_factor = (per_cu >= 4 && max_per_cu(rp, rpp) == 4) ? kFourPerCu : per_cu >= 3 ? 1.0 : per_cu == 2 ? kTwoPerCu : kOnePerCu;
         } else {
             const sid::MfmaLdsLayout L = sid::mfma_lds_layout(wn, wn, s, 4, use_paired(K));
             const int per_cu = blocks_per_cu(L.total), ntx = (r + 15) / 16;

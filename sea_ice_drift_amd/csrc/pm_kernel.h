@@ -131,9 +131,12 @@ __host__ __device__ inline int rp_band_y0(int b, int nbands, int rh, int band)
 // band: output rows per sweep work item (4, or 8 for the two-workgroups-per-CU class).
 // force_pitch: window pitch fixed by the launch class (a compile-time constant of the kernel instantiation: rp_class_pitch);
 // 0 = the natural pitch.  A forced pitch below the natural one is ignored (the kernel then refuses the point).
-// largest LDS footprint with the same number of workgroups per CU as `lds_bytes` (1280-byte granules of the 160 KB:
-// 42 granules each for three - the register budget allows no more -, 64 for two)
-__host__ __device__ constexpr int rp_class_limit(int lds_bytes) { return lds_bytes <= 42 * 1280 ? 42 * 1280 : lds_bytes <= 64 * 1280 ? 64 * 1280 : 128 * 1280; }
+// largest LDS footprint with the same number of workgroups per CU as `lds_bytes` (1280-byte granules of the 160 KB: 32
+// granules each for four - slot-group layouts, whose 128-VGPR build allows them -, 42 for three, 64 for two)
+__host__ __device__ constexpr int rp_class_limit(int lds_bytes)
+{
+    return lds_bytes <= 32 * 1280 ? 32 * 1280 : lds_bytes <= 42 * 1280 ? 42 * 1280 : lds_bytes <= 64 * 1280 ? 64 * 1280 : 128 * 1280;
+}
 // tab_pitch: bytes per operand-table row = 32 x (slots that hold distinct operands): 512, or rp_tab_pitch(paired) with slot
 // groups - the lanes of the later groups read the first group's operands at a lagging address, so only those are stored
 __host__ __device__ constexpr int rp_tab_pitch(int paired) { return paired == 2 ? 128 : paired == 1 ? 256 : 512; }
@@ -217,8 +220,9 @@ __host__ __device__ inline int rp_class_pitch(int natural)
     return natural <= 104 ? 104 : natural <= 136 ? 136 : natural <= 168 ? 168 : 0;
 }
 // paired: 0 = one group of 16 slots, 1 = two groups (at most 7 angles), 2 = four groups (at most 3 angles)
-int launch_pm_rp(const PMArgs &args, int lds_bytes, int nthreads, int band, int paired, int pitch, void *stream);
-bool rp_pitch_instantiated(int band, int paired, int pitch);
+// occ: wavefronts per SIMD the build allows - 3, or 4 (128 VGPRs; slot groups with pitch 104 only: four workgroups per CU)
+int launch_pm_rp(const PMArgs &args, int lds_bytes, int nthreads, int band, int paired, int pitch, int occ, void *stream);
+bool rp_pitch_instantiated(int band, int paired, int pitch, int occ = 3);
 
 __host__ __device__ inline int samp_pitch(int s) { return round_up(s, 4); }
 constexpr double kSampGuard = 1e-5;   // table entries whose coordinate is this close to k + 1/2 are flagged

@@ -50,10 +50,19 @@ typedef int v4i __attribute__((ext_vector_type(4)));
 
 // Threads per grid point are chosen at launch: 256, or 768 for the LDS-footprint class that fits one
 // point per CU only (12 wavefronts = 3 per SIMD, the register budget).
+#ifdef SID_OCC4_TU
+// pm_kernel_rp_occ4.hip compiles this file a second time for the launches whose LDS footprint fits FOUR workgroups per CU
+// (row-pair kernel with slot groups, borders 20 and 21): 128 VGPRs, 256 threads.  A translation unit of its own because
+// the register budget of a kernel is handed down to the non-inlined phase functions it calls: instantiated side by side,
+// the 128-VGPR kernels slowed the 168-VGPR ones by 0.9 %.
+constexpr int kMaxBlockM = 256;
+constexpr int kOccM = 4;
+#else
 constexpr int kMaxBlockM = 768;
+constexpr int kOccM = 3;             // wavefronts per SIMD the register allocation must allow
+#endif
 #define kBlockM ((int)blockDim.x)
 #define kWavesM ((int)(blockDim.x >> 6))
-constexpr int kOccM = 3;             // wavefronts per SIMD the register allocation must allow
 constexpr int kSlots = 16;           // MFMA M: 15 angles + ones
 constexpr int kAnglesPerGroup = kRpGroup;
 constexpr float kMargin = 1e-5f;     // pre-filter margin (see header)
@@ -1872,6 +1881,7 @@ __global__ __launch_bounds__(BAND == 8 ? 512 : kMaxBlockM, BAND == 8 ? 2 : kOccM
 
 #include "pm_kernel_rp.inc"
 
+#ifndef SID_OCC4_TU
 // exact_from_sums_fast against exact_from_sums on pseudo-random sums of plausible windows (diagnostic):
 // out[0] = evaluations, out[1] = results that differ, out[2] = evaluations that took the spec's route
 __global__ void ncc_selftest_kernel(unsigned long long seed, int per_thread, int s, unsigned long long *out)
@@ -1940,7 +1950,21 @@ __global__ void rsqrt_kernel(const double *x, double *y, int64_t n)
     if (i < n) y[i] = 1.0 / sqrt(x[i]);
 }
 
+#endif  // SID_OCC4_TU
+
 }  // namespace
+
+#ifdef SID_OCC4_TU
+// the only export of the second compilation: its kernels (slot groups, window pitch 104)
+void (*rp_occ4_kernel(int img_size, int paired, int pitch))(const PMArgs)
+{
+    if (pitch != 104 || (paired != 1 && paired != 2)) return nullptr;
+    if (img_size == 34) return paired == 2 ? pm_kernel_rp<34, 4, 2, 104> : pm_kernel_rp<34, 4, 1, 104>;
+    if (img_size == 35) return paired == 2 ? pm_kernel_rp<35, 4, 2, 104> : pm_kernel_rp<35, 4, 1, 104>;
+    return nullptr;
+}
+#else
+void (*rp_occ4_kernel(int img_size, int paired, int pitch))(const PMArgs);   // pm_kernel_rp_occ4.hip
 
 int max_lds_bytes() { return 160 * 1024; }
 
@@ -2023,20 +2047,24 @@ static void (*rp_kernel_for(int band, int paired, int pitch))(const PMArgs)
          : pitch == 168 ? pm_kernel_rp<S, 4, 0, 168> : pitch == 0 ? pm_kernel_rp<S, 4, 0, 0> : nullptr;
 }
 
-// true when launch_pm_rp carries an instantiation with this compile-time window pitch (0 = run-time pitch: always)
-bool rp_pitch_instantiated(int band, int paired, int pitch)
+// true when launch_pm_rp carries an instantiation with this compile-time window pitch (0 = run-time pitch: always) and
+// register budget (occ = 3 wavefronts per SIMD, or 4: pm_kernel_rp_occ4.hip)
+bool rp_pitch_instantiated(int band, int paired, int pitch, int occ)
 {
+    if (occ == 4) return band == 4 && rp_occ4_kernel(34, paired, pitch) != nullptr;
     return rp_kernel_for<34>(band, paired, pitch) != nullptr;
 }
 
-int launch_pm_rp(const PMArgs &args, int lds_bytes, int nthreads, int band, int paired, int pitch, void *stream)
+int launch_pm_rp(const PMArgs &args, int lds_bytes, int nthreads, int band, int paired, int pitch, int occ, void *stream)
 {
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (args.n_launch <= 0) return (int)hipSuccess;
     if (!rp_size_supported(args.img_size)) return (int)hipErrorInvalidValue;
     if ((band != 4 && band != 8) || (band == 8 && nthreads != 256)) return (int)hipErrorInvalidValue;
+    if ((occ != 3 && occ != 4) || (occ == 4 && (nthreads != 256 || band != 4))) return (int)hipErrorInvalidValue;
     if (paired && (band != 4 || args.n_angles > (paired == 2 ? kQuadMaxAngles : kPairedMaxAngles))) return (int)hipErrorInvalidValue;
-    void (*kern)(const PMArgs) = args.img_size == 34 ? rp_kernel_for<34>(band, paired, pitch) : rp_kernel_for<35>(band, paired, pitch);
+    void (*kern)(const PMArgs) = occ == 4 ? rp_occ4_kernel(args.img_size, paired, pitch)
+                               : args.img_size == 34 ? rp_kernel_for<34>(band, paired, pitch) : rp_kernel_for<35>(band, paired, pitch);
     if (!kern) return (int)hipErrorInvalidValue;
     const hipError_t e = allow_max_lds(kern);
     if (e != hipSuccess) return (int)e;
@@ -2044,5 +2072,6 @@ int launch_pm_rp(const PMArgs &args, int lds_bytes, int nthreads, int band, int 
     hipLaunchKernelGGL(kern, dim3(args.n_launch), dim3(nthreads), lds_bytes, st, args);
     return (int)hipGetLastError();
 }
+#endif  // SID_OCC4_TU
 
 }  // namespace sid

@@ -51,6 +51,33 @@ def test_small_pair_matches_oracle(pm_ctx, c_oracle, s, alpha0, angles):
     assert_parity(got, got_ij, exp, exp_ij)
 
 
+@pytest.mark.parametrize('s,angles', [(34, ANGLES7), (34, [-3, 0, 3]), (35, [-3, 0, 3])])
+def test_four_per_cu_build_equals_the_three_per_cu_build_and_the_oracle(pm_ctx, c_oracle, monkeypatch, s, angles):
+    """Slot-group layouts at borders 20 and 21 fit four workgroups per CU and run the 128-VGPR build of the row-pair kernel
+    (pm_kernel_rp_occ4.hip); borders 22 .. 30 exercise the short operand table in the other launch classes.  Both builds
+    against the oracle, and bit-identical to each other (SID_PM_NO_OCC4 is read at every set_points)."""
+    img1, img2 = syn.make_pair(900, 900, seed=11)
+    g = syn.make_grid(900, 900, 14, margin=120)
+    n = len(g['c1'])
+    border = np.array([20, 21, 20, 22, 26, 21, 30, 20][:8] * (n // 8 + 1), dtype=np.float64)[:n]
+    rot = rot_for(angles, 0.0, s)
+    exp, exp_ij = c_oracle.pm_batch(img1, img2, g['c1'], g['r1'], g['c2fg'], g['r2fg'], border, s, 0.0, angles, rot=rot,
+                                    nthreads=8)
+    pm_ctx.upload_pair(img1, img2)
+    res = []
+    for no_occ4 in (False, True):
+        if no_occ4:
+            monkeypatch.setenv('SID_PM_NO_OCC4', '1')
+        pm_ctx.set_points(g['c1'], g['r1'], g['c2fg'], g['r2fg'], border, s, 0.0, angles, rot=rot)
+        pm_ctx.run()
+        got, got_ij = pm_ctx.fetch()
+        assert_parity(got, got_ij, exp, exp_ij)
+        res.append((got.copy(), got_ij.copy(), pm_ctx.work_info()['launches']))
+    np.testing.assert_array_equal(res[0][0], res[1][0])
+    np.testing.assert_array_equal(res[0][1], res[1][1])
+    assert res[0][2] > res[1][2]                     # borders 20 and 21 were a launch of their own
+
+
 def test_sampling_table_flagged_entries_and_fractional_centres(pm_ctx, c_oracle):
     """The offset table serves integral template centres; entries whose coordinate sits on a rounding
     boundary are flagged and recomputed per point (forced here with tc.T = 17.5: every row coordinate is
