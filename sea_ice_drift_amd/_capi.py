@@ -206,7 +206,11 @@ class PMContext(object):
             lib().sid_pm_destroy(self._h)
             self._h = C.c_void_p()
 
-    __del__ = close
+    def __del__(self):
+        try:
+            self.close()
+        except TypeError:                                  # interpreter shutdown: the module globals are already gone
+            pass
 
     def __enter__(self):
         return self
@@ -410,7 +414,11 @@ class StageWorkspace(object):
             lib().sid_stage_destroy(self._h)
             self._h = C.c_void_p()
 
-    __del__ = close
+    def __del__(self):
+        try:
+            self.close()
+        except TypeError:                                  # interpreter shutdown: the module globals are already gone
+            pass
 
     def begin(self, ptr, rows, cols, stride, stream=0):
         """First pass: number of non-NaN pixels; keeps the leading-digit histogram for order_stats."""

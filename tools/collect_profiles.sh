@@ -7,19 +7,7 @@ R=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-python3 $R/bench.py --steps 20 --warmup 3 > $OUT/bench.json 2> $OUT/bench.err
-for cfg in "--border 20" "--border 50" "--angles 3" "--border 20 --angles 3" "--angles 1" "--border 20 --angles 1" "--img-size 35" "--img-size 35 --angles 1"; do
-  python3 $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline $cfg 2>/dev/null | python3 -c "
-import sys, json
-d = json.loads(sys.stdin.read())
-print(json.dumps({'args': '$cfg', 'ms_per_step': d['ms_per_step'], 'value': d['value'], 'workload': d['config']['workload'], 'mfma_frac': d['roofline']['frac'], 'parity_check': d['parity_check']}))" >> $OUT/other_configs.jsonl
-done
-python3 $R/bench.py --mode stream --pairs 16 --steps 2 --warmup 1 --check 32 > $OUT/stream_bench.json 2>> $OUT/bench.err
-python3 $R/bench.py --gpus 2 --steps 5 --warmup 1 --no-cpu-baseline > $OUT/dryrun_2ranks_1gpu.json 2>> $OUT/bench.err
-python3 $R/bench.py --gpus 1 --force-collective --steps 20 --warmup 3 --no-cpu-baseline > $OUT/force_collective_rccl_1gpu.json 2>> $OUT/bench.err
-python3 $R/bench.py --mode ftpm --check 400 > $OUT/ftpm_bench.json 2>> $OUT/bench.err
-rocprofv3 --kernel-trace --stats -d /tmp/kt_$TAG -o kt -- python3 $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
-python3 $R/tools/rocpd_summary.py $(find /tmp/kt_$TAG -name "*.db" | head -1) > $OUT/kernel_trace_stats.txt
+# HBM traffic first: bench.py quotes profiles/traffic.json and checks that it was collected on the library it runs
 rocprofv3 --pmc FETCH_SIZE -d /tmp/pf_$TAG -o pf -- python3 $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE -d /tmp/pw_$TAG -o pw -- python3 $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
 python3 $R/tools/pmc_traffic.py $(find /tmp/pf_$TAG -name "*.db" | head -1) $(find /tmp/pw_$TAG -name "*.db" | head -1) pm_kernel > $OUT/pmc_traffic.json
@@ -40,6 +28,20 @@ print(json.dumps({
  'source': 'rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `python3 bench.py --steps 4 --warmup 1 --no-cpu-baseline` (%d dispatches), summed with tools/pmc_traffic.py (tools/collect_profiles.sh)' % disp,
  'note': 'fetch: search windows, image-1 patches, sampling table; write: 52 B of results per point (+ callee-saved register saves); algorithmic bytes = both images once (0.2 GB per step)'}, indent=1))
 PY
+cp $OUT/traffic.json $R/profiles/traffic.json
+python3 $R/bench.py --steps 20 --warmup 3 > $OUT/bench.json 2> $OUT/bench.err
+for cfg in "--border 20" "--border 50" "--angles 3" "--border 20 --angles 3" "--angles 1" "--border 20 --angles 1" "--img-size 35" "--img-size 35 --angles 1"; do
+  python3 $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline $cfg 2>/dev/null | python3 -c "
+import sys, json
+d = json.loads(sys.stdin.read())
+print(json.dumps({'args': '$cfg', 'ms_per_step': d['ms_per_step'], 'value': d['value'], 'workload': d['config']['workload'], 'mfma_frac': d['roofline']['frac'], 'parity_check': d['parity_check']}))" >> $OUT/other_configs.jsonl
+done
+python3 $R/bench.py --mode stream --pairs 16 --steps 2 --warmup 1 --check 32 > $OUT/stream_bench.json 2>> $OUT/bench.err
+python3 $R/bench.py --gpus 2 --steps 5 --warmup 1 --no-cpu-baseline > $OUT/dryrun_2ranks_1gpu.json 2>> $OUT/bench.err
+python3 $R/bench.py --gpus 1 --force-collective --steps 20 --warmup 3 --no-cpu-baseline > $OUT/force_collective_rccl_1gpu.json 2>> $OUT/bench.err
+python3 $R/bench.py --mode ftpm --check 400 > $OUT/ftpm_bench.json 2>> $OUT/bench.err
+rocprofv3 --kernel-trace --stats -d /tmp/kt_$TAG -o kt -- python3 $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
+python3 $R/tools/rocpd_summary.py $(find /tmp/kt_$TAG -name "*.db" | head -1) > $OUT/kernel_trace_stats.txt
 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU -d /tmp/p1_$TAG -o p1 -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
 rocprofv3 --pmc SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_LDS -d /tmp/p2_$TAG -o p2 -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
 rocprofv3 --pmc SQ_VALU_MFMA_COEXEC_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_CYCLES -d /tmp/p3_$TAG -o p3 -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
