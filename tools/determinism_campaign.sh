@@ -18,4 +18,11 @@ run 10000 60 --angles 3
 SID_PM_NO_RP=1 run 4000 300 --angles 7
 SID_PM_NO_RP=1 run 4000 300 --angles 3
 run 4000 200 --angles 10 --img-size 40
+# round 3: the four-per-CU class of the slot-group layouts (128-VGPR build) and the short operand table
+run 4000 400 --angles 3 --border 20
+run 4000 400 --angles 1 --border 21
+run 4000 300 --angles 1 --no-table
+run 4000 300 --angles 1 --img-size 35
+run 4000 200 --angles 3 --border 26
+run 4000 200 --angles 1 --border 38
 cat $OUT
