@@ -95,8 +95,9 @@ __global__ __launch_bounds__(256) void k_locate(const Simp *simp, int64_t ns, in
 
 // doubt[i] = 1: the caller must not trust out[i] / simplex[i] (see kTol); also set when a value comes within 1e-6 of a
 // half-integer (the reference rounds the first guess next, pmlib.py:285-288: a last-bit difference could tip it)
+// The flagged queries are also appended to list[] (count: *nlist; any order) for k_resolve.
 __global__ void k_eval(const Simp *simp, const int32_t *loc, const int32_t *near, const double *values, const double *q, int64_t nq,
-                       double *out, int32_t *simplex, int32_t *doubt)
+                       double *out, int32_t *simplex, int32_t *doubt, int32_t *list, int32_t *nlist)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nq) return;
@@ -115,8 +116,9 @@ __global__ void k_eval(const Simp *simp, const int32_t *loc, const int32_t *near
         dbt = (fmin(c0, fmin(c1, c2)) < kTol || h0 < 1e-6 || h1 < 1e-6 || !(fabs(o0) < 1e15) || !(fabs(o1) < 1e15)) ? 1 : 0;
     }
     out[2 * i] = o0; out[2 * i + 1] = o1;
-    if (simplex) simplex[i] = k == 0x7f7f7f7f ? -1 : k;
-    if (doubt) doubt[i] = dbt;
+    simplex[i] = k == 0x7f7f7f7f ? -1 : k;
+    doubt[i] = dbt;
+    if (dbt) list[atomicAdd(nlist, 1)] = (int32_t)i;
 }
 
 // Second look at the flagged queries (k_eval: on an edge, a vertex or the hull), against EVERY simplex, no early exit.  A
@@ -126,39 +128,56 @@ __global__ void k_eval(const Simp *simp, const int32_t *loc, const int32_t *near
 // integers (a shared vertex or edge interpolates to the same value from either side, up to the last bits); (c) no such
 // value lies within 1e-6 of a half-integer.  Resolved queries get the values of the lowest-index containing simplex (or
 // NaN); the others keep their flag.
-__global__ __launch_bounds__(256) void k_resolve(const Simp *simp, int64_t ns, const double *values, const double *q, int64_t nq,
-                                                 double *out, int32_t *simplex, int32_t *doubt)
+__global__ __launch_bounds__(256) void k_resolve(const Simp *simp, int64_t ns, const double *values, const double *q,
+                                                 const int32_t *list, const int32_t *nlist, double *out, int32_t *simplex, int32_t *doubt)
 {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= nq || !doubt[i]) return;
-    const double x = q[2 * i], y = q[2 * i + 1];
+    // one WAVEFRONT per flagged query: its 64 lanes share the simplices (lane l takes l, l + 64, ...: coalesced 64-byte
+    // records) and merge what they found - one thread per query walking all 6 x 10^4 simplices took 19 of the 21 ms of the call
+    // with the integer-coordinate key points of a detector
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    const int32_t nf = *nlist;
     const double eps = 100.0 * DBL_EPSILON;
-    bool hull_unclear = false, disagree = false, near_half = false, any = false;
-    double R0 = 0.0, R1 = 0.0, V0 = NAN, V1 = NAN;
-    int32_t K = -1;
-    for (int64_t k = 0; k < ns; ++k) {
-        const Simp s = simp[k];
-        if (!s.ok) continue;
-        const double dx = x - s.rx, dy = y - s.ry;
-        const double c0 = s.t00 * dx + s.t01 * dy, c1 = s.t10 * dx + s.t11 * dy;
-        const double c2 = 1.0 - c0 - c1;
-        const double mc = fmin(c0, fmin(c1, c2));
-        if (!(mc >= -kTol)) continue;
-        if (fabs(mc + eps) < 4e-15) hull_unclear = true;               // (eps itself is 2.2e-14; a coordinate carries ~1e-16 of rounding)
-        if (mc >= -eps) {
-            const double *v0 = values + 2 * (int64_t)s.v0, *v1 = values + 2 * (int64_t)s.v1, *v2 = values + 2 * (int64_t)s.v2;
-            double o0 = c0 * v0[0]; o0 += c1 * v1[0]; o0 += c2 * v2[0];
-            double o1 = c0 * v0[1]; o1 += c1 * v1[1]; o1 += c2 * v2[1];
-            const double r0 = rint(o0), r1 = rint(o1);                 // half to even, as np.round
-            near_half = near_half || fabs(o0 - floor(o0) - 0.5) < 1e-6 || fabs(o1 - floor(o1) - 0.5) < 1e-6 || !(fabs(o0) < 1e15) || !(fabs(o1) < 1e15);
-            if (!any) { any = true; R0 = r0; R1 = r1; V0 = o0; V1 = o1; K = (int32_t)k; }
-            else if (r0 != R0 || r1 != R1) disagree = true;
+    for (int64_t f = wave; f < nf; f += nwaves) {
+        const int64_t i = list[f];
+        const double x = q[2 * i], y = q[2 * i + 1];
+        bool hull_unclear = false, disagree = false, near_half = false, any = false;
+        double R0 = 0.0, R1 = 0.0, V0 = NAN, V1 = NAN;
+        int32_t K = 0x7fffffff;                                         // this lane's lowest containing simplex
+        for (int64_t k = lane; k < ns; k += 64) {
+            const Simp s = simp[k];
+            if (!s.ok) continue;
+            const double dx = x - s.rx, dy = y - s.ry;
+            const double c0 = s.t00 * dx + s.t01 * dy, c1 = s.t10 * dx + s.t11 * dy;
+            const double c2 = 1.0 - c0 - c1;
+            const double mc = fmin(c0, fmin(c1, c2));
+            if (!(mc >= -kTol)) continue;
+            if (fabs(mc + eps) < 4e-15) hull_unclear = true;           // (eps itself is 2.2e-14; a coordinate carries ~1e-16 of rounding)
+            if (mc >= -eps) {
+                const double *v0 = values + 2 * (int64_t)s.v0, *v1 = values + 2 * (int64_t)s.v1, *v2 = values + 2 * (int64_t)s.v2;
+                double o0 = c0 * v0[0]; o0 += c1 * v1[0]; o0 += c2 * v2[0];
+                double o1 = c0 * v0[1]; o1 += c1 * v1[1]; o1 += c2 * v2[1];
+                const double r0 = rint(o0), r1 = rint(o1);             // half to even, as np.round
+                near_half = near_half || fabs(o0 - floor(o0) - 0.5) < 1e-6 || fabs(o1 - floor(o1) - 0.5) < 1e-6 || !(fabs(o0) < 1e15) || !(fabs(o1) < 1e15);
+                if (!any) { any = true; R0 = r0; R1 = r1; V0 = o0; V1 = o1; K = (int32_t)k; }
+                else if (r0 != R0 || r1 != R1) disagree = true;
+            }
+        }
+        // merge: the lowest containing simplex of all lanes gives the values; every lane's own first one (with which the
+        // rest of its share agrees, or `disagree` is set) must round like it
+        int32_t kmin = K;
+        for (int d = 32; d >= 1; d >>= 1) { const int32_t o = __shfl_xor(kmin, d); kmin = o < kmin ? o : kmin; }
+        const unsigned long long owner = __ballot(any && K == kmin);
+        const int src = owner ? __ffsll((long long)owner) - 1 : 0;
+        const double G0 = __shfl(R0, src), G1 = __shfl(R1, src), W0 = __shfl(V0, src), W1 = __shfl(V1, src);
+        if (any && (R0 != G0 || R1 != G1)) disagree = true;
+        if (__any(hull_unclear || disagree || near_half)) continue;    // stays flagged
+        if (lane == 0) {
+            out[2 * i] = owner ? W0 : NAN; out[2 * i + 1] = owner ? W1 : NAN;
+            simplex[i] = owner ? kmin : -1;
+            doubt[i] = 0;
         }
     }
-    if (hull_unclear || disagree || near_half) return;                  // stays flagged
-    out[2 * i] = V0; out[2 * i + 1] = V1;
-    if (simplex) simplex[i] = K;
-    doubt[i] = 0;
 }
 
 __global__ __launch_bounds__(256) void k_nearest(const double *seeds, int64_t ns, const double *q, int64_t nq, double *dist)
@@ -234,15 +253,15 @@ SID_EXPORT int sid_fg_interp_linear(int device, const double *pts, int64_t n_pts
     std::lock_guard<std::mutex> lock(g_pool_mu);
     auto up = [](size_t b) { return (b + 255) / 256 * 256; };
     const size_t need = up(sizeof(double) * 2 * n_pts) * 2 + up(sizeof(double) * 2 * n_q) * 2 + up(sizeof(int32_t) * 3 * n_simp) +
-                        up(sizeof(Simp) * n_simp) + up(sizeof(int32_t) * n_q) * 4;
+                        up(sizeof(Simp) * n_simp) + up(sizeof(int32_t) * n_q) * 5 + 256;
     unsigned char *blk = nullptr;
-    double *d_pts = nullptr, *d_val = nullptr, *d_q = nullptr, *d_out = nullptr; int32_t *d_simp = nullptr, *d_loc = nullptr, *d_near = nullptr, *d_sx = nullptr, *d_dbt = nullptr; Simp *d_t = nullptr;
+    double *d_pts = nullptr, *d_val = nullptr, *d_q = nullptr, *d_out = nullptr; int32_t *d_simp = nullptr, *d_loc = nullptr, *d_near = nullptr, *d_sx = nullptr, *d_dbt = nullptr, *d_list = nullptr, *d_nlist = nullptr; Simp *d_t = nullptr;
     if ((rc = pool_reserve(device, need, &blk))) { (void)hipSetDevice(prev); return rc; }
     {
         Carver cv(blk);
         d_pts = cv.take<double>(2 * n_pts); d_val = cv.take<double>(2 * n_pts); d_q = cv.take<double>(2 * n_q); d_out = cv.take<double>(2 * n_q);
         d_simp = cv.take<int32_t>(3 * n_simp); d_t = cv.take<Simp>(n_simp); d_loc = cv.take<int32_t>(n_q);
-        d_near = cv.take<int32_t>(n_q); d_sx = cv.take<int32_t>(n_q); d_dbt = cv.take<int32_t>(n_q);
+        d_near = cv.take<int32_t>(n_q); d_sx = cv.take<int32_t>(n_q); d_dbt = cv.take<int32_t>(n_q); d_list = cv.take<int32_t>(n_q); d_nlist = cv.take<int32_t>(1);
     }
     HIP_TRY(hipMemcpyAsync(d_pts, pts, sizeof(double) * 2 * n_pts, hipMemcpyHostToDevice, 0));
     HIP_TRY(hipMemcpyAsync(d_val, values, sizeof(double) * 2 * n_pts, hipMemcpyHostToDevice, 0));
@@ -259,8 +278,11 @@ SID_EXPORT int sid_fg_interp_linear(int device, const double *pts, int64_t n_pts
         HIP_TRY(hipMemsetAsync(d_loc, 0x7f, sizeof(int32_t) * n_q, 0));                 // 0x7f7f7f7f: above any index
         HIP_TRY(hipMemsetAsync(d_near, 0, sizeof(int32_t) * n_q, 0));
         hipLaunchKernelGGL(k_locate, dim3(qb, ychunks), dim3(256), 0, 0, d_t, n_simp, chunk, d_q, n_q, d_loc, d_near);
-        hipLaunchKernelGGL(k_eval, dim3(qb), dim3(256), 0, 0, d_t, d_loc, d_near, d_val, d_q, n_q, d_out, d_sx, d_dbt);
-        hipLaunchKernelGGL(k_resolve, dim3(qb), dim3(256), 0, 0, d_t, n_simp, d_val, d_q, n_q, d_out, d_sx, d_dbt);
+        HIP_TRY(hipMemsetAsync(d_nlist, 0, sizeof(int32_t), 0));
+        hipLaunchKernelGGL(k_eval, dim3(qb), dim3(256), 0, 0, d_t, d_loc, d_near, d_val, d_q, n_q, d_out, d_sx, d_dbt, d_list, d_nlist);
+        // (the number of flagged queries is only known on the device: enough wavefronts for a few thousand of them at once,
+        // each taking every 4096th entry of the list)
+        hipLaunchKernelGGL(k_resolve, dim3(1024), dim3(256), 0, 0, d_t, n_simp, d_val, d_q, d_list, d_nlist, d_out, d_sx, d_dbt);
     }
     HIP_TRY(hipGetLastError());
     if (simplex) HIP_TRY(hipMemcpyAsync(simplex, d_sx, sizeof(int32_t) * n_q, hipMemcpyDeviceToHost, 0));
