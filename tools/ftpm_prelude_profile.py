@@ -1,4 +1,5 @@
-"""Config 4 (FT -> PM): where the first-guess prelude of get_drift_PM spends its time - SciPy Delaunay of the key points,\nthe device evaluation (sid_fg_interp_linear), the queries left flagged for SciPy.  Run on the GPU box."""
+"""Config 4 (FT -> PM): where the first-guess prelude of get_drift_PM spends its time - SciPy Delaunay of the key points,
+the device evaluation (sid_fg_interp_linear), the queries left flagged for SciPy.  Run on the GPU box."""
 import sys, os, time
 sys.path.insert(0, os.environ.get('GRAFT_REPO_ROOT', '.'))
 import numpy as np, torch
