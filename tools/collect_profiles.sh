@@ -31,7 +31,7 @@ PY
 cp $OUT/traffic.json $R/profiles/traffic.json
 python3 $R/bench.py --steps 20 --warmup 3 > $OUT/bench.json 2> $OUT/bench.err
 for cfg in "--border 20" "--border 50" "--angles 3" "--border 20 --angles 3" "--angles 1" "--border 20 --angles 1" "--img-size 35" "--img-size 35 --angles 1"; do
-  python3 $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline $cfg 2>/dev/null | python3 -c "
+  python3 $R/bench.py --steps 30 --warmup 5 --no-cpu-baseline $cfg 2>/dev/null | python3 -c "
 import sys, json
 d = json.loads(sys.stdin.read())
 print(json.dumps({'args': '$cfg', 'ms_per_step': d['ms_per_step'], 'value': d['value'], 'workload': d['config']['workload'], 'mfma_frac': d['roofline']['frac'], 'parity_check': d['parity_check']}))" >> $OUT/other_configs.jsonl
