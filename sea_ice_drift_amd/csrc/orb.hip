@@ -16,6 +16,7 @@
 #include <algorithm>
 #include <vector>
 #include <chrono>
+#include <mutex>
 
 #include "../../include/sid_orb.h"
 #include "../../include/sid_pm.h"
@@ -252,6 +253,54 @@ __global__ void k_describe(const uint8_t *blur, int cols, const int32_t *kp, con
 
 }  // namespace
 
+namespace {
+
+// Workspaces: device buffers, a private stream and pinned staging, kept between calls (a call used to spend ~3 ms of its 17
+// in twelve hipMalloc / hipFree and ran on the null stream).  A call takes a free workspace of its device or makes one, so
+// two host threads - the two images of a pair (ftlib.track) - run side by side on streams of their own.
+struct OrbWs {
+    int device = -1; bool busy = false;
+    hipStream_t stream = nullptr;
+    unsigned char *blk = nullptr; size_t cap = 0;
+    unsigned int *h_small = nullptr;                                   // pinned: a counter / a 2048-bin histogram
+};
+std::mutex g_ws_mu;
+std::vector<OrbWs *> g_ws;
+
+OrbWs *ws_acquire(int device)
+{
+    std::lock_guard<std::mutex> lock(g_ws_mu);
+    for (OrbWs *w : g_ws) if (w->device == device && !w->busy) { w->busy = true; return w; }
+    OrbWs *w = new (std::nothrow) OrbWs();
+    if (!w) return nullptr;
+    w->device = device; w->busy = true;
+    if (hipStreamCreateWithFlags(&w->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipHostMalloc(reinterpret_cast<void **>(&w->h_small), 2048 * sizeof(unsigned int), hipHostMallocDefault) != hipSuccess) {
+        if (w->stream) (void)hipStreamDestroy(w->stream);
+        delete w;
+        return nullptr;
+    }
+    g_ws.push_back(w);
+    return w;
+}
+void ws_release(OrbWs *w) { if (w) { std::lock_guard<std::mutex> lock(g_ws_mu); w->busy = false; } }
+hipError_t ws_reserve(OrbWs *w, size_t bytes)
+{
+    if (w->cap >= bytes) return hipSuccess;
+    if (w->blk) (void)hipFree(w->blk);
+    w->blk = nullptr; w->cap = 0;
+    const hipError_t e = hipMalloc(reinterpret_cast<void **>(&w->blk), bytes);
+    if (e == hipSuccess) w->cap = bytes;
+    return e;
+}
+struct WsCarver {
+    unsigned char *base; size_t off = 0;
+    template <typename T> T *take(size_t n) { T *r = reinterpret_cast<T *>(base + off); off += (n * sizeof(T) + 255) / 256 * 256; return r; }
+};
+size_t up256(size_t b) { return (b + 255) / 256 * 256; }
+
+}  // namespace
+
 SID_EXPORT const char *sid_orb_last_error(void) { return g_err; }
 
 SID_EXPORT int sid_orb_detect(int device, const uint8_t *img, int64_t rows, int64_t cols, int64_t stride,
@@ -272,9 +321,11 @@ SID_EXPORT int sid_orb_detect(int device, const uint8_t *img, int64_t rows, int6
     // SID_ORB_VERBOSE=1: wall-clock milliseconds per stage on stderr (synchronises after every stage)
     const bool verbose = getenv("SID_ORB_VERBOSE") != nullptr;
     auto t_last = std::chrono::steady_clock::now();
+    OrbWs *ws = nullptr;
+    hipStream_t st = nullptr;
     auto tick = [&](const char *what, int level) {
         if (!verbose) return;
-        (void)hipDeviceSynchronize();
+        (void)hipStreamSynchronize(st);
         const auto now = std::chrono::steady_clock::now();
         fprintf(stderr, "[sid_orb] level %d %-22s %8.3f ms\n", level, what, std::chrono::duration<double, std::milli>(now - t_last).count());
         t_last = now;
@@ -300,19 +351,23 @@ SID_EXPORT int sid_orb_detect(int device, const uint8_t *img, int64_t rows, int6
             want[L - 1] = std::max(P->n_features - sum, 0);
         }
         const size_t area0 = (size_t)rows * cols;
-        HIP_TRY(hipMalloc(&d_img0, area0));
-        HIP_TRY(hipMalloc(&d_lvl, area0));
-        HIP_TRY(hipMalloc(&d_aux, area0));
-        HIP_TRY(hipMalloc(&d_cand, (area0 / 4 + 16) * sizeof(Cand)));
-        HIP_TRY(hipMalloc(&d_count, sizeof(unsigned int)));
-        HIP_TRY(hipMalloc(&d_hist, 2048 * sizeof(unsigned int)));
-        HIP_TRY(hipMalloc(&d_sel, (size_t)sel_cap * sizeof(Cand)));
-        HIP_TRY(hipMalloc(&d_pat, 32 * 1024));
-        HIP_TRY(hipMalloc(&d_dirs, 64 * sizeof(int32_t)));
-        HIP_TRY(hipMemcpy2D(d_img0, (size_t)cols, img, (size_t)stride, (size_t)cols, (size_t)rows, hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(d_pat, pattern, 32 * 1024, hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(d_dirs, dirs, 64 * sizeof(int32_t), hipMemcpyHostToDevice));
-        tick("alloc + upload", -1);
+        const size_t nkp = (size_t)std::max<int64_t>(std::min<int64_t>((int64_t)P->n_features, max_out), 1);   // most key points of one level
+        ws = ws_acquire(device);
+        if (!ws) { rc = fail(SID_PM_ERR_NOMEM, "no detector workspace"); goto done; }
+        st = ws->stream;
+        HIP_TRY(ws_reserve(ws, 3 * up256(area0) + up256((area0 / 4 + 16) * sizeof(Cand)) + up256((size_t)sel_cap * sizeof(Cand)) + up256(32 * 1024) +
+                               up256(nkp * 4 * sizeof(int32_t)) + up256(nkp * sizeof(int32_t)) + up256(nkp * 32) + 4 * 256 + up256(2048 * sizeof(unsigned int))));
+        {
+            WsCarver cv{ws->blk};
+            d_img0 = cv.take<uint8_t>(area0); d_lvl = cv.take<uint8_t>(area0); d_aux = cv.take<uint8_t>(area0);
+            d_cand = cv.take<Cand>(area0 / 4 + 16); d_sel = cv.take<Cand>(sel_cap); d_pat = cv.take<int8_t>(32 * 1024);
+            d_kp = cv.take<int32_t>(nkp * 4); d_dir = cv.take<int32_t>(nkp); d_desc = cv.take<uint8_t>(nkp * 32);
+            d_count = cv.take<unsigned int>(1); d_dirs = cv.take<int32_t>(64); d_hist = cv.take<unsigned int>(2048);
+        }
+        HIP_TRY(hipMemcpy2DAsync(d_img0, (size_t)cols, img, (size_t)stride, (size_t)cols, (size_t)rows, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(d_pat, pattern, 32 * 1024, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(d_dirs, dirs, 64 * sizeof(int32_t), hipMemcpyHostToDevice, st));
+        tick("workspace + upload", -1);
         for (int l = 0; l < L && total < max_out; ++l) {
             const int r = lr[l], c = lc[l];
             if (r <= 2 * edge || c <= 2 * edge || want[l] <= 0) continue;
@@ -321,19 +376,21 @@ SID_EXPORT int sid_orb_detect(int device, const uint8_t *img, int64_t rows, int6
             if (l > 0) {
                 const unsigned long long sx = ((unsigned long long)cols << 16) / (unsigned long long)c,
                                          sy = ((unsigned long long)rows << 16) / (unsigned long long)r;
-                hipLaunchKernelGGL(k_resize, grd, blk, 0, 0, d_img0, (int)rows, (int)cols, (long long)cols, d_lvl, r, c, sx, sy);
+                hipLaunchKernelGGL(k_resize, grd, blk, 0, st, d_img0, (int)rows, (int)cols, (long long)cols, d_lvl, r, c, sx, sy);
                 lvl = d_lvl;
             }
-            hipLaunchKernelGGL(k_fast, grd, blk, 0, 0, lvl, r, c, edge, P->fast_threshold, d_aux);
-            HIP_TRY(hipMemset(d_count, 0, sizeof(unsigned int)));
+            hipLaunchKernelGGL(k_fast, grd, blk, 0, st, lvl, r, c, edge, P->fast_threshold, d_aux);
+            HIP_TRY(hipMemsetAsync(d_count, 0, sizeof(unsigned int), st));
             const unsigned int cap = (unsigned int)((size_t)r * c / 4 + 16);
-            hipLaunchKernelGGL(k_nms, dim3(grd.x, (unsigned)((r + kNmsRows - 1) / kNmsRows)), blk, 0, 0, d_aux, r, c, edge, d_cand, d_count, cap);
+            hipLaunchKernelGGL(k_nms, dim3(grd.x, (unsigned)((r + kNmsRows - 1) / kNmsRows)), blk, 0, st, d_aux, r, c, edge, d_cand, d_count, cap);
             unsigned int nc = 0;
-            HIP_TRY(hipMemcpy(&nc, d_count, sizeof nc, hipMemcpyDeviceToHost));
+            HIP_TRY(hipMemcpyAsync(ws->h_small, d_count, sizeof nc, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            nc = ws->h_small[0];
             tick("resize + fast + nms", l);
             if (nc > cap) { rc = fail(SID_PM_ERR_HIP, "candidate list overflow (cannot happen: one maximum per 2x2 block)"); goto done; }
             if (nc == 0) continue;
-            hipLaunchKernelGGL(k_harris, dim3((nc + 255) / 256), dim3(256), 0, 0, lvl, c, d_cand, nc);
+            hipLaunchKernelGGL(k_harris, dim3((nc + 255) / 256), dim3(256), 0, st, lvl, c, d_cand, nc);
             const Cand *d_src = d_cand;
             const int64_t keep = std::min<int64_t>(want[l], max_out - total);
             if ((int64_t)nc > 2 * keep + 1024) {
@@ -343,22 +400,27 @@ SID_EXPORT int sid_orb_detect(int device, const uint8_t *img, int64_t rows, int6
                 const int shifts[3] = {21, 10, 0}; const uint32_t dmask[3] = {2047u, 2047u, 1023u};
                 std::vector<unsigned int> hist(2048);
                 for (int pass = 0; pass < 3; ++pass) {
-                    HIP_TRY(hipMemset(d_hist, 0, 2048 * sizeof(unsigned int)));
-                    hipLaunchKernelGGL(k_key_hist, dim3((nc + 256 * kHistPer - 1) / (256 * kHistPer)), dim3(256), 0, 0, d_cand, nc, prefix, pmask, shifts[pass], dmask[pass], d_hist);
-                    HIP_TRY(hipMemcpy(hist.data(), d_hist, 2048 * sizeof(unsigned int), hipMemcpyDeviceToHost));
+                    HIP_TRY(hipMemsetAsync(d_hist, 0, 2048 * sizeof(unsigned int), st));
+                    hipLaunchKernelGGL(k_key_hist, dim3((nc + 256 * kHistPer - 1) / (256 * kHistPer)), dim3(256), 0, st, d_cand, nc, prefix, pmask, shifts[pass], dmask[pass], d_hist);
+                    HIP_TRY(hipMemcpyAsync(ws->h_small, d_hist, 2048 * sizeof(unsigned int), hipMemcpyDeviceToHost, st));
+                    HIP_TRY(hipStreamSynchronize(st));
+                    memcpy(hist.data(), ws->h_small, 2048 * sizeof(unsigned int));
                     int d = (int)dmask[pass];
                     for (; d > 0; --d) { if ((int64_t)above + hist[(size_t)d] >= keep) break; above += hist[(size_t)d]; }
                     prefix |= (uint32_t)d << shifts[pass]; pmask |= dmask[pass] << shifts[pass];
                 }
-                HIP_TRY(hipMemset(d_count, 0, sizeof(unsigned int)));
-                hipLaunchKernelGGL(k_compact, dim3((nc + 255) / 256), dim3(256), 0, 0, d_cand, nc, prefix, d_sel, d_count, sel_cap);
+                HIP_TRY(hipMemsetAsync(d_count, 0, sizeof(unsigned int), st));
+                hipLaunchKernelGGL(k_compact, dim3((nc + 255) / 256), dim3(256), 0, st, d_cand, nc, prefix, d_sel, d_count, sel_cap);
                 unsigned int ns = 0;
-                HIP_TRY(hipMemcpy(&ns, d_count, sizeof ns, hipMemcpyDeviceToHost));
+                HIP_TRY(hipMemcpyAsync(ws->h_small, d_count, sizeof ns, hipMemcpyDeviceToHost, st));
+                HIP_TRY(hipStreamSynchronize(st));
+                ns = ws->h_small[0];
                 if (ns <= sel_cap && (int64_t)ns >= keep) { d_src = d_sel; nc = ns; }   // (else: massive ties - order them all)
             }
             tick("select", l);
             cand.resize(nc);
-            HIP_TRY(hipMemcpy(cand.data(), d_src, (size_t)nc * sizeof(Cand), hipMemcpyDeviceToHost));
+            HIP_TRY(hipMemcpyAsync(cand.data(), d_src, (size_t)nc * sizeof(Cand), hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
             std::sort(cand.begin(), cand.end(), [](const Cand &p, const Cand &q) {
                 if (p.resp != q.resp) return p.resp > q.resp;
                 if (p.y != q.y) return p.y < q.y;
@@ -368,20 +430,16 @@ SID_EXPORT int sid_orb_detect(int device, const uint8_t *img, int64_t rows, int6
             int64_t n = std::min<int64_t>(std::min<int64_t>(nc, want[l]), max_out - total);
             kp.resize((size_t)(4 * n));
             for (int64_t i = 0; i < n; ++i) { kp[4 * i] = cand[(size_t)i].x; kp[4 * i + 1] = cand[(size_t)i].y; kp[4 * i + 2] = l; kp[4 * i + 3] = 0; }
-            if (d_kp) { (void)hipFree(d_kp); d_kp = nullptr; }
-            if (d_dir) { (void)hipFree(d_dir); d_dir = nullptr; }
-            if (d_desc) { (void)hipFree(d_desc); d_desc = nullptr; }
-            HIP_TRY(hipMalloc(&d_kp, (size_t)(4 * n) * sizeof(int32_t)));
-            HIP_TRY(hipMalloc(&d_dir, (size_t)n * sizeof(int32_t)));
-            HIP_TRY(hipMalloc(&d_desc, (size_t)n * 32));
-            HIP_TRY(hipMemcpy(d_kp, kp.data(), (size_t)(4 * n) * sizeof(int32_t), hipMemcpyHostToDevice));
-            hipLaunchKernelGGL(k_orient, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, 0, lvl, c, d_kp, (int)n, R, d_dirs, d_dir);
-            hipLaunchKernelGGL(k_blur, grd, blk, 0, 0, lvl, r, c, d_aux);                 // the score map is no longer needed
-            hipLaunchKernelGGL(k_describe, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, 0, d_aux, c, d_kp, d_dir, (int)n, d_pat, d_desc);
+            if ((size_t)n > nkp) { rc = fail(SID_PM_ERR_HIP, "level key points exceed the workspace (cannot happen)"); goto done; }
+            HIP_TRY(hipMemcpyAsync(d_kp, kp.data(), (size_t)(4 * n) * sizeof(int32_t), hipMemcpyHostToDevice, st));
+            hipLaunchKernelGGL(k_orient, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, lvl, c, d_kp, (int)n, R, d_dirs, d_dir);
+            hipLaunchKernelGGL(k_blur, grd, blk, 0, st, lvl, r, c, d_aux);                // the score map is no longer needed
+            hipLaunchKernelGGL(k_describe, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, d_aux, c, d_kp, d_dir, (int)n, d_pat, d_desc);
             HIP_TRY(hipGetLastError());
             dir_h.resize((size_t)n); desc_h.resize((size_t)n * 32);
-            HIP_TRY(hipMemcpy(dir_h.data(), d_dir, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost));
-            HIP_TRY(hipMemcpy(desc_h.data(), d_desc, (size_t)n * 32, hipMemcpyDeviceToHost));
+            HIP_TRY(hipMemcpyAsync(dir_h.data(), d_dir, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipMemcpyAsync(desc_h.data(), d_desc, (size_t)n * 32, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
             for (int64_t i = 0; i < n; ++i) {
                 const int64_t o = total + i;
                 xy[2 * o] = (float)((double)cand[(size_t)i].x * sc[l]);
@@ -396,9 +454,8 @@ SID_EXPORT int sid_orb_detect(int device, const uint8_t *img, int64_t rows, int6
         *n_out = total;
     }
 done:
-    (void)hipFree(d_img0); (void)hipFree(d_lvl); (void)hipFree(d_aux); (void)hipFree(d_cand); (void)hipFree(d_count);
-    (void)hipFree(d_pat); (void)hipFree(d_dirs); (void)hipFree(d_kp); (void)hipFree(d_dir); (void)hipFree(d_desc);
-    (void)hipFree(d_hist); (void)hipFree(d_sel);
+    if (st) (void)hipStreamSynchronize(st);                            // (nothing of this call may still be in flight in a workspace that is free)
+    ws_release(ws);
     (void)hipSetDevice(prev);
     return rc;
 }

@@ -119,15 +119,24 @@ def match(kp1, descr1, kp2, descr2, ratio_test=0.7, device=0, verbose=False):
 
 # --------------------------------------------------------------------------- the pipeline
 def track(n1, n2, detector, domainMargin=0, ratio_test=0.7, max_speed=0.5, max_drift=None, psi=200, order=2,
-          device=0, verbose=False, **detector_kwargs):
+          device=0, verbose=False, concurrent_detection=False, **detector_kwargs):
     """Detector -> domain masks -> matcher + ratio mask -> drift mask -> model mask (ftlib.py:259-281).
-    Fewer than two key points on either side at any stage ends with four empty arrays."""
-    sets = []
-    for n in (n1, n2):
+    Fewer than two key points on either side at any stage ends with four empty arrays.
+    ``concurrent_detection``: the two images on two host threads (the package's own detector only: its per-level host
+    work - candidate selection, sorting - then runs beside the other image's kernels; the results do not depend on it)."""
+    def detect(n):
         kp, descr = detector(n[1], **detector_kwargs)
-        if len(kp) < 2:
-            return _EMPTY
-        sets.append((kp, np.asarray(descr)))
+        return kp, np.asarray(descr)
+    if concurrent_detection:
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=2) as pool:
+            sets = list(pool.map(detect, (n1, n2)))
+    else:
+        sets = [detect(n1)]
+        if len(sets[0][0]) >= 2:
+            sets.append(detect(n2))
+    if any(len(kp) < 2 for kp, _ in sets):
+        return _EMPTY
     for this, other, (kp, descr) in ((0, n2, sets[0]), (1, n1, sets[1])):
         keep = mask_inside_domain((n1, n2)[this], _xy(kp), other, domainMargin)
         _say(verbose, 'Domain filter: %d -> %d', len(keep), int(keep.sum()))
@@ -203,4 +212,5 @@ def feature_tracking(n1, n2, find_key_points=find_key_points, **kwargs):
     det_kw = {k: v for k, v in kwargs.items() if k not in own or k in ('verbose', 'device')}
     if find_key_points is not globals()['find_key_points']:
         det_kw = dict(kwargs)                       # a user detector sees everything, like the reference's call
-    return tuple(track(n1, n2, lambda image, **kw: find_key_points(image, **det_kw), **stage_kw))
+    return tuple(track(n1, n2, lambda image, **kw: find_key_points(image, **det_kw),
+                       concurrent_detection=find_key_points is globals()['find_key_points'], **stage_kw))
