@@ -49,7 +49,9 @@ typedef struct sid_orb_params {
  * meta:      [max_out][4] int32 out: level x, level y, level, direction index (may be NULL)
  * response:  [max_out] int64 out: Harris response (may be NULL)
  * desc:      [max_out][32] uint8 out
- * Key points are ordered by level, then by descending response, then by (y, x).  *n_out <= max_out. */
+ * Key points are ordered by level, then by descending response, then by (y, x).  *n_out <= max_out.
+ * Thread-safe: every call takes a free workspace of its device (device buffers ~7 bytes per pixel, a private stream; kept
+ * for the life of the process) or creates one, so calls from several host threads run side by side. */
 int sid_orb_detect(int device, const uint8_t *img, int64_t rows, int64_t cols, int64_t stride,
                    const sid_orb_params *params, const int8_t *pattern, const int32_t *dirs,
                    float *xy, int32_t *meta, int64_t *response, uint8_t *desc, int64_t max_out, int64_t *n_out);
