@@ -68,3 +68,20 @@ def test_feature_tracking_end_to_end_with_the_gpu_detector():
     dc, dr = syn.true_displacement(x1, y1)
     err = np.hypot(x2 - x1 - dc, y2 - y1 - dr)
     assert (err < 3.0).mean() > 0.9
+
+
+@pytest.mark.gpu
+def test_detector_calls_from_several_threads_share_nothing():
+    """sid_orb_detect takes a workspace (buffers + stream) per call: four threads on four different images, three rounds,
+    give what the same calls give one after the other (ftlib.track runs the two images of a pair this way)."""
+    from concurrent.futures import ThreadPoolExecutor
+    imgs = [syn.make_pair(900 + 64 * k, 1000 - 32 * k, seed=70 + k)[k & 1] for k in range(4)]
+    kw = dict(n_features=4000, n_levels=5)
+    ref = [orb.detect_and_compute(im, full=True, **kw) for im in imgs]
+    for _ in range(3):
+        with ThreadPoolExecutor(max_workers=4) as pool:
+            got = list(pool.map(lambda im: orb.detect_and_compute(im, full=True, **kw), imgs))
+        for g, e in zip(got, ref):
+            assert len(e[0]) > 500
+            for a, b in zip(g, e):
+                np.testing.assert_array_equal(a, b)
