@@ -34,7 +34,9 @@ int sid_ft_knn2(int device, const uint8_t *desc1, int64_t n1, const uint8_t *des
                 int32_t *idx, int32_t *dist);
 
 /* Same on device-resident buffers (16-byte aligned descriptors), asynchronous on `hip_stream`
- * (a hipStream_t, may be NULL); `workspace` must hold sid_ft_workspace_bytes(n1, n2) bytes.          */
+ * (a hipStream_t, may be NULL); `workspace` (16-byte aligned) must hold sid_ft_workspace_bytes(n1, n2) bytes: the per-chunk
+ * candidates and, from 2^24 pairs on, the byte-per-bit copies of both descriptor sets for the int8-MFMA form (256 bytes per
+ * descriptor, padded to multiples of 256 descriptors).                                                                  */
 int sid_ft_knn2_device(const uint8_t *d_desc1, int64_t n1, const uint8_t *d_desc2, int64_t n2,
                        int32_t *d_idx, int32_t *d_dist, void *d_workspace, void *hip_stream);
 int64_t sid_ft_workspace_bytes(int64_t n1, int64_t n2);

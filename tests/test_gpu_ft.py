@@ -33,6 +33,29 @@ def test_knn2_matches_oracle(n1, n2):
     np.testing.assert_array_equal(idx, eidx)           # and indices (ties: smaller index first)
 
 
+@pytest.mark.parametrize('n1,n2', [(4097, 4100), (5000, 6701)])
+def test_mfma_form_equals_the_valu_form_and_the_oracle(monkeypatch, n1, n2):
+    """From 2^24 pairs on the distances come from v_mfma_i32_16x16x64_i8 (|a xor b| = |a| + |b| - 2 a.b on 0/1 bytes);
+    sizes that are no multiples of the 256-descriptor tiles, duplicates (ties: smaller index first), all-zero and all-one
+    descriptors (the extremes of the key range).  SID_FT_NO_MFMA=1 runs the one-thread-per-query kernel on the same input."""
+    rng = np.random.default_rng(n1)
+    d2 = descriptors(rng, n2)
+    d1 = descriptors(rng, n1, like=d2, flips=40)
+    d2[17] = d2[5]; d2[n2 - 1] = d2[5]; d1[0] = d2[5]
+    d2[100] = 0; d2[101] = 255; d1[1] = 0; d1[2] = 255; d1[3] = d2[n2 - 2]
+    idx, dist = _capi.ft_knn2(d1, d2)
+    monkeypatch.setenv('SID_FT_NO_MFMA', '1')
+    vidx, vdist = _capi.ft_knn2(d1, d2)
+    np.testing.assert_array_equal(dist, vdist)
+    np.testing.assert_array_equal(idx, vidx)
+    m = 600                                            # (the NumPy oracle is slow: the first and the last queries)
+    for sl in (slice(0, m), slice(n1 - m, n1)):
+        eidx, edist = fo.knn2(d1[sl], d2)
+        np.testing.assert_array_equal(dist[sl], edist)
+        np.testing.assert_array_equal(idx[sl], eidx)
+    assert dist[1, 0] == 0 and idx[1, 0] == 100 and dist[2, 0] == 0 and idx[2, 0] == 101 and idx[0, 0] == 5 and idx[0, 1] == 17
+
+
 def test_single_train_descriptor_and_empty_sets():
     rng = np.random.default_rng(7)
     d1 = descriptors(rng, 10)

@@ -36,7 +36,8 @@ ok = bool(np.array_equal(eidx, idx[:m]) and np.array_equal(edist, dist[:m]))
 pairs = float(n1) * n2
 print(json.dumps({'metric': 'Hamming kNN (k=2) descriptor match', 'n1': n1, 'n2': n2,
                   'kernel_ms': t_kernel * 1e3, 'pairs_per_s': pairs / t_kernel,
-                  'valu_note': '21 VALU lane-ops per pair (8 xor + 8 bcnt + key + 3 min/max)',
+                  'form': 'mfma (256 int8 MACs + 4 VALU lane-ops per pair)' if pairs >= 2 ** 24 and n2 >= 1024 and not os.environ.get('SID_FT_NO_MFMA')
+                          else 'one thread per query (21 VALU lane-ops per pair: 8 xor + 8 bcnt + key + 3 min/max)',
                   'host_call_ms_incl_alloc_and_pcie': t_host * 1e3,
                   'numpy_oracle_s_extrapolated_from_%d_queries' % m: t_cpu, 'parity_vs_oracle_sample': ok,
                   'reference_notebook_s': 3.42 if (n1, n2) == (24183, 22694) else None}))

@@ -31,10 +31,16 @@ px = 1e8
 for k, calls, total, avg in kernels('stage'):
     if 'hist_kernel' in k: res.setdefault('stage.hip hist_kernel', []).append({'avg_ns': avg, 'calls': calls, 'bytes_per_launch': 4 * px, 'GBps': 4 * px / avg, 'frac_of_8TBps': 4 * px / avg / HBM})
     if 'scale_kernel' in k: res.setdefault('stage.hip scale_kernel', []).append({'avg_ns': avg, 'calls': calls, 'bytes_per_launch': 5 * px, 'GBps': 5 * px / avg, 'frac_of_8TBps': 5 * px / avg / HBM})
-# matcher: 24183 x 22694 pairs, 21 lane-ops per pair
+# matcher: 24183 x 22694 pairs.  MFMA form: 256 int8 MACs per pair on the matrix pipe (dense int8 peak 5 POP/s = 2.5e15 MAC/s)
+# + 4 VALU lane-ops per pair for the top two (key by one v_mad_i32_i24, three min / max); one-thread-per-query form: 21 lane-ops
 for k, calls, total, avg in kernels('ft_match'):
-    if 'knn' in k.lower() or 'match' in k.lower():
-        ops = 24183.0 * 22694.0 * 21
+    pairs = 24183.0 * 22694.0
+    if 'ft_knn2_mfma' in k:
+        res.setdefault('ft_match.hip ft_knn2_mfma', []).append({'avg_ns': avg, 'calls': calls, 'int8_macs_per_launch': pairs * 256, 'TOPs': 2 * pairs * 256 / avg / 1e3,
+            'frac_of_5POPs_int8': 2 * pairs * 256 / (avg * 1e-9) / 5e15, 'valu_lane_ops_per_launch': pairs * 4, 'frac_of_valu_issue_rate': pairs * 4 / (avg * 1e-9) / VALU32,
+            'note': 'the two pipes of a SIMD barely overlap (DESIGN.md section 6.2): the sum of the two fractions is the figure of merit'})
+    elif 'ft_knn2_partial' in k:
+        ops = pairs * 21
         res.setdefault('ft_match.hip ' + k[:40], []).append({'avg_ns': avg, 'calls': calls, 'lane_ops_per_launch': ops, 'Glaneops_per_s': ops / avg, 'frac_of_valu_issue_rate': ops / (avg * 1e-9) / VALU32})
 # detector / first guess: per-kernel times (bytes models in DESIGN.md)
 for nm in ('orb', 'first_guess'):
