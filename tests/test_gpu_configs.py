@@ -213,3 +213,47 @@ def test_two_threads_share_the_device_handle_without_mixing_results(c_oracle):
     img, g, angles, exp = cases[0]
     got = my.pm_dispatch(img[0], img[1], g['c1'], g['r1'], g['c2fg'], g['r2fg'], g['border'], 34, 0.0, angles=angles)
     np.testing.assert_array_equal(got[:, :4], exp[:, :4])
+
+
+@pytest.mark.parametrize('nang', [15, 3])
+def test_full_size_properties_order_subset_and_translation(nang):
+    """BASELINE's full size (200x200 grid on a 10000x10000 pair, mixed borders) through properties that need no oracle run of
+    that size: (a) the result of a point does not depend on the ORDER of the points (launch classes, XCD-aware order, buckets
+    of the four-per-CU build for 3 angles); (b) nor on which OTHER points are in the call; (c) cropping both images and moving
+    the coordinates along moves c2, r2 by the same offset and leaves a, r, h alone.  All bit for bit."""
+    from sea_ice_drift_amd.pmlib import rotation_table
+    size, s = 10000, 34
+    angles = list(range(-(nang // 2), nang // 2 + 1))
+    img1, img2 = syn.make_pair(size, size)
+    g = syn.make_grid(size, size, 200)
+    rot = rotation_table(angles, 0.0, s)
+    names = ('c1', 'r1', 'c2fg', 'r2fg', 'border')
+    rng = np.random.default_rng(2026)
+    with _capi.PMContext(0) as ctx:
+        ctx.upload_pair(img1, img2)
+
+        def run(sel, off=(0.0, 0.0)):
+            v = [g[k][sel] for k in names]
+            ctx.set_points(v[0] - off[0], v[1] - off[1], v[2] - off[0], v[3] - off[1], v[4], s, 0.0, angles, rot=rot)
+            ctx.run()
+            return ctx.fetch()
+        base, base_ij = run(slice(None))
+        ok = np.isfinite(base[:, 0])
+        assert ok.sum() > 39000
+        perm = rng.permutation(len(base))
+        got, got_ij = run(perm)
+        np.testing.assert_array_equal(got, base[perm])
+        np.testing.assert_array_equal(got_ij, base_ij[perm])
+        sub = np.sort(rng.choice(len(base), 5000, replace=False))
+        got, got_ij = run(sub)
+        np.testing.assert_array_equal(got, base[sub])
+        np.testing.assert_array_equal(got_ij, base_ij[sub])
+        # (c) crop 640 columns and 512 rows off the top left of both images (keeps the 16-byte alignment of the rows)
+        oc, orr = 640, 512
+        inner = np.nonzero((g['c1'] - oc > 200) & (g['r1'] - orr > 200) & (g['c2fg'] - oc > 200) & (g['r2fg'] - orr > 200))[0]
+        ctx.upload_pair(np.ascontiguousarray(img1[orr:, oc:]), np.ascontiguousarray(img2[orr:, oc:]))
+        got, got_ij = run(inner, off=(float(oc), float(orr)))
+        exp = base[inner].copy()
+        exp[:, 0] -= oc; exp[:, 1] -= orr
+        np.testing.assert_array_equal(got, exp)
+        np.testing.assert_array_equal(got_ij, base_ij[inner])
