@@ -25,4 +25,7 @@ run 4000 300 --angles 1 --no-table
 run 4000 300 --angles 1 --img-size 35
 run 4000 200 --angles 3 --border 26
 run 4000 200 --angles 1 --border 38
+run 10000 100 --angles 1
+run 10000 100 --angles 3
+run 10000 40 --angles 1 --img-size 35
 cat $OUT
