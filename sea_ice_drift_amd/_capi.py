@@ -23,7 +23,7 @@ SYMBOLS = (
     'sid_pm_batch', 'sid_pm_create', 'sid_pm_destroy', 'sid_pm_set_stream', 'sid_pm_upload_pair',
     'sid_pm_select_pair', 'sid_pm_bind_pair', 'sid_pm_set_points', 'sid_pm_bind_results', 'sid_pm_run', 'sid_pm_sync',
     'sid_pm_fetch', 'sid_pm_device_results', 'sid_pm_work_info', 'sid_pm_debug_point', 'sid_pm_debug_ncc_selftest',
-    'sid_pm_debug_rsqrt', 'sid_pm_debug_hypot_selftest', 'sid_pm_estimate_cost',
+    'sid_pm_debug_rsqrt', 'sid_pm_debug_hypot_selftest', 'sid_pm_estimate_cost', 'sid_pm_estimate_residency',
 )
 
 # every symbol include/sid_ft.h declares (feature-tracking matcher, same library)
@@ -99,6 +99,7 @@ def lib():
     L.sid_pm_debug_rsqrt.argtypes = [C.c_void_p, _f64p, _f64p, C.c_int64]
     L.sid_pm_debug_ncc_selftest.argtypes = [C.c_void_p, C.c_uint64, C.c_int64, C.c_int, C.POINTER(C.c_uint64)]
     L.sid_pm_estimate_cost.argtypes = [_f64p, C.c_int64, C.c_int, C.c_int, _f64p]
+    L.sid_pm_estimate_residency.argtypes = [_f64p, C.c_int64, C.c_int, C.c_int, _i32p]
     L.sid_pm_debug_hypot_selftest.argtypes = [C.c_void_p, C.c_uint64, C.c_int64, C.POINTER(C.c_uint64)]
     L.sid_ft_knn2.argtypes = [C.c_int, _u8p, C.c_int64, _u8p, C.c_int64, _i32p, _i32p]
     L.sid_ft_knn2_device.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -165,6 +166,14 @@ def estimate_cost(border, img_size=34, n_angles=15):
     b = _f64(border).ravel()
     out = np.empty(b.size, dtype=np.float64)
     _check(lib().sid_pm_estimate_cost(_p(b, _f64p), b.size, int(img_size), int(n_angles), _p(out, _f64p)))
+    return out
+
+
+def estimate_residency(border, img_size=34, n_angles=15):
+    """Workgroups per CU (1 .. 4) of the launch class of each grid point (include/sid_pm.h sid_pm_estimate_residency)."""
+    b = _f64(border).ravel()
+    out = np.empty(b.size, dtype=np.int32)
+    _check(lib().sid_pm_estimate_residency(_p(b, _f64p), b.size, int(img_size), int(n_angles), _p(out, _i32p)))
     return out
 
 

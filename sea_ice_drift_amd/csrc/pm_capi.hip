@@ -918,9 +918,9 @@ SID_EXPORT int sid_pm_debug_hypot_selftest(sid_pm_ctx *ctx, uint64_t seed, int64
 // winner's NCC matrix, the placements themselves - times a factor for the residency class of its LDS footprint (fewer
 // co-resident workgroups hide less latency).  The six constants were fitted to tools/border_cost.py (template side 34, 15
 // angles, borders 20..50: within 4 % everywhere); what matters to the sharding are the ratios between points.
-SID_EXPORT int sid_pm_estimate_cost(const double *border, int64_t n, int img_size, int n_angles, double *cost_ns)
+static int estimate_points(const double *border, int64_t n, int img_size, int n_angles, double *cost_ns, int32_t *per_cu_out)
 {
-    if (n < 0 || (n > 0 && (!border || !cost_ns))) return fail(SID_PM_ERR_ARG, "bad argument");
+    if (n < 0 || (n > 0 && (!border || (!cost_ns && !per_cu_out)))) return fail(SID_PM_ERR_ARG, "bad argument");
     const int s = img_size, K = n_angles;
     if (!sid::mfma_img_size_supported(s) || K < 1) return fail(SID_PM_ERR_UNSUPPORTED, "img_size / angle count not supported");
     const bool rp = use_rp(s, K);
@@ -930,10 +930,12 @@ SID_EXPORT int sid_pm_estimate_cost(const double *border, int64_t n, int img_siz
     constexpr double kSweep = 7.06e-3, kWinner = 8.64e-3, kPos = 3.28e-3, kFixed = 43.3, kTwoPerCu = 1.32, kOnePerCu = 1.69, kFourPerCu = 0.93;
     for (int64_t i = 0; i < n; ++i) {
         const double b = border[i];
-        if (!(b >= 0.0 && b < 4096.0)) { cost_ns[i] = kFixed; continue; }      // NaN / absurd: a point that writes NaN at once
+        if (per_cu_out) per_cu_out[i] = kMaxPerCu;
+        if (!(b >= 0.0 && b < 4096.0)) { if (cost_ns) cost_ns[i] = kFixed; continue; }      // NaN / absurd: a point that writes NaN at once
         const int wn = 2 * hws + 2 * (int)b + 1, r = wn - s + 1;
-        if (r < 2) { cost_ns[i] = kFixed; continue; }
+        if (r < 2) { if (cost_ns) cost_ns[i] = kFixed; continue; }
         double sweep, winner, cls_factor;
+        int cls = kMaxPerCu;
         if (rp) {
             const sid::RpLdsLayout L4 = sid::rp_lds_layout(wn, wn, s, K <= sid::kRpGroup, rp_rows(rpp, 4), 0, sid::rp_tab_pitch(rpp));
             int per_cu = blocks_per_cu(L4.total), band = 4;
@@ -946,14 +948,31 @@ SID_EXPORT int sid_pm_estimate_cost(const double *border, int64_t n, int img_siz
             sweep = groups * (rpp == 2 ? 0.33 : rpp == 1 ? 0.55 : 1.0) * units * (rows * per_row_tile + 2.0);
             winner = wunits * 76.0;
             cls_factor = (per_cu >= 4 && max_per_cu(rp, rpp) == 4) ? kFourPerCu : per_cu >= 3 ? 1.0 : per_cu == 2 ? kTwoPerCu : kOnePerCu;
+            cls = std::max(1, std::min(per_cu, max_per_cu(rp, rpp)));
         } else {
             const sid::MfmaLdsLayout L = sid::mfma_lds_layout(wn, wn, s, 4, use_paired(K));
             const int per_cu = blocks_per_cu(L.total), ntx = (r + 15) / 16;
             sweep = groups * (double)r * ntx * s * (use_paired(K) ? 0.55 : 1.0) * 1.3;    // one template row per MFMA
             winner = (double)((r + 15) / 16) * ntx * (16 + s - 1) * 2.0;
             cls_factor = per_cu >= 3 ? 1.0 : per_cu == 2 ? kTwoPerCu : kOnePerCu;
+            cls = std::max(1, std::min(per_cu, kMaxPerCu));
         }
-        cost_ns[i] = (kSweep * sweep + kWinner * winner + kPos * (double)r * r + kFixed) * cls_factor;
+        if (cost_ns) cost_ns[i] = (kSweep * sweep + kWinner * winner + kPos * (double)r * r + kFixed) * cls_factor;
+        if (per_cu_out) per_cu_out[i] = cls;
     }
     return SID_PM_OK;
+}
+
+SID_EXPORT int sid_pm_estimate_cost(const double *border, int64_t n, int img_size, int n_angles, double *cost_ns)
+{
+    if (n > 0 && !cost_ns) return fail(SID_PM_ERR_ARG, "bad argument");
+    return estimate_points(border, n, img_size, n_angles, cost_ns, nullptr);
+}
+
+// Workgroups per CU of the launch a point of that border joins (its LDS residency class: 1 .. 3, 4 for the slot-group
+// layouts): a launch runs 256 x that many points at a time, which is what the tail of a SHORT launch costs (dist.py).
+SID_EXPORT int sid_pm_estimate_residency(const double *border, int64_t n, int img_size, int n_angles, int32_t *per_cu)
+{
+    if (n > 0 && !per_cu) return fail(SID_PM_ERR_ARG, "bad argument");
+    return estimate_points(border, n, img_size, n_angles, nullptr, per_cu);
 }

@@ -36,23 +36,65 @@ def point_cost(border, img_size=34, n_angles=15):
     return _capi.estimate_cost(np.asarray(border, dtype=np.float64), img_size, n_angles)
 
 
+# tail of a launch in run times of one of its workgroups, by residency class (workgroups per CU): with 256 x class points in
+# flight the last round is half empty on average; the classes with few slots run the large borders, whose run times differ by
+# up to 1.5x inside one launch, and end less evenly.  Fitted to the shards tools/shard_sim.py measures on the GPU
+# (8 shards of the benchmark grid: 0.5 everywhere left the one-per-CU shard 6.5 % and the mixed one 7.4 % above the others).
+_TAIL_ROUNDS = {1: 1.0, 2: 0.7, 3: 0.5, 4: 0.5}
+
+
+def _shard_times(cost, cls, cuts):
+    """Estimated kernel time of every shard [cuts[r], cuts[r+1]) of the border-ordered points: per launch class the sum of
+    the point costs plus the tail of the launch (``_TAIL_ROUNDS`` x the run time of a workgroup = slots x mean cost); a launch
+    shorter than one round still takes a full one."""
+    t = np.zeros(len(cuts) - 1)
+    for r in range(len(cuts) - 1):
+        a, b = cuts[r], cuts[r + 1]
+        for c in np.unique(cls[a:b]):
+            sel = cost[a:b][cls[a:b] == c]
+            latency = 256.0 * c * sel.mean()
+            t[r] += max(sel.sum() + _TAIL_ROUNDS.get(int(c), 0.5) * latency, latency)
+    return t
+
+
 def shard_indices_by_cost(border, world_size, rank, img_size=34, n_angles=15):
     """Indices owned by `rank` when the points, ordered by border (largest first, stable), are cut into `world_size`
-    contiguous runs of equal estimated cost.  A rank then holds one or two neighbouring border classes instead of an
+    contiguous runs of equal estimated TIME.  A rank then holds one or two neighbouring border classes instead of an
     eighth of every class, i.e. one or two launches that are eight times longer: at 5 000 points per rank the tails of
-    three short launches cost a quarter of the step.
+    three short launches cost a quarter of the step.  The time of a run is the cost of its points
+    (``point_cost``) plus the tails of its launches (``_shard_times``): cut by cost alone, the rank with the largest borders -
+    one workgroup per CU, 7 rounds of 256 points - came out 6 % slower than the others on the GPU (tools/shard_sim.py).
 
     Every rank's kernels must finish before the gather can complete, so the step time is the slowest rank's kernel time
-    plus the exchange step; shortening rank 0's shard would not hide the exchange (it starts when the LAST rank is done)."""
+    plus the exchange step; shortening rank 0's shard would not hide the exchange (it starts when the LAST rank is done).
+    Pure function of its arguments: every rank computes the same cuts."""
+    from . import _capi
     border = np.asarray(border)
     order = np.argsort(-border, kind='stable')
+    n = order.size
+    if n == 0 or world_size <= 1:
+        return np.sort(order) if rank == 0 else np.zeros(0, dtype=order.dtype)
     cost = point_cost(border[order], img_size, n_angles)
-    cum = np.cumsum(cost)
-    total = cum[-1] if cum.size else 0.0
-    # point k goes to the rank whose cost interval holds the middle of its own
-    mid = cum - 0.5 * cost
-    owner = np.minimum((mid * world_size / total).astype(np.int64), world_size - 1) if total > 0 else np.zeros(0, np.int64)
-    return np.sort(order[owner == rank])
+    cls = _capi.estimate_residency(border[order], img_size, n_angles)
+    cum = np.concatenate([[0.0], np.cumsum(cost)])
+    share = np.full(world_size, cum[-1] / world_size)               # cost each shard is to hold
+
+    def cuts_for(share):
+        # point k goes to the shard whose cost interval holds the middle of its own
+        edges = np.cumsum(share)[:-1]
+        mid = cum[:-1] + 0.5 * cost
+        c = np.searchsorted(mid, edges, side='left')
+        return np.concatenate([[0], c, [n]]).astype(np.int64)
+    best_cuts, best = None, np.inf
+    for _ in range(24):                                             # move cost from the slow shards to the fast ones
+        cuts = cuts_for(share)
+        t = _shard_times(cost, cls, cuts)
+        if t.max() < best:
+            best, best_cuts = t.max(), cuts
+        share = np.maximum(share + 0.7 * (t.mean() - t), 0.0)
+        share *= cum[-1] / share.sum()
+    a, b = best_cuts[rank], best_cuts[rank + 1]
+    return np.sort(order[a:b])
 
 
 def shard_size(n_total, world_size):
