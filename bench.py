@@ -13,7 +13,9 @@ touches torch or the GPU (a process that has initialised the GPU is never replac
     search border 20..50 px; the five kernel-input vectors and both images are resident in HBM before the
     timed region.  A step = one pass of the hot path over the whole grid: kernel launches for every point,
     the gather of the packed (N,5) float64 + (N,3) int32 results to rank 0 (one RCCL gather when N > 1) and
-    their copy to the host (the reference's seam ends with the results in the parent, pmlib.py:444,462).
+    their copy to the host (the reference's seam ends with the results in the parent, pmlib.py:444,462).  With one
+    rank the kernels write their 52 B per point straight into the pinned host buffer (zero copy; the step ends with the
+    stream synchronised and the results readable on the host - the parity check reads exactly that buffer).
     N > 1 is STRONG scaling by default - the same 200x200 grid cut into runs of equal estimated cost (by search border)
     (sea_ice_drift_amd/dist.py) - and the weak figure ((200*N)x200 grid, 40 000 points per GPU) is measured
     after it and reported under "weak_scaling"; ``--scaling weak`` makes the weak workload the headline.
@@ -356,6 +358,8 @@ def grid_mode(args, torch, dist, dev, world, rank, local_rank):
                    'points_total': int(n_total), 'points_per_gpu': int(n_local),
                    # (shards of equal estimated cost are unequal in length: rank 0 holds the largest windows)
                    'points_per_gpu_all': [int(len(shard_indices_by_cost(run.g['border'], world, r, s, len(angles)))) for r in range(world)],
+                   'results': ('written by the kernels into pinned host memory (zero copy); step = launches + stream synchronise'
+                               if getattr(run.gather, 'zero_copy', False) else 'device block -> (gather, un-permutation) -> one copy to pinned host memory'),
                    'parallelism': ('single GPU, no collective' if world == 1 else
                                    'points cut into %d runs of equal estimated cost (neighbouring borders per GPU), one RCCL gather of the packed '
                                    'result blocks to rank 0' % world)},

@@ -8,6 +8,8 @@ share of every search-window size, and ONE collective at the end - a gather of t
 (N/G, 5) float64 (+ (N/G, 3) int32) result blocks to rank 0.  The payload is tiny (40 000
 points -> 1.6 MB + 0.5 MB), so the gather is latency-bound, not xGMI-link-bound.
 """
+import os
+
 import numpy as np
 
 
@@ -246,6 +248,14 @@ class PackedGatherer(object):
             self.host = torch.empty(n * self.ROW, dtype=torch.uint8, pin_memory=pin)
             self.host_out = self.host[:n * 40].view(torch.float64).view(n, 5)
             self.host_ij = self.host[n * 40:].view(torch.int32).view(n, 3)
+            # zero copy: with one rank, the points in their own order and no forced collective, the kernels write their 52 B per
+            # point straight into the pinned host buffer (device-visible on ROCm: hipHostMalloc) - 2 MB of posted PCIe writes
+            # spread over the step instead of a 50 us copy after it.  SID_PM_NO_ZERO_COPY=1: copy as before (A/B runs).
+            self.zero_copy = self.identity and pin and os.environ.get('SID_PM_NO_ZERO_COPY') is None
+            if self.zero_copy:
+                self.host_out.fill_(float('nan'))
+                self.host_ij.fill_(-1)
+                self.out_local, self.ij_local = self.host_out, self.host_ij
 
     def local_views(self):
         """The [n_local,5] float64 and [n_local,3] int32 tensors the kernels of this rank write."""
@@ -274,7 +284,8 @@ class PackedGatherer(object):
         if getattr(self, 'identity', False):
             if ev:
                 ev[2].record()
-            self.host.copy_(self.block, non_blocking=True)
+            if not self.zero_copy:
+                self.host.copy_(self.block, non_blocking=True)
             if ev:
                 ev[3].record()
             if self.device.type == 'cuda':
