@@ -124,7 +124,10 @@ int sid_pm_set_points(sid_pm_ctx *ctx, const double *c1, const double *r1, const
 /* Optional: have the kernels write into caller-owned device arrays ([n][5] float64 and
  * [n][3] int32, e.g. torch tensors that an RCCL gather will read) instead of the handle's
  * own.  Call after set_points; the binding is dropped by the next set_points.  NULL, NULL
- * restores the handle's buffers. */
+ * restores the handle's buffers.  Any device-visible pointer serves: bound to pinned host
+ * memory (hipHostMalloc) the kernels write their 52 bytes per point straight to the host and
+ * sid_pm_run + sid_pm_sync is the whole step (no copy after the kernels; do not call
+ * sid_pm_fetch then - it copies FROM the bound arrays). */
 int sid_pm_bind_results(sid_pm_ctx *ctx, double *d_out, int32_t *d_out_ij);
 
 /* Enqueue the kernels for the resident points on the resident pair (asynchronous). */

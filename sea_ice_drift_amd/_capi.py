@@ -324,6 +324,17 @@ class PMContext(object):
         _check(lib().sid_pm_bind_results(self._h, C.c_void_p(t_out.data_ptr()),
                                          C.c_void_p(t_ij.data_ptr()) if t_ij is not None else None))
 
+    def bind_results_host(self):
+        """Zero-copy results: allocate pinned host tensors float64 [n,5] / int32 [n,3] and make the kernels write their 52 B per
+        point straight into them (pinned memory is device-visible on ROCm).  After ``run()`` + ``sync()`` the tensors hold
+        the results - no copy after the kernels, which is worth 1 % of a 40 000-point step and more of a shorter one.
+        Returns (out, ij); they stay bound until the next ``set_points`` / ``bind_results_tensors``."""
+        import torch
+        out = torch.empty((self.n, 5), dtype=torch.float64, pin_memory=True)
+        ij = torch.empty((self.n, 3), dtype=torch.int32, pin_memory=True)
+        self.bind_results_tensors(out, ij)
+        return out, ij
+
     def run(self):
         _check(lib().sid_pm_run(self._h))
 

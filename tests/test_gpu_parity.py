@@ -233,3 +233,24 @@ def test_shortened_hypot_is_numpys_float32_hypot(pm_ctx):
     n, bad = pm_ctx.debug_hypot_selftest(1 << 27, seed=20261002)
     assert n >= 1 << 27
     assert bad == 0
+
+
+def test_results_written_straight_into_pinned_host_memory(pm_ctx, c_oracle):
+    """bind_results_host: the kernels write into pinned host tensors (zero copy); after run + sync they hold what fetch() returns
+    from the device buffers - NaN rows included."""
+    img1, img2 = syn.make_pair(700, 700, seed=19)
+    img1 = img1.copy()
+    img1[350:365, 340:370] = 0                        # NaN rows
+    g = syn.make_grid(700, 700, 13, margin=90)
+    rot = rot_for(ANGLES15, 0.0, 34)
+    pm_ctx.upload_pair(img1, img2)
+    pm_ctx.set_points(g['c1'], g['r1'], g['c2fg'], g['r2fg'], g['border'], 34, 0.0, ANGLES15, rot=rot)
+    pm_ctx.run()
+    ref, ref_ij = pm_ctx.fetch()
+    assert np.isnan(ref[:, 0]).any()
+    out, ij = pm_ctx.bind_results_host()
+    out.fill_(-7.0); ij.fill_(-7)
+    pm_ctx.run()
+    pm_ctx.sync()
+    np.testing.assert_array_equal(out.numpy(), ref)
+    np.testing.assert_array_equal(ij.numpy(), ref_ij)
