@@ -73,6 +73,9 @@ def parse_args(argv=None):
                     help='N > 1, grid mode: strong (default) = the same grid sharded; weak = grid rows x N')
     ap.add_argument('--no-weak', action='store_true', help='skip the secondary weak-scaling measurement')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-also-defaults', action='store_true',
+                    help="N = 1, grid mode: skip the second measurement on the reference's DEFAULT configuration (img_size 35, "
+                         "angles [-3, 0, 3]; pmlib.py:118,329) that is reported under 'reference_defaults'")
     ap.add_argument('--force-collective', action='store_true',
                     help='N = 1: initialise a one-rank nccl (RCCL) group and run the broadcast, the all_reduce and the gathers '
                          'of the N-GPU path on it (exercises the RCCL code path on a one-GPU box)')
@@ -160,6 +163,13 @@ class GridRun(object):
         if ev is not None:
             ev[1].record()
         self.gather.gather_to_host()            # rank 0: results on the host = end of the seam
+        self.ctx.check()                        # (stream synchronised above) no valid point was refused by its launch
+
+    def poisoned_step(self):
+        """One more, untimed step whose result buffers were overwritten (NaN / -1) first: what the parity check reads is
+        the output of THIS step - a step that launched or gathered nothing cannot pass on the values of an earlier one."""
+        self.gather.poison()
+        self.step()
 
     def results(self):
         return self.gather.host_results()
@@ -187,6 +197,7 @@ def timed_steps(torch, dist, world, run, steps, warmup, discard_warmup=None):
         run.step(ev[k])
     fence()
     elapsed = time.perf_counter() - t0
+    timed_steps.local_elapsed = elapsed                    # this rank's own clock (per-rank breakdown of the stream mode)
     if world > 1:
         te = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
         dist.all_reduce(te, op=dist.ReduceOp.MAX)
@@ -250,12 +261,31 @@ def cpu_baselines(args, img1, img2, g, n_total, angles, rot, s):
     n1 = int(min(n_total, max(len(cal1), rate1 * 8.0)))
     smp1 = np.linspace(0, n_total - 1, n1).astype(np.int64)
     tc = time.perf_counter()
-    b1_baseline.run(img1, img2, *pick(smp1), s, 0.0, angles, processes=nthreads)
+    res1 = b1_baseline.run(img1, img2, *pick(smp1), s, 0.0, angles, processes=nthreads)
     dt1 = time.perf_counter() - tc
     out['b1'] = {'value': n1 / dt1, 'unit': 'grid-points/s', 'cores': nthreads, 'kind': 'port',
                  'sample': 'B1: %d points, one Python task per point under multiprocessing.Pool(%d) as pmlib.py:436-448; '
                            'scipy affine_transform templates, float32-FFT correlation standing in for cv2 (absent), '
                            'NumPy Hessian; %.1f s' % (n1, nthreads, dt1)}
+    # Differential run of a float32-FFT matcher - OpenCV's route for TM_CCOEFF_NORMED, the one call the oracle cannot pin
+    # (cv2 is absent) - against the exact-integer oracle: B1's results on its sample and on EVERY point whose peak lies
+    # within 1e-4 of the runner-up (the ones a noisy matcher could flip).  A flip = peak position or angle differs.
+    if len(smp) == n_total:
+        close = np.flatnonzero(np.isfinite(gap) & (gap > 0) & (gap < 1e-4))
+        res_c = b1_baseline.run(img1, img2, *pick(close), s, 0.0, angles, processes=nthreads) if close.size else np.zeros((0, 5))
+
+        def flips(sel, got):
+            want = exp[sel]
+            both = np.isfinite(want[:, 0]) & np.isfinite(got[:, 0])
+            moved = both & ((got[:, 0] != want[:, 0]) | (got[:, 1] != want[:, 1]) | (got[:, 2] != want[:, 2]))
+            dr = np.abs(got[both, 3] - want[both, 3])
+            return {'points': int(len(sel)), 'peak_or_angle_differs': int(moved.sum()),
+                    'nan_disagreements': int((np.isfinite(want[:, 0]) != np.isfinite(got[:, 0])).sum()),
+                    'max_abs_r_difference': float(dr.max()) if dr.size else None}
+        out['fft_f32_differential'] = {
+            'matcher': 'oracle/b1_baseline._ccoeff_normed_fft: float32 FFT correlation, float64 normalisation (OpenCV-like), '
+                       'scipy affine_transform templates, NumPy argmax - against oracle/pm_oracle.c (exact integers)',
+            'b1_sample': flips(smp1, res1), 'points_with_gap_below_1e-4': flips(close, res_c)}
     return out, (smp, exp, exp_ij, gap)
 
 
@@ -319,9 +349,15 @@ def grid_mode(args, torch, dist, dev, world, rank, local_rank):
     run = GridRun(args, dev, world, rank, local_rank, t1, t2, headline_rows, angles, rot)
     run.gather.timings()                                   # (reset: construction and warm-up are not the timed steps)
     elapsed, kern_ms = timed_steps(torch, dist, world, run, args.steps, args.warmup, discard_warmup=run.gather.timings)
-    exchange = run.gather.timings() if rank == 0 else None
+    exchange = run.gather.timings()
+    # every rank's share of a step on rank 0 (one all_gather): the slowest rank of an N-GPU run is then identifiable
+    from sea_ice_drift_amd.dist import per_rank_breakdown
+    per_rank = per_rank_breakdown([kern_ms, exchange['gather_ms'], exchange['unpermute_ms'], exchange['d2h_ms'], len(run.idx),
+                                   run.info['launches']], dev) if (world > 1 or args.force_collective) else None
+    run.poisoned_step()                                    # untimed; the parity check below reads this step's output
     res, res_ij = run.results() if rank == 0 else (None, None)
     n_total, info, g = run.n_total, run.info, run.g
+    zero_copy, device_unpermute = getattr(run.gather, 'zero_copy', False), getattr(run.gather, 'device_unpermute', False)
     from sea_ice_drift_amd.dist import shard_indices_by_cost
     n_local = len(run.idx)
     run.close()
@@ -359,7 +395,9 @@ def grid_mode(args, torch, dist, dev, world, rank, local_rank):
                    # (shards of equal estimated cost are unequal in length: rank 0 holds the largest windows)
                    'points_per_gpu_all': [int(len(shard_indices_by_cost(run.g['border'], world, r, s, len(angles)))) for r in range(world)],
                    'results': ('written by the kernels into pinned host memory (zero copy); step = launches + stream synchronise'
-                               if getattr(run.gather, 'zero_copy', False) else 'device block -> (gather, un-permutation) -> one copy to pinned host memory'),
+                               if zero_copy else 'device block -> one gather -> one kernel that un-permutes into pinned host memory'
+                               if device_unpermute else 'device block -> (gather, un-permutation) -> one copy to pinned host memory'),
+                   'parity_reads': 'the output of one more, untimed step run after the result buffers were overwritten with NaN / -1',
                    'parallelism': ('single GPU, no collective' if world == 1 else
                                    'points cut into %d runs of equal estimated cost (neighbouring borders per GPU), one RCCL gather of the packed '
                                    'result blocks to rank 0' % world)},
@@ -382,22 +420,76 @@ def grid_mode(args, torch, dist, dev, world, rank, local_rank):
     }
     if weak is not None:
         line['weak_scaling'] = weak
-    if exchange is not None and exchange['steps'] > 0:
-        # where a step of the N-GPU path goes on rank 0: its own kernels, then the exchange step (HIP events on the launch
-        # stream; the gather also holds the wait for the slowest rank), the un-permutation and the copy to the host
+    if per_rank is not None and exchange['steps'] > 0:
+        # where a step of the N-GPU path goes: rank 0's own kernels, then the exchange step (HIP events on the launch
+        # stream; the gather also holds the wait for the slowest rank), the un-permutation into pinned host memory - and the
+        # same numbers of EVERY rank, with the slowest rank's kernels named (max / argmax)
+        kcol = per_rank[:, 0]
         line['step_breakdown_ms'] = {'kernel_ms': kern_ms, 'gather_ms': exchange['gather_ms'], 'unpermute_ms': exchange['unpermute_ms'],
                                      'd2h_ms': exchange['d2h_ms'], 'backend': dist.get_backend() if dist.is_initialized() else None,
+                                     'results': ('one kernel (sid_pm_unpermute) reads the gathered blocks and writes pinned host memory'
+                                                 if getattr(run.gather, 'device_unpermute', False) else 'index_select x2 + one copy to the host'),
                                      'collectives': 'broadcast x2 (pair), all_reduce(MAX) + gather (indices) at set-up, one gather of '
-                                                    'the packed block per step'}
+                                                    'the packed block per step',
+                                     'per_rank': {'kernel_ms': [float(v) for v in kcol], 'gather_ms': [float(v) for v in per_rank[:, 1]],
+                                                  'points': [int(v) for v in per_rank[:, 4]], 'launches': [int(v) for v in per_rank[:, 5]]},
+                                     'slowest_rank': int(kcol.argmax()), 'slowest_kernel_ms': float(kcol.max()),
+                                     'fastest_kernel_ms': float(kcol.min())}
     oracle_run = None
     if not args.no_cpu_baseline:
         line['cpu_baseline'], oracle_run = cpu_baselines(args, img1, img2, g, n_total, angles, rot, s)
     if args.check > 0 or oracle_run is not None:
         line['parity_check'] = parity_block(args, img1, img2, g, n_total, res, res_ij, angles, rot, s, oracle_run)
+        if 'fft_f32_differential' in line.get('cpu_baseline', {}):
+            # how far a float32-FFT matcher (OpenCV's route, unpinnable here) parts from the exact-integer specification
+            line['parity_check']['fft_f32_flips'] = line['cpu_baseline'].pop('fft_f32_differential')
         if not line['parity_check']['ok']:
             print(json.dumps(line))
             raise SystemExit('PARITY FAILURE against the CPU oracle - the number above is invalid')
+    if world == 1 and not args.no_also_defaults and not args.force_collective and args.img_size == 34 and args.angles == 7:
+        line['reference_defaults'] = defaults_block(args, torch, dist, dev, local_rank, t1, t2, img1, img2)
+        if not line['reference_defaults']['parity_check']['ok']:
+            print(json.dumps(line))
+            raise SystemExit("PARITY FAILURE against the CPU oracle on the reference's default configuration")
     return line
+
+
+def defaults_block(args, torch, dist, dev, local_rank, t1, t2, img1, img2):
+    """The reference's DEFAULT configuration on the same pair and grid (pmlib.py:118 angles = [-3, 0, 3]; pmlib.py:329
+    img_size = 35): timed like the headline, every point of the timed output compared with the C oracle."""
+    import copy
+    import numpy as np
+    from oracle import c_oracle
+    from sea_ice_drift_amd.pmlib import rotation_table
+    a2 = copy.copy(args)
+    a2.img_size, a2.force_collective = 35, False
+    angles = [-3, 0, 3]
+    rot = rotation_table(angles, 0.0, a2.img_size)
+    run = GridRun(a2, dev, 1, 0, local_rank, t1, t2, a2.grid, angles, rot)
+    elapsed, kern_ms = timed_steps(torch, dist, 1, run, args.steps, args.warmup)
+    run.poisoned_step()
+    res, res_ij = run.results()
+    g, n_total, info = run.g, run.n_total, run.info
+    run.close()
+    c_oracle.build()
+    tc = time.perf_counter()
+    exp, exp_ij = c_oracle.pm_batch(img1, img2, g['c1'], g['r1'], g['c2fg'], g['r2fg'], g['border'], a2.img_size, 0.0, angles,
+                                    rot=rot, nthreads=host_cores())
+    dt = time.perf_counter() - tc
+    bad_ij = ~np.all(res_ij == exp_ij, axis=1)
+    a, b = res[:, :4], exp[:, :4]
+    bad_v = ~np.all((a == b) | (np.isnan(a) & np.isnan(b)), axis=1)
+    bad_h = ~np.isclose(res[:, 4], exp[:, 4], rtol=1e-5, atol=1e-5, equal_nan=True)
+    ok = not (bad_ij.any() or bad_v.any() or bad_h.any())
+    return {'workload': '%dx%d grid on the same pair, template 35 px (pmlib.py:329), angles [-3, 0, 3] (pmlib.py:118), border %s'
+                        % (a2.grid, a2.grid, args.border),
+            'value': n_total / (elapsed / args.steps), 'unit': 'grid-points/s', 'ms_per_step': elapsed / args.steps * 1e3,
+            'kernel_ms_per_step': kern_ms, 'launches_per_step': info['launches'],
+            'roofline_frac_mfma': 2.0 * info['macs'] / (kern_ms * 1e-3) / 1e12 / MFMA_I8_PEAK_TOPS,
+            'cpu_oracle_points_per_s': n_total / dt,
+            'parity_check': {'points': int(n_total), 'ok': bool(ok),
+                             'mismatches': {'peak_or_angle_index': int(bad_ij.sum()), 'c2_r2_a_r_bits': int(bad_v.sum()),
+                                            'h_beyond_1e-5': int(bad_h.sum())}}}
 
 
 def stream_mode(args, torch, dist, dev, world, rank, local_rank):
@@ -465,6 +557,8 @@ def stream_mode(args, torch, dist, dev, world, rank, local_rank):
 
     run = Run()
     elapsed, kern_ms = timed_steps(torch, dist, world, run, args.steps, args.warmup)
+    from sea_ice_drift_amd.dist import per_rank_breakdown
+    per_rank = per_rank_breakdown([timed_steps.local_elapsed / args.steps * 1e3, kern_ms, len(mine)], dev) if world > 1 else None
     line = None
     # parity: up to three pairs of this rank against the oracle on a subsample (checker only)
     ok, checked = True, 0
@@ -507,6 +601,12 @@ def stream_mode(args, torch, dist, dev, world, rank, local_rank):
             'parity_check': {'pairs_checked_per_rank': checked, 'ok': ok},
             'setup_s': {'generate_and_pin_pairs': t_gen},
         }
+        if per_rank is not None:                               # every rank's own clock: the slowest one is named
+            line['step_breakdown_ms'] = {'per_rank': {'batch_ms': [float(v) for v in per_rank[:, 0]],
+                                                      'kernel_ms_first_pair': [float(v) for v in per_rank[:, 1]],
+                                                      'pairs': [int(v) for v in per_rank[:, 2]]},
+                                         'slowest_rank': int(per_rank[:, 0].argmax()), 'slowest_batch_ms': float(per_rank[:, 0].max()),
+                                         'fastest_batch_ms': float(per_rank[:, 0].min())}
         if not ok:
             print(json.dumps(line))
             raise SystemExit('PARITY FAILURE against the CPU oracle - the number above is invalid')

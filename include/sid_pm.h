@@ -132,13 +132,28 @@ int sid_pm_bind_results(sid_pm_ctx *ctx, double *d_out, int32_t *d_out_ij);
 
 /* Enqueue the kernels for the resident points on the resident pair (asynchronous). */
 int sid_pm_run(sid_pm_ctx *ctx);
-/* Wait for the stream. */
+/* Wait for the stream; then sid_pm_check. */
 int sid_pm_sync(sid_pm_ctx *ctx);
-/* Copy results to the host (waits for the stream).  out_ij may be NULL. */
+/* Points with a valid search window that a launch of the runs since the last check refused (the LDS layout the kernel
+ * computes for the point did not fit the launch the host's classification sized for it - a library bug, not a property of
+ * the data): SID_PM_ERR_STATE with the count in sid_pm_last_error(), and the counter is cleared.  Such a point would
+ * otherwise be indistinguishable from the reference's legitimate NaN row (zero pixel in the template, pmlib.py:152-154).
+ * Reads a pinned host word the kernels write: call it once the launch stream is synchronised, by whatever means
+ * (sid_pm_sync and sid_pm_fetch do). */
+int sid_pm_check(sid_pm_ctx *ctx);
+/* Copy results to the host (waits for the stream; then sid_pm_check).  out_ij may be NULL. */
 int sid_pm_fetch(sid_pm_ctx *ctx, double *out, int32_t *out_ij);
 /* Device pointers of the result arrays ([n][5] float64, [n][3] int32, original point
  * order) for device-side consumers such as an RCCL gather.  Valid until set_points/destroy. */
 int sid_pm_device_results(sid_pm_ctx *ctx, double **d_out, int32_t **d_out_ij);
+
+/* Exchange step of the N-GPU path (what Pool.map's result list is to the reference, pmlib.py:444,462): `world` blocks of m
+ * rows [m x 5 float64 | m x 3 int32] - every rank's kernels wrote one in place, one RCCL gather stacked them on the
+ * destination rank - are put back into the original point order in one kernel: out[i] / out_ij[i] = row d_perm[i] of the
+ * stacked blocks (m even).  `out` / `out_ij` may be pinned host memory (any device-visible pointer): the results then
+ * reach the host without a copy after the kernel.  out_ij may be NULL.  Asynchronous on `hip_stream`. */
+int sid_pm_unpermute(const void *d_stack, int64_t world, int64_t m, const int32_t *d_perm, int64_t n,
+                     double *out, int32_t *out_ij, void *hip_stream);
 
 /* Work accounting of the resident points, for roofline reporting (DESIGN.md "Measurement"):
  *   info[0] = kernel launches per run          info[1] = valid points

@@ -21,7 +21,7 @@ ABI_VERSION = 2
 SYMBOLS = (
     'sid_pm_abi_version', 'sid_pm_strerror', 'sid_pm_last_error', 'sid_pm_device_count',
     'sid_pm_batch', 'sid_pm_create', 'sid_pm_destroy', 'sid_pm_set_stream', 'sid_pm_upload_pair',
-    'sid_pm_select_pair', 'sid_pm_bind_pair', 'sid_pm_set_points', 'sid_pm_bind_results', 'sid_pm_run', 'sid_pm_sync',
+    'sid_pm_select_pair', 'sid_pm_bind_pair', 'sid_pm_set_points', 'sid_pm_bind_results', 'sid_pm_run', 'sid_pm_sync', 'sid_pm_check', 'sid_pm_unpermute',
     'sid_pm_fetch', 'sid_pm_device_results', 'sid_pm_work_info', 'sid_pm_debug_point', 'sid_pm_debug_ncc_selftest',
     'sid_pm_debug_rsqrt', 'sid_pm_debug_hypot_selftest', 'sid_pm_estimate_cost', 'sid_pm_estimate_residency',
 )
@@ -90,6 +90,8 @@ def lib():
     L.sid_pm_bind_results.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     L.sid_pm_run.argtypes = [C.c_void_p]
     L.sid_pm_sync.argtypes = [C.c_void_p]
+    if hasattr(L, 'sid_pm_check'):               # (absent from the libraries of earlier rounds that A/B runs load through SID_PM_LIB)
+        L.sid_pm_check.argtypes = [C.c_void_p]
     L.sid_pm_fetch.argtypes = [C.c_void_p, _f64p, _i32p]
     L.sid_pm_device_results.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]
     L.sid_pm_work_info.argtypes = [C.c_void_p, _f64p]
@@ -98,6 +100,8 @@ def lib():
                                                                       _i32p, _f64p, _i32p, C.POINTER(C.c_int64)]
     L.sid_pm_debug_rsqrt.argtypes = [C.c_void_p, _f64p, _f64p, C.c_int64]
     L.sid_pm_debug_ncc_selftest.argtypes = [C.c_void_p, C.c_uint64, C.c_int64, C.c_int, C.POINTER(C.c_uint64)]
+    if hasattr(L, 'sid_pm_unpermute'):
+        L.sid_pm_unpermute.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
     L.sid_pm_estimate_cost.argtypes = [_f64p, C.c_int64, C.c_int, C.c_int, _f64p]
     L.sid_pm_estimate_residency.argtypes = [_f64p, C.c_int64, C.c_int, C.c_int, _i32p]
     L.sid_pm_debug_hypot_selftest.argtypes = [C.c_void_p, C.c_uint64, C.c_int64, C.POINTER(C.c_uint64)]
@@ -123,8 +127,11 @@ def lib():
     L.sid_fg_interp_linear.argtypes = [C.c_int, _f64p, C.c_int64, _i32p, C.c_int64, _f64p, _f64p, C.c_int64, _f64p, _i32p, _i32p]
     L.sid_fg_nearest_dist.argtypes = [C.c_int, _f64p, C.c_int64, _f64p, C.c_int64, _f64p]
     L.sid_fg_last_error.restype = C.c_char_p
+    # SID_PM_LIB (A/B runs against the library of an earlier round) may lack the entry points added since
+    optional = ('sid_pm_check', 'sid_pm_unpermute') if os.environ.get('SID_PM_LIB') else ()
     for name in SYMBOLS:
-        getattr(L, name)                      # AttributeError here = header/library mismatch
+        if name not in optional:
+            getattr(L, name)                  # AttributeError here = header/library mismatch
     if L.sid_pm_abi_version() != ABI_VERSION:
         raise ImportError('libsid_pm.so ABI %d != binding ABI %d' % (L.sid_pm_abi_version(), ABI_VERSION))
     _lib = L
@@ -159,6 +166,11 @@ def _f64(a):
 
 def _p(a, t):
     return a.ctypes.data_as(t)
+
+
+def unpermute(stack_ptr, world, m, perm_ptr, n, out_ptr, ij_ptr, stream):
+    """``sid_pm_unpermute`` on raw device(-visible) pointers (torch ``data_ptr()``) and a HIP stream handle."""
+    _check(lib().sid_pm_unpermute(stack_ptr, int(world), int(m), perm_ptr, int(n), out_ptr, ij_ptr, stream))
 
 
 def estimate_cost(border, img_size=34, n_angles=15):
@@ -340,6 +352,12 @@ class PMContext(object):
 
     def sync(self):
         _check(lib().sid_pm_sync(self._h))
+
+    def check(self):
+        """Raise if a launch refused a point with a valid window (``sid_pm_check``); for callers that synchronise the
+        stream themselves (torch) instead of through ``sync`` / ``fetch``."""
+        if hasattr(lib(), 'sid_pm_check'):
+            _check(lib().sid_pm_check(self._h))
 
     def fetch(self, want_ij=True):
         out = np.empty((self.n, 5), dtype=np.float64)

@@ -102,6 +102,7 @@ struct sid_pm_ctx {
     DevBuf<double> out;
     DevBuf<int32_t> out_ij;
     DevBuf<int32_t> dbg_err;            // debugging builds only (SID_PM_DEBUG_CHECK=1)
+    int32_t *h_refused = nullptr;       // pinned, device-visible: valid points a launch could not hold (PMArgs::refused)
     double *user_out = nullptr;         // caller-owned result arrays (bind_results)
     int32_t *user_ij = nullptr;
     std::vector<Bucket> buckets;
@@ -281,6 +282,7 @@ int fill_args(sid_pm_ctx *ctx, sid::PMArgs &A)
     A.angles = ctx->d_angles; A.rot = ctx->d_rot; A.samp = ctx->have_samp ? ctx->d_samp : nullptr; A.samp_nflag = ctx->samp_nflag;
     A.out = ctx->user_out ? ctx->user_out : ctx->out.p;
     A.out_ij = ctx->user_out ? ctx->user_ij : ctx->out_ij.p;
+    A.refused = ctx->h_refused;
     if (getenv("SID_PM_DEBUG_CHECK")) {
         if (!ctx->dbg_err.p && ctx->dbg_err.reserve(320) == SID_PM_OK) (void)hipMemset(ctx->dbg_err.p, 0, 320 * sizeof(int32_t));
         A.dbg_err = ctx->dbg_err.p;
@@ -508,7 +510,9 @@ SID_EXPORT int sid_pm_create(int device, sid_pm_ctx **out)
             e = hipEventCreateWithFlags(&ctx->slot_ready[k], hipEventDisableTiming);
             if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->slot_done[k], hipEventDisableTiming);
         }
+        if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void **>(&ctx->h_refused), sizeof(int32_t), hipHostMallocMapped);
         if (e != hipSuccess) { sid_pm_destroy(ctx); return fail(SID_PM_ERR_HIP, "stream/event creation failed: %s", hipGetErrorString(e)); }
+        *ctx->h_refused = 0;
     }
     *out = ctx;
     return SID_PM_OK;
@@ -527,6 +531,7 @@ SID_EXPORT void sid_pm_destroy(sid_pm_ctx *ctx)
     for (auto &pair : ctx->own) for (auto &b : pair) b.release();
     ctx->arena.release();
     ctx->out.release(); ctx->out_ij.release(); ctx->dbg_err.release();
+    if (ctx->h_refused) (void)hipHostFree(ctx->h_refused);
     delete ctx;
 }
 
@@ -694,12 +699,26 @@ SID_EXPORT int sid_pm_run(sid_pm_ctx *ctx)
     return SID_PM_OK;
 }
 
+// Valid points the kernels refused since the last check (the launch their classification put them in could not hold
+// their LDS layout: host and device disagree - a bug, reported as an error instead of the NaN row the point received).
+// Reads a pinned host word: call it once the launch stream is synchronised, by whatever means.
+SID_EXPORT int sid_pm_check(sid_pm_ctx *ctx)
+{
+    if (!ctx) return fail(SID_PM_ERR_ARG, "null ctx");
+    if (!ctx->h_refused) return SID_PM_OK;
+    const int32_t n = __atomic_exchange_n(ctx->h_refused, 0, __ATOMIC_ACQ_REL);
+    if (n != 0)
+        return fail(SID_PM_ERR_STATE, "%d grid point(s) with a valid search window were refused by their launch (LDS layout of the "
+                                      "kernel and classification of the host disagree); their rows hold NaN", (int)n);
+    return SID_PM_OK;
+}
+
 SID_EXPORT int sid_pm_sync(sid_pm_ctx *ctx)
 {
     if (!ctx) return fail(SID_PM_ERR_ARG, "null ctx");
     Guard g(ctx->device);
     HIP_TRY(hipStreamSynchronize(ctx->stream));
-    return SID_PM_OK;
+    return sid_pm_check(ctx);
 }
 
 SID_EXPORT int sid_pm_fetch(sid_pm_ctx *ctx, double *out, int32_t *out_ij)
@@ -731,6 +750,39 @@ SID_EXPORT int sid_pm_fetch(sid_pm_ctx *ctx, double *out, int32_t *out_ij)
             (void)hipMemset(ctx->dbg_err.p, 0, sizeof e);
         }
     }
+    return sid_pm_check(ctx);
+}
+
+// ---- exchange step of the N-GPU path: the gathered per-rank blocks -> original point order, in ONE pass ----
+// stack: `world` blocks of m rows [m x 5 float64 | m x 3 int32] (what every rank's kernels wrote, gathered by RCCL);
+// perm[i] = row of point i in the stacked blocks.  One thread per (point, field): eight threads move the 52 bytes of a
+// point, so the writes of a wavefront are 8 x 40 + 8 x 12 contiguous bytes.  `out` / `out_ij` may be pinned host memory:
+// the results then reach the host without a copy after the kernel (posted PCIe writes).
+namespace {
+__global__ void unpermute_rows_kernel(const uint8_t *stack, int64_t m, const int32_t *perm, int64_t n, double *out, int32_t *out_ij)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t i = t >> 3;
+    const int f = (int)(t & 7);
+    if (i >= n) return;
+    const int64_t row = perm[i], blk = row / m, r = row - blk * m;
+    const uint8_t *base = stack + blk * m * 52;
+    if (f < 5) out[i * 5 + f] = reinterpret_cast<const double *>(base)[r * 5 + f];
+    else if (out_ij) out_ij[i * 3 + (f - 5)] = reinterpret_cast<const int32_t *>(base + m * 40)[r * 3 + (f - 5)];
+}
+}  // namespace
+
+SID_EXPORT int sid_pm_unpermute(const void *d_stack, int64_t world, int64_t m, const int32_t *d_perm, int64_t n,
+                                double *out, int32_t *out_ij, void *hip_stream)
+{
+    if (n < 0 || world < 1 || m < 1 || (m & 1) || (n > 0 && (!d_stack || !d_perm || !out)))
+        return fail(SID_PM_ERR_ARG, "unpermute: bad argument (rows per block must be even: the blocks then keep their doubles aligned)");
+    if (n == 0) return SID_PM_OK;
+    const int64_t threads = n * 8;
+    hipLaunchKernelGGL(unpermute_rows_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(hip_stream),
+                       static_cast<const uint8_t *>(d_stack), m, d_perm, n, out, out_ij);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(SID_PM_ERR_HIP, "unpermute: %s", hipGetErrorString(e));
     return SID_PM_OK;
 }
 

@@ -28,6 +28,10 @@ struct PMArgs {
     double gauss_w[5];                              // hes_smth: normalised sigma-1 Gaussian taps w[0] (|k| = 4) .. w[4] (centre), host-computed
     double *out;                                    // [n_total][5]
     int32_t *out_ij;                                // [n_total][3]
+    // points with a valid search window that the kernel refused because the launch did not fit them (LDS size or window
+    // pitch chosen by the host's classification): counted here - pinned host memory, read by sid_pm_sync / sid_pm_fetch /
+    // sid_pm_check - so that a disagreement between host and device layout is an error, never a silent NaN
+    int32_t *refused;
     // diagnostics (debug_point only; null in production launches)
     uint8_t *dbg_templates; float *dbg_ccm; float *dbg_hes; int32_t *dbg_shape; int64_t dbg_cap;
     long long *dbg_cycles;                          // [32] shader-clock stamps at phase boundaries
@@ -40,6 +44,7 @@ __host__ __device__ inline int round_up(int v, int m) { return (v + m - 1) / m *
 constexpr int kMiscMfmaBytes = 2688;
 constexpr int kTrowPad = 36;         // zero rows around a winner operand block: 16 above, 20 below (the step loop runs in fours)
 constexpr int kQueueCap = 192;       // arg-max candidates waiting for exact evaluation (16 B each)
+constexpr int kRpQueueMin = 64;      // row-pair kernel: the queue shrinks to this where it decides the residency class (overflow is evaluated in place)
 
 struct MfmaLdsLayout {
     int wpitch;        // bytes per window row (int8, re-centred)
@@ -98,17 +103,19 @@ __host__ __device__ inline MfmaLdsLayout mfma_lds_layout(int wh, int ww, int s, 
 // ---- row-pair kernel (pm_kernel_rp.inc): template sides 34 and 35, more than kPairedMaxAngles angles ----
 // Sweep operands: the template columns 0..31 live in a table [row -1 .. s+1][16 slots][32 B] (zero rows around),
 // from which one MFMA operand = two consecutive template rows x 32 columns (K = 64 all useful); the columns
-// 32.. ("strip") are multiplied through a column-pair copy of the window, WP[u][rho] = (W[rho][u], W[rho][u+1]),
-// so that K = 32 window rows x 2 columns.
+// 32.. ("strip") are multiplied through a TRANSPOSED copy of the window columns 32.., WT[v][rho] = W[rho][32 + v],
+// so that K = 2 window columns x 32 rows and a lane's operand is 16 contiguous bytes of one WT row (round 4: half the
+// LDS of the column-pair copy of rounds 2-3, which moves borders 24-26 to three and 37-41 to two workgroups per CU).
 constexpr int kRpGroup = 15;    // angles per group of MFMA slots (the 16th slot is the all-ones template)
 struct RpLdsLayout {
     int wpitch, wrows;          // window pitch (multiple of 8) and rows written (window + zero rows)
     int win_off, sii_off;
-    int wp_off, wp_pitch, wp_rows, wp_len;   // column-pair copy: wp_rows rows (u = 32 + row) of wp_len entries (2 B each)
+    int wp_off, wp_pitch, wp_rows, wp_len;   // transposed window columns 32..: wp_rows rows (window column 32 + row) of wp_len bytes (one per window row)
     int u_off;                  // union: column sums | table + strip + patch + queue | winner operands + NCC matrix
     int tab_rows, tab_pitch;    // s + 3 rows of tab_pitch bytes (32 per stored slot)
     int strip_off, ncp, nrg;    // strip operand fragments: ncp column pairs x nrg row groups, 1 KB each
     int patch_off, ppitch, pdim, pradius, queue_off, trow_bytes;
+    int queue_cap;              // candidate-queue entries (16 B each): kRpQueueMin .. kQueueCap, as many as the residency class leaves room for
     int npair, nsingle;         // x tiling of a band: npair items of 32 placements, then nsingle (0/1) of 16
     int total;
 };
@@ -167,11 +174,13 @@ __host__ __device__ inline RpLdsLayout rp_lds_layout(int wh, int ww, int s, bool
     L.sii_off = round_up(L.win_off + L.wrows * L.wpitch, 16);
     L.u_off = round_up(L.sii_off + rh * rw * 4, 16);
     L.ncp = (s - 32 + 1) / 2; L.nrg = 2;
-    L.wp_rows = rw + 2 * (L.ncp - 1);
-    L.wp_len = y0max + 40 + band;                    // last read: entries y0max + 32 .. + 32 + 11 (band 4: 24 bytes) / + 15 (band 8: 32 bytes)
-    //                           // entries rho = 0 .. y0max + 3 + 32 + 8 (+ slack of a 24-byte read)
-    L.wp_pitch = round_up(2 * L.wp_len, 8);
-    if (!((L.wp_pitch / 8) & 1)) L.wp_pitch += 8;    // 8 x odd: at most two-way bank conflicts for the lane-private rows
+    // transposed copy: one row per window column 32 .. 32 + rw - 1 + 2 ncp - 1 (the builder writes four rows at a time);
+    // a lane reads 20 bytes (4-row band: shifts 0..3 + 16) or 24 (8-row band) from rho = y0 + 16 (g >> 1) (template rows
+    // 0..31) and from y0 + 32 (rows 32..47), so the last byte read is y0max + 32 + 23
+    L.wp_rows = rw + 2 * L.ncp - 1;
+    L.wp_len = y0max + 56;
+    L.wp_pitch = round_up(L.wp_len, 4);
+    if (!((L.wp_pitch / 4) & 1)) L.wp_pitch += 4;    // 4 x odd: the 16 rows read by the lanes of one k-group fall into distinct banks
     L.tab_rows = s + 3;
     L.tab_pitch = tab_pitch;
     L.strip_off = L.u_off + L.tab_rows * tab_pitch;
@@ -186,14 +195,15 @@ __host__ __device__ inline RpLdsLayout rp_lds_layout(int wh, int ww, int s, bool
     // loaded together with the window only where they do not lie on the column sums (pm_kernel_rp: patch_early); with a
     // short operand table (slot groups) the natural place does, so the patch is moved up behind the column sums - unless
     // the larger footprint would cost a workgroup per CU.
-    auto place = [&](int patch_off) {
+    auto place = [&](int patch_off, int cap) {
         L.patch_off = patch_off;
+        L.queue_cap = cap;
         const int patch_end = round_up(L.patch_off + L.pdim * L.ppitch + 1, 16);
         L.queue_off = one_group ? round_up(L.patch_off, 16) : patch_end;
-        // the column-pair copy only lives during the sweep: behind the queue, inside the union (built after the
-        // column sums are dead, overwritten by the winner's NCC matrix)
-        L.wp_off = round_up(L.queue_off + kQueueCap * 16, 16);
-        if (L.wp_off < patch_end) L.wp_off = patch_end;          // (the column-pair copy is built while the patch is live)
+        // the transposed columns only live during the sweep: behind the queue, inside the union (built when the templates
+        // are - with one group of angles the patch is dead by then and they lie over it, like the queue -, overwritten by
+        // the winner's NCC matrix)
+        L.wp_off = round_up(L.queue_off + cap * 16, 16);
         int u = rh * ww * 4;
         const int sweep = L.wp_off + L.wp_rows * L.wp_pitch - L.u_off;
         if (u < sweep) u = sweep;
@@ -204,11 +214,18 @@ __host__ __device__ inline RpLdsLayout rp_lds_layout(int wh, int ww, int s, bool
         L.total = round_up(L.u_off + u, 16);
     };
     const int natural = L.strip_off + L.ncp * L.nrg * 1024 + 16, clear = round_up(L.u_off + rh * ww * 4, 16);   // (+ 16 scratch bytes)
-    place(natural);
+    // the candidate queue takes what its residency class leaves: the smallest queue decides the class, then it grows
+    auto place_q = [&](int patch_off) {
+        place(patch_off, kRpQueueMin);
+        const int room = (rp_class_limit(L.total) - L.wp_rows * L.wp_pitch - L.queue_off) / 16;   // entries that keep the class
+        const int cap = room > kQueueCap ? kQueueCap : room;
+        if (cap > kRpQueueMin) place(patch_off, cap);
+    };
+    place_q(natural);
     if (tab_pitch < 512 && clear > natural) {                    // (full table: measured no gain at the borders it would change)
         const int limit = rp_class_limit(L.total);
-        place(clear);
-        if (L.total > limit) place(natural);
+        place_q(clear);
+        if (L.total > limit) place_q(natural);
     }
     return L;
 }
@@ -217,7 +234,7 @@ __host__ __device__ inline RpLdsLayout rp_lds_layout(int wh, int ww, int s, bool
 // `natural`, or 0 (run-time pitch) beyond the largest
 __host__ __device__ inline int rp_class_pitch(int natural)
 {
-    return natural <= 104 ? 104 : natural <= 136 ? 136 : natural <= 168 ? 168 : 0;
+    return natural <= 104 ? 104 : natural <= 112 ? 112 : natural <= 136 ? 136 : natural <= 168 ? 168 : 0;
 }
 // paired: 0 = one group of 16 slots, 1 = two groups (at most 7 angles), 2 = four groups (at most 3 angles)
 // occ: wavefronts per SIMD the build allows - 3, or 4 (128 VGPRs; slot groups with pitch 104 only: four workgroups per CU)

@@ -103,6 +103,7 @@ struct Geo {
     u32 patch_magic, rw_magic;       // same for ppitch/4 and for rw
     int band;                        // output rows per sweep work item (kernel template parameter)
     int wp_off, wp_pitch, wp_rows, strip_off, wrows, npair, nsingle;   // row-pair kernel (RpLdsLayout)
+    int queue_cap;                   // row-pair kernel: entries of the candidate queue (RpLdsLayout::queue_cap)
     int hist_off;                    // 5 KB behind the NCC matrix of the winning angle for ph_hessian_fast (0: none - the general ph_hessian runs)
     long long r0, c0;                // window origin on image 2
     double c1, r1, nd;
@@ -1776,6 +1777,7 @@ __global__ __launch_bounds__(BAND == 8 ? 512 : kMaxBlockM, BAND == 8 ? 2 : kOccM
     // the launch was sized by the host for the image shape it classified the points with (pm_capi.hip
     // classify_points); a window that needs more LDS than that must never be touched
     if (mfma_lds_layout(wh, ww, s, BAND, PAIRED).total > A.lds_bytes) {
+        if (tid == 0 && A.refused) atomicAdd(A.refused, 1);            // an error the host reports (PMArgs::refused), never a silent NaN
         if (tid < 5) out[tid] = NAN;
         if (oij && tid < 3) oij[tid] = -1;
         return;
@@ -2038,12 +2040,12 @@ int launch_pm_mfma(const PMArgs &args, int lds_bytes, int nthreads, int band, bo
 template <int S>
 static void (*rp_kernel_for(int band, int paired, int pitch))(const PMArgs)
 {
-    if (paired == 2) return pitch == 104 ? pm_kernel_rp<S, 4, 2, 104> : pitch == 136 ? pm_kernel_rp<S, 4, 2, 136>
+    if (paired == 2) return pitch == 104 ? pm_kernel_rp<S, 4, 2, 104> : pitch == 112 ? pm_kernel_rp<S, 4, 2, 112> : pitch == 136 ? pm_kernel_rp<S, 4, 2, 136>
                           : pitch == 168 ? pm_kernel_rp<S, 4, 2, 168> : pitch == 0 ? pm_kernel_rp<S, 4, 2, 0> : nullptr;
-    if (paired == 1) return pitch == 104 ? pm_kernel_rp<S, 4, 1, 104> : pitch == 136 ? pm_kernel_rp<S, 4, 1, 136>
+    if (paired == 1) return pitch == 104 ? pm_kernel_rp<S, 4, 1, 104> : pitch == 112 ? pm_kernel_rp<S, 4, 1, 112> : pitch == 136 ? pm_kernel_rp<S, 4, 1, 136>
                           : pitch == 168 ? pm_kernel_rp<S, 4, 1, 168> : pitch == 0 ? pm_kernel_rp<S, 4, 1, 0> : nullptr;
     if (band == 8) return pitch == 136 ? pm_kernel_rp<S, 8, 0, 136> : pitch == 0 ? pm_kernel_rp<S, 8, 0, 0> : nullptr;
-    return pitch == 104 ? pm_kernel_rp<S, 4, 0, 104> : pitch == 136 ? pm_kernel_rp<S, 4, 0, 136>
+    return pitch == 104 ? pm_kernel_rp<S, 4, 0, 104> : pitch == 112 ? pm_kernel_rp<S, 4, 0, 112> : pitch == 136 ? pm_kernel_rp<S, 4, 0, 136>
          : pitch == 168 ? pm_kernel_rp<S, 4, 0, 168> : pitch == 0 ? pm_kernel_rp<S, 4, 0, 0> : nullptr;
 }
 

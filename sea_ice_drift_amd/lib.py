@@ -59,7 +59,33 @@ def get_speed_ms(n1, x1, y1, n2, x2, y2):
 
 
 def _is_projected(nsr):
-    return nsr is not None and getattr(nsr, 'srs', None) not in (None, '')
+    """True when ``nsr`` names a projected spatial reference.  Understood: an ``osr.SpatialReference`` (what nansat's NSR
+    is: ``IsGeographic()``), the local placeholder (``.srs``), anything else that carries its definition as ``.wkt`` -
+    a definition that reads as geographic ('+proj=longlat', 'GEOGCS[', 'GEOGCRS[') is not projected."""
+    if nsr is None:
+        return False
+    is_geographic = getattr(nsr, 'IsGeographic', None)
+    if callable(is_geographic):
+        try:
+            return not bool(is_geographic())
+        except Exception:                        # noqa: BLE001
+            pass
+    text = getattr(nsr, 'srs', None)
+    if text in (None, ''):
+        text = getattr(nsr, 'wkt', None)
+    if text in (None, ''):
+        return False
+    text = str(text).lstrip()
+    return not ('+proj=longlat' in text or '+proj=latlong' in text or text.upper().startswith(('GEOGCS', 'GEOGCRS')))
+
+
+def _nansat_domain():
+    """nansat's ``Domain`` class when nansat is installed, else None."""
+    try:
+        from nansat import Domain                # pragma: no cover - not installed in this image
+    except Exception:                            # noqa: BLE001
+        return None
+    return Domain                                # pragma: no cover
 
 
 def get_drift_vectors(n1, x1, y1, n2, x2, y2, nsr=None, **kwargs):
@@ -70,23 +96,22 @@ def get_drift_vectors(n1, x1, y1, n2, x2, y2, nsr=None, **kwargs):
     a point in ``nsr``, its pixel is (X + 10, 10 - Y), so u = (X2 + 10) - (X1 + 10) and v = (10 - Y1) - (10 - Y2).
     That arithmetic is restated here.  Where (X, Y) come from:
 
-    * default ``nsr`` (lon/lat WGS84): X = lon, Y = lat;
-    * a projected ``nsr`` with nansat installed: the reference's own Domain call;
-    * a projected ``nsr`` without nansat: the images' own ``transform_points(x, y, 0, nsr)`` (pixel -> coordinates
+    * nansat installed: the reference's own Domain call, for every ``nsr``;
+    * no nansat, default or geographic ``nsr`` (lon/lat WGS84): X = lon, Y = lat;
+    * no nansat, projected ``nsr`` (``_is_projected``: an ``osr.SpatialReference`` that is not geographic, the local
+      placeholder's ``.srs``, or a ``.wkt`` that does not read as geographic): the images' own ``transform_points(x, y, 0, nsr)`` (pixel -> coordinates
       in the destination SRS, the call pm_postlude makes for ``srs=``, pmlib.py:473-478; Appendix A of SURVEY.md) -
       any Nansat-like object that implements it serves; one that does not raises NotImplementedError."""
     lon1, lat1 = n1.transform_points(x1, y1)
     lon2, lat2 = n2.transform_points(x2, y2)
+    Domain = _nansat_domain()
+    if nsr is not None and Domain is not None:
+        # nansat is installed: the reference's own call for every nsr, geographic or projected (lib.py:394-399)
+        d = Domain(nsr, '-te -10 -10 10 10 -tr 1 1')
+        px1, py1 = d.transform_points(lon1, lat1, 1)
+        px2, py2 = d.transform_points(lon2, lat2, 1)
+        return px2 - px1, py1 - py2, lon1, lat1, lon2, lat2
     if _is_projected(nsr):
-        try:
-            from nansat import Domain            # pragma: no cover - not installed in this image
-        except Exception:                        # noqa: BLE001
-            Domain = None
-        if Domain is not None:                                                # pragma: no cover
-            d = Domain(nsr, '-te -10 -10 10 10 -tr 1 1')
-            px1, py1 = d.transform_points(lon1, lat1, 1)
-            px2, py2 = d.transform_points(lon2, lat2, 1)
-            return px2 - px1, py1 - py2, lon1, lat1, lon2, lat2
         try:
             X1, Y1 = n1.transform_points(x1, y1, 0, nsr)
             X2, Y2 = n2.transform_points(x2, y2, 0, nsr)

@@ -21,36 +21,45 @@ int main()
                         const int hws = s / 2, wh = 2 * hws + 2 * b + 1, ww = wh - dw;
                         if (ww < s + 1) continue;
                         const int rows = paired == 2 ? 16 : paired == 1 ? 8 : band, tp = rp_tab_pitch(paired);
-                        const RpLdsLayout N = rp_lds_layout(wh, ww, s, true, rows, 0, tp);
+                        for (int one_group = 0; one_group <= 1; ++one_group) {
+                        const RpLdsLayout N = rp_lds_layout(wh, ww, s, one_group != 0, rows, 0, tp);
                         const int cp = rp_class_pitch(N.wpitch);
                         for (int pitch : {0, cp}) {
                             if (pitch && pitch < N.wpitch) continue;
-                            const RpLdsLayout L = rp_lds_layout(wh, ww, s, true, rows, pitch, tp);
+                            const RpLdsLayout L = rp_lds_layout(wh, ww, s, one_group != 0, rows, pitch, tp);
                             const int rh = wh - s + 1, rw = ww - s + 1;
-                            char tag[96]; snprintf(tag, sizeof tag, "s=%d paired=%d band=%d b=%d dw=%d pitch=%d", s, paired, band, b, dw, pitch);
+                            char tag[96]; snprintf(tag, sizeof tag, "s=%d paired=%d band=%d b=%d dw=%d pitch=%d groups=%s", s, paired, band, b, dw, pitch, one_group ? "one" : "several");
                             CHECK(L.wpitch >= ww && L.wpitch % 8 == 0 && (!pitch || L.wpitch == pitch), "%s: window pitch %d", tag, L.wpitch);
                             CHECK(L.win_off >= kMiscMfmaBytes && L.sii_off >= L.win_off + L.wrows * L.wpitch, "%s: window overlaps the sums", tag);
                             CHECK(L.u_off >= L.sii_off + rh * rw * 4, "%s: sums overlap the union", tag);
                             CHECK(L.tab_pitch == tp && L.strip_off == L.u_off + L.tab_rows * tp, "%s: table", tag);
                             CHECK(L.patch_off >= L.strip_off + L.ncp * L.nrg * 1024 + 16, "%s: patch overlaps the strip operands", tag);
-                            CHECK(L.queue_off >= L.patch_off && L.wp_off >= L.queue_off + kQueueCap * 16, "%s: queue / column-pair copy", tag);
-                            CHECK(L.wp_off >= L.patch_off + L.pdim * L.ppitch, "%s: column-pair copy overlaps the patch", tag);
-                            CHECK(L.wp_off + L.wp_rows * L.wp_pitch <= L.total, "%s: column-pair copy beyond the end", tag);
+                            CHECK(L.queue_cap >= kRpQueueMin && L.queue_cap <= kQueueCap, "%s: queue of %d entries", tag, L.queue_cap);
+                            CHECK(L.queue_off >= L.patch_off && L.wp_off >= L.queue_off + L.queue_cap * 16, "%s: queue / transposed columns", tag);
+                            // several groups of angles: the patch stays live through the sweeps; one group: queue and columns lie over it
+                            if (!one_group) CHECK(L.queue_off >= L.patch_off + L.pdim * L.ppitch + 1, "%s: queue overlaps the live patch", tag);
+                            CHECK(L.patch_off + L.pdim * L.ppitch + 1 <= L.total, "%s: patch beyond the end", tag);
+                            CHECK(L.wp_rows >= rw + 2 * L.ncp - 1 && L.wp_pitch % 4 == 0 && ((L.wp_pitch / 4) & 1), "%s: transposed columns %d x %d", tag, L.wp_rows, L.wp_pitch);
+                            // last strip read: 24 bytes from y0max + 32 (rp_item_strip); y0max <= rh - 1 rounded up to the band
+                            CHECK(L.wp_pitch >= rp_band_y0((rh + rows - 1) / rows - 1, (rh + rows - 1) / rows, rh, rows) + 56, "%s: transposed row too short", tag);
+                            CHECK(L.wp_off + L.wp_rows * L.wp_pitch <= L.total, "%s: transposed columns beyond the end", tag);
                             CHECK(L.u_off + rh * ww * 4 <= L.total, "%s: column sums beyond the end", tag);
-                            CHECK(L.u_off + 2 * L.trow_bytes + rh * rw * 4 + 5120 <= L.total, "%s: winner + histogram beyond the end", tag);
+                            CHECK(L.u_off + 2 * L.trow_bytes + rh * rw * 4 + (one_group ? 5120 : 0) <= L.total, "%s: winner + histogram beyond the end", tag);
                             CHECK(L.total % 16 == 0, "%s: total %d", tag, L.total);
                             if (b <= 50 && dw == 0) CHECK(L.total <= 160 * 1024, "%s: %d bytes do not fit the LDS", tag, L.total);
+                        }
                         }
                     }
     // residency classes of the benchmark's borders (the numbers DESIGN.md quotes)
     auto total = [](int b, int paired) {
-        const int w = 34 + 2 * b, rows = paired == 2 ? 16 : paired == 1 ? 8 : 4, tp = rp_tab_pitch(paired);
+        const int w = 35 + 2 * b, rows = paired == 2 ? 16 : paired == 1 ? 8 : 4, tp = rp_tab_pitch(paired);
         const int cp = rp_class_pitch(rp_lds_layout(w, w, 34, true, rows, 0, tp).wpitch);
         return rp_lds_layout(w, w, 34, true, rows, cp, tp).total;
     };
-    CHECK(total(20, 0) <= 42 * 1280 && total(23, 0) <= 42 * 1280 && total(24, 0) > 42 * 1280, "15 angles: borders 20..23 three per CU");
+    CHECK(total(20, 0) <= 42 * 1280 && total(27, 0) <= 42 * 1280 && total(28, 0) > 42 * 1280, "15 angles: borders 20..27 three per CU");
+    CHECK(total(28, 0) <= 64 * 1280 && total(38, 0) <= 64 * 1280 && total(39, 0) > 64 * 1280, "15 angles: borders 28..38 two per CU");
     CHECK(total(20, 1) <= 32 * 1280 && total(21, 1) <= 32 * 1280 && total(22, 1) > 32 * 1280, "7 angles: borders 20, 21 four per CU");
-    CHECK(total(20, 2) <= 32 * 1280 && total(22, 2) <= 32 * 1280, "3 angles: borders 20..22 four per CU");
+    CHECK(total(20, 2) <= 32 * 1280 && total(21, 2) <= 32 * 1280, "3 angles: borders 20, 21 four per CU");
     printf("%d violations\n", bad);
     return bad > 100 ? 100 : bad;
 }

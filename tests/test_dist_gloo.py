@@ -1,5 +1,6 @@
-"""CPU test of the multi-GPU path's host logic with 2 gloo processes: sharding by border and
-the gather that undoes it (on the GPU box the same code runs over RCCL with device tensors)."""
+"""CPU tests of the multi-GPU path's host logic with 2 and 8 gloo processes: shards of equal estimated time (unequal
+lengths) and the one-collective exchange step that undoes them (on the GPU box the same code runs over RCCL with device
+tensors and un-permutes with one kernel)."""
 import os
 import socket
 
@@ -8,8 +9,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from sea_ice_drift_amd.dist import (PackedGatherer, ResultGatherer, point_cost, shard_indices, shard_indices_by_cost,
-                                    shard_size)
+from sea_ice_drift_amd.dist import PackedGatherer, per_rank_breakdown, point_cost, shard_indices_by_cost
 
 
 def _free_port():
@@ -28,55 +28,28 @@ def _worker(rank, world, port, n_total, q):
     border = np.clip(np.floor(rng.rayleigh(16.0, n_total)), 20, 50)
     truth = rng.standard_normal((n_total, 5))
     truth_ij = rng.integers(0, 100, (n_total, 3)).astype(np.int32)
-    idx = shard_indices(border, world, rank)
-    m = shard_size(n_total, world)
-    out_local = torch.full((m, 5), float('nan'), dtype=torch.float64)
-    ij_local = torch.full((m, 3), -1, dtype=torch.int32)
-    out_local[:len(idx)] = torch.from_numpy(truth[idx])          # stands in for the kernel's output
-    ij_local[:len(idx)] = torch.from_numpy(truth_ij[idx])
-    g = ResultGatherer(n_total, idx, torch.device('cpu'))
-    for _ in range(2):                                           # reusable across steps
-        out, ij = g.gather(out_local, ij_local)
-    # the one-collective form bench.py uses: the "kernel" writes into the packed block in place
+    # shards of equal estimated time (what bench.py uses): unequal lengths, block rows = the largest shard (made even)
+    idx = shard_indices_by_cost(border, world, rank)
+    lens = [len(shard_indices_by_cost(border, world, r)) for r in range(world)]
     pg = PackedGatherer(n_total, idx, torch.device('cpu'))
+    assert pg.m == max(lens) + (max(lens) & 1) and pg.n_local == lens[rank]
     o_v, j_v = pg.local_views()
-    o_v.copy_(torch.from_numpy(truth[idx]))
-    j_v.copy_(torch.from_numpy(truth_ij[idx]))
-    for _ in range(2):
+    for step in range(2):                                        # reusable across steps; the second step after a poisoning
+        o_v.copy_(torch.from_numpy(truth[idx] + step))           # stands in for the kernels' output, written in place
+        j_v.copy_(torch.from_numpy(truth_ij[idx] + step))
         pg.gather_to_host()
-    if rank == 0:
-        p_out, p_ij = pg.host_results()
-        assert np.array_equal(p_out, truth) and np.array_equal(p_ij, truth_ij)
-    # shards of equal estimated cost (what bench.py uses): unequal lengths, block rows = the largest shard
-    idx_c = shard_indices_by_cost(border, world, rank)
-    pc = PackedGatherer(n_total, idx_c, torch.device('cpu'))
-    o_v, j_v = pc.local_views()
-    o_v.copy_(torch.from_numpy(truth[idx_c]))
-    j_v.copy_(torch.from_numpy(truth_ij[idx_c]))
-    pc.gather_to_host()
-    if rank == 0:
-        c_out, c_ij = pc.host_results()
-        assert np.array_equal(c_out, truth) and np.array_equal(c_ij, truth_ij)
-    if rank == 0:
-        q.put((np.array_equal(out.numpy(), truth), np.array_equal(ij.numpy(), truth_ij),
-               float(border[idx].sum()), len(idx)))
-    else:
-        assert out is None and ij is None
-        q.put((None, None, float(border[idx].sum()), len(idx)))
+        if rank == 0:
+            p_out, p_ij = pg.host_results()
+            assert np.array_equal(p_out, truth + step) and np.array_equal(p_ij, truth_ij + step)
+        pg.poison()
+        if rank == 0:
+            assert np.isnan(pg.host_results()[0]).all() and (pg.host_results()[1] == -1).all()
+    # every rank's step numbers on every rank (bench.py's per-rank breakdown)
+    table = per_rank_breakdown([10.0 + rank, float(len(idx))], torch.device('cpu'))
+    assert table.shape == (world, 2) and list(table[:, 0]) == [10.0 + r for r in range(world)] and list(table[:, 1]) == lens
+    q.put((rank, len(idx), float(point_cost(border[idx]).sum())))
     dist.barrier()
     dist.destroy_process_group()
-
-
-def test_shards_partition_and_balance():
-    rng = np.random.default_rng(1)
-    border = np.clip(np.floor(rng.rayleigh(16.0, 1001)), 20, 50)
-    for world in (1, 2, 4, 8):
-        parts = [shard_indices(border, world, r) for r in range(world)]
-        allidx = np.sort(np.concatenate(parts))
-        np.testing.assert_array_equal(allidx, np.arange(1001))               # a partition
-        assert max(len(p) for p in parts) <= shard_size(1001, world)
-        work = [((2 * border[p] + 2) ** 2).sum() for p in parts]
-        assert max(work) / min(work) < 1.02                                   # balanced by window size
 
 
 def test_cost_shards_partition_and_balance():
@@ -106,18 +79,29 @@ def test_cost_shards_partition_and_balance():
                                   np.arange(5))
 
 
-def test_two_rank_gather_roundtrip():
-    world, n_total = 2, 1001
+def _roundtrip(world, n_total):
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
     port = _free_port()
     procs = [ctx.Process(target=_worker, args=(r, world, port, n_total, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=120) for _ in range(world)]
+    res = [q.get(timeout=300) for _ in range(world)]
     for p in procs:
-        p.join(timeout=60)
+        p.join(timeout=120)
         assert p.exitcode == 0
-    root = [r for r in res if r[0] is not None]
-    assert len(root) == 1 and root[0][0] and root[0][1]
-    assert sum(r[3] for r in res) == n_total
+    assert sorted(r[0] for r in res) == list(range(world))
+    assert sum(r[1] for r in res) == n_total
+    return res
+
+
+def test_two_rank_gather_roundtrip():
+    _roundtrip(2, 1001)
+
+
+def test_eight_rank_gather_roundtrip_with_unequal_shards():
+    """BASELINE config 3's rank count on CPU: eight gloo ranks, shards of equal estimated time - the rank with the largest
+    borders holds far fewer points than the one with the smallest -, one gather of blocks of the largest shard's rows."""
+    res = _roundtrip(8, 6007)
+    lens = [r[1] for r in sorted(res)]
+    assert max(lens) > 1.5 * min(lens)                            # unequal on purpose

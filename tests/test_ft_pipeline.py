@@ -94,6 +94,60 @@ def test_drift_vectors_projected_nsr_and_displacement_pix():
         lib.get_drift_vectors(NoDst(), x1, y1, NoDst(), x2, y2, nsr=lib.NSR('+proj=stere'))
 
 
+def test_projected_nsr_is_recognised_without_the_placeholders_srs_attribute(monkeypatch):
+    """nansat's NSR is an osr.SpatialReference - it has ``wkt`` / ``IsGeographic`` and no ``srs``.  Such
+    an object must select projected units too, and with nansat installed EVERY nsr goes through the reference's own
+    ``Domain(nsr, '-te -10 -10 10 10 -tr 1 1')`` call (lib.py:394-399)."""
+    import sys
+    import types
+    from sea_ice_drift_amd.domain import ArrayNansat
+
+    class OsrLike(object):                       # no .srs
+        def __init__(self, wkt, geographic):
+            self.wkt, self._geo = wkt, geographic
+
+        def IsGeographic(self):
+            return int(self._geo)
+
+    class WktOnly(object):
+        def __init__(self, wkt):
+            self.wkt = wkt
+    assert lib._is_projected(OsrLike('PROJCS["stere"]', False))
+    assert not lib._is_projected(OsrLike('GEOGCS["WGS 84"]', True))
+    assert lib._is_projected(WktOnly('PROJCS["stere"]')) and not lib._is_projected(WktOnly('GEOGCS["WGS 84"]'))
+    assert not lib._is_projected(WktOnly('+proj=longlat +datum=WGS84')) and not lib._is_projected(None)
+    assert lib._is_projected(lib.NSR('+proj=stere')) and not lib._is_projected(lib.NSR())
+    img = np.ones((64, 64), dtype=np.uint8)
+    n1 = ArrayNansat(img, origin=(3.0, 4.0), matrix=((0.5, 0.0), (0.0, -0.25)), dst_scale=1000.0)
+    n2 = ArrayNansat(img, origin=(3.5, 4.5), matrix=((0.5, 0.0), (0.0, -0.25)), dst_scale=1000.0)
+    x1, y1 = np.array([10.0, 20.0]), np.array([8.0, 12.0])
+    u, v = lib.get_drift_vectors(n1, x1, y1, n2, x1 + 3.0, y1 - 2.0, nsr=OsrLike('PROJCS["stere"]', False))[:2]
+    np.testing.assert_allclose(u, [2000.0, 2000.0], rtol=0, atol=1e-9)
+    np.testing.assert_allclose(v, [1000.0, 1000.0], rtol=0, atol=1e-9)
+    u, v = lib.get_drift_vectors(n1, x1, y1, n2, x1 + 3.0, y1 - 2.0, nsr=OsrLike('GEOGCS["WGS 84"]', True))[:2]
+    np.testing.assert_allclose(u, [2.0, 2.0], rtol=0, atol=1e-12)
+    np.testing.assert_allclose(v, [1.0, 1.0], rtol=0, atol=1e-12)
+
+    # nansat "installed": a Domain that records the call and maps lon/lat to the pixels of a 100 m grid
+    calls = []
+
+    class FakeDomain(object):
+        def __init__(self, nsr, ext):
+            calls.append((nsr, ext))
+
+        def transform_points(self, lon, lat, DstToSrc=0):
+            assert DstToSrc == 1
+            return np.asarray(lon) * 100.0 + 10.0, 10.0 - np.asarray(lat) * 100.0
+    fake = types.ModuleType('nansat')
+    fake.Domain = FakeDomain
+    monkeypatch.setitem(sys.modules, 'nansat', fake)
+    nsr = OsrLike('PROJCS["stere"]', False)
+    u, v = lib.get_drift_vectors(n1, x1, y1, n2, x1 + 3.0, y1 - 2.0, nsr=nsr)[:2]
+    assert calls == [(nsr, '-te -10 -10 10 10 -tr 1 1')]
+    np.testing.assert_allclose(u, [200.0, 200.0], rtol=0, atol=1e-9)      # 2 degrees east on the 100-per-degree grid
+    np.testing.assert_allclose(v, [100.0, 100.0], rtol=0, atol=1e-9)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize('timed', [False, True])
 def test_feature_tracking_on_gpu_equals_reference(timed):

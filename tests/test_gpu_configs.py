@@ -88,6 +88,23 @@ def test_config3_dry_run_bench_spawns_its_own_ranks():
     # the N > 1 line says where rank 0's step goes (kernels / gather / un-permutation / copy to the host)
     bd = two['step_breakdown_ms']
     assert bd['backend'] == 'gloo' and bd['kernel_ms'] > 0 and bd['gather_ms'] >= 0 and bd['d2h_ms'] >= 0
+    # ... and every rank's share, with the slowest rank named
+    pr = bd['per_rank']
+    assert len(pr['kernel_ms']) == 2 and min(pr['kernel_ms']) > 0 and pr['points'] == two['config']['points_per_gpu_all']
+    assert bd['slowest_rank'] in (0, 1) and bd['slowest_kernel_ms'] == max(pr['kernel_ms'])
+
+
+def test_config5_dry_run_two_ranks_stream_their_shares():
+    """BASELINE config 5's multi-GPU half as a dry run: `python bench.py --mode stream --gpus 2` - two ranks sharing the
+    one GPU (gloo for the flag reduction), each streaming its share of the batch through its own two device slots; no
+    collective on the data path.  Every rank's pairs are checked against the oracle and every rank's clock is reported."""
+    d = run_bench('--mode', 'stream', '--gpus', '2', '--pairs', '6', '--steps', '1', '--warmup', '1', '--size', '3000', '--grid', '60',
+                  '--check', '32', timeout=1800)
+    assert d['n_gpus'] == 2 and d['config']['pairs_total'] == 6 and d['config']['pairs_per_gpu'] == 3
+    assert d['parity_check']['ok'] and d['parity_check']['pairs_checked_per_rank'] == 3
+    pr = d['step_breakdown_ms']['per_rank']
+    assert pr['pairs'] == [3, 3] and min(pr['batch_ms']) > 0 and d['step_breakdown_ms']['slowest_rank'] in (0, 1)
+    assert d['value'] > 0 and d['config']['points_per_pair'] == 3600
 
 
 def test_rccl_code_path_runs_on_one_gpu():
@@ -99,7 +116,9 @@ def test_rccl_code_path_runs_on_one_gpu():
                   '--no-cpu-baseline')
     bd = d['step_breakdown_ms']
     assert bd['backend'] == 'nccl'
-    assert bd['kernel_ms'] > 0 and bd['gather_ms'] > 0 and bd['unpermute_ms'] > 0 and bd['d2h_ms'] > 0
+    # one kernel (sid_pm_unpermute) reads the gathered block and writes the pinned host buffer: no separate copy
+    assert bd['kernel_ms'] > 0 and bd['gather_ms'] > 0 and bd['unpermute_ms'] > 0 and bd['d2h_ms'] >= 0
+    assert 'sid_pm_unpermute' in bd['results'] and bd['per_rank']['points'] == [3600] and bd['slowest_rank'] == 0
     assert d['parity_check']['ok'] and d['config']['points_total'] == 3600
 
 

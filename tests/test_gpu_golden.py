@@ -181,10 +181,11 @@ def test_fullsize_properties(pm_ctx, full_pair):
     same = (out3[:, 3] == out[sel, 3])
     assert same.mean() > 0.97                      # a few points find a better peak in the wider window
     np.testing.assert_array_equal(out3[same, :3], out[sel][same, :3])
-    # (5) sharded == unsharded (the multi-GPU partition, run on one device)
-    from sea_ice_drift_amd.dist import shard_indices
-    for rank in (0, 3):
-        idx = shard_indices(b, 4, rank)[::10]
+    # (5) sharded == unsharded (the multi-GPU partition bench.py ships - contiguous runs of equal estimated time in border
+    #     order - run on one device: the first, a middle and the last of eight ranks)
+    from sea_ice_drift_amd.dist import shard_indices_by_cost
+    for rank in (0, 3, 7):
+        idx = shard_indices_by_cost(b, 8, rank, 34, len(angles))[::5]
         pm_ctx.set_points(*[x[idx] for x in v], 34, 0.0, angles, rot=rot)
         pm_ctx.run()
         o, j = pm_ctx.fetch()

@@ -13,9 +13,16 @@ size, grid, s = 10000, 200, 34
 img1, img2 = syn.make_pair(size, size)
 g = syn.make_grid(size, size, grid)
 angles = list(range(-7, 8)); rot = rotation_table(angles, 0.0, s)
-schemes = {'snake deal by border (dist.shard_indices)': lambda r: dist.shard_indices(g['border'], world, r)}
-if hasattr(dist, 'shard_indices_by_cost'):
-    schemes['contiguous chunks of equal estimated cost (dist.shard_indices_by_cost)'] = lambda r: dist.shard_indices_by_cost(g['border'], world, r)
+def snake_deal(border, world_size, rank):
+    """The round-1/2 partition (kept here for the comparison only): points ordered by border, dealt 0..G-1, G-1..0, ..."""
+    order = np.argsort(-np.asarray(border), kind='stable')
+    pos = np.arange(order.size)
+    k, rnd = pos % world_size, pos // world_size
+    return np.sort(order[np.where(rnd % 2 == 0, k, world_size - 1 - k) == rank])
+
+
+schemes = {'snake deal by border (rounds 1-2)': lambda r: snake_deal(g['border'], world, r),
+           'contiguous runs of equal estimated time (dist.shard_indices_by_cost)': lambda r: dist.shard_indices_by_cost(g['border'], world, r)}
 out = {}
 with _capi.PMContext(0) as ctx:
     ctx.upload_pair(img1, img2)
