@@ -24,6 +24,10 @@
  * membership is clear (no smallest coordinate within 4e-15 of SciPy's threshold -2.2e-14), all containing simplices round to the same
  * integers and no value lies within 1e-6 of a half-integer; every other query lies strictly inside exactly one simplex
  * (flagged only when its value is that close to a half-integer).
+ * Limitation: degenerate (flat) simplices are skipped here, whereas SciPy gives them a NaN transform and then accepts
+ * queries in their neighbours with a wider tolerance (sqrt(eps)) towards them - a case the flags do not model.  The
+ * caller must not use this entry point for a triangulation that holds such a simplex: sea_ice_drift_amd/lib.py checks
+ * (condition number of every simplex) and evaluates with SciPy alone then.
  * Host buffers in / host buffers out; 0 on success, a negative SID_PM_ERR_* code otherwise (sid_pm.h).
  */
 #ifndef SID_FG_H
@@ -44,6 +48,10 @@ int sid_fg_interp_linear(int device, const double *pts, int64_t n_pts, const int
 int sid_fg_nearest_dist(int device, const double *seeds, int64_t n_seeds, const double *q, int64_t n_q, double *dist);
 
 const char *sid_fg_last_error(void);
+/* Free the grow-only device scratch block of the two entry points on `device` (every device: -1).  The blocks are kept between calls so that no call pays for
+ * hipMalloc / hipFree; a long-lived process that is done with the GPU hands the memory back with this (the Python mirror's
+ * pmlib.release_contexts() calls it).  Not to be called while a call on that device is in flight. */
+int sid_fg_release(int device);
 
 #ifdef __cplusplus
 }

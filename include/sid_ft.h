@@ -42,6 +42,10 @@ int sid_ft_knn2_device(const uint8_t *d_desc1, int64_t n1, const uint8_t *d_desc
 int64_t sid_ft_workspace_bytes(int64_t n1, int64_t n2);
 
 const char *sid_ft_last_error(void);
+/* Free the grow-only device scratch block of sid_ft_knn2 on `device` (every device: -1).  The blocks are kept between calls so that no call pays for
+ * hipMalloc / hipFree; a long-lived process that is done with the GPU hands the memory back with this (the Python mirror's
+ * pmlib.release_contexts() calls it).  Not to be called while a call on that device is in flight. */
+int sid_ft_release(int device);
 
 #ifdef __cplusplus
 }

@@ -57,6 +57,10 @@ int sid_orb_detect(int device, const uint8_t *img, int64_t rows, int64_t cols, i
                    float *xy, int32_t *meta, int64_t *response, uint8_t *desc, int64_t max_out, int64_t *n_out);
 
 const char *sid_orb_last_error(void);
+/* Free the idle detector workspaces (device buffers of ~7 bytes per pixel, a stream and pinned staging each; at most two idle ones are kept per device) on `device` (every device: -1).  The blocks are kept between calls so that no call pays for
+ * hipMalloc / hipFree; a long-lived process that is done with the GPU hands the memory back with this (the Python mirror's
+ * pmlib.release_contexts() calls it).  Not to be called while a call on that device is in flight. */
+int sid_orb_release(int device);
 
 #ifdef __cplusplus
 }

@@ -166,8 +166,10 @@ int sid_pm_work_info(sid_pm_ctx *ctx, double info[6]);
  * footprint - for cutting points into shards of equal cost over several GPUs.  Pure host arithmetic (no device needed).
  * Replaces the role of `threads`-sized chunks of the reference's Pool.map (pmlib.py:442-444).                          */
 int sid_pm_estimate_cost(const double *border, int64_t n, int img_size, int n_angles, double *cost_ns);
-/* Workgroups per CU (1 .. 4) of the launch class a point of that border joins: a launch has 256 x that many points in flight,
- * which prices the tail of a short launch when the points are cut into shards.  Host arithmetic as well.               */
+/* Launch class of a point of that border: low four bits = workgroups per CU (1 .. 4) of its launch - a launch has 256 x that
+ * many points in flight, which prices the tail of a short launch when the points are cut into shards -, + 16 when the point
+ * runs in the launches that keep the per-placement sum of squares in global memory (round 4).  Points of equal value share a
+ * launch.  Host arithmetic as well.                                                                                     */
 int sid_pm_estimate_residency(const double *border, int64_t n, int img_size, int n_angles, int32_t *per_cu);
 
 /* ---- diagnostics used by the parity tests ---- */

@@ -27,17 +27,17 @@ SYMBOLS = (
 )
 
 # every symbol include/sid_ft.h declares (feature-tracking matcher, same library)
-FT_SYMBOLS = ('sid_ft_knn2', 'sid_ft_knn2_device', 'sid_ft_workspace_bytes', 'sid_ft_last_error')
+FT_SYMBOLS = ('sid_ft_knn2', 'sid_ft_knn2_device', 'sid_ft_workspace_bytes', 'sid_ft_last_error', 'sid_ft_release')
 
 # every symbol include/sid_stage.h declares (uint8 staging, same library)
 STAGE_SYMBOLS = ('sid_stage_create', 'sid_stage_destroy', 'sid_stage_begin', 'sid_stage_order_stats_ws',
                  'sid_stage_count_valid', 'sid_stage_order_stats', 'sid_stage_scale_u8', 'sid_stage_last_error')
 
 # every symbol include/sid_orb.h declares (key-point detector, same library)
-ORB_SYMBOLS = ('sid_orb_detect', 'sid_orb_last_error')
+ORB_SYMBOLS = ('sid_orb_detect', 'sid_orb_last_error', 'sid_orb_release')
 
 # every symbol include/sid_fg.h declares (first-guess evaluation, same library)
-FG_SYMBOLS = ('sid_fg_interp_linear', 'sid_fg_nearest_dist', 'sid_fg_last_error')
+FG_SYMBOLS = ('sid_fg_interp_linear', 'sid_fg_nearest_dist', 'sid_fg_last_error', 'sid_fg_release')
 
 _u8p = C.POINTER(C.c_uint8)
 _f64p = C.POINTER(C.c_double)
@@ -168,6 +168,15 @@ def _p(a, t):
     return a.ctypes.data_as(t)
 
 
+def release_workspaces(device=-1):
+    """Hand the cached device memory of the detector, the matcher and the first-guess evaluation back (``sid_orb_release``,
+    ``sid_ft_release``, ``sid_fg_release``; -1: every device).  No call on that device may be in flight."""
+    L = lib()
+    for name in ('sid_orb_release', 'sid_ft_release', 'sid_fg_release'):
+        if hasattr(L, name):
+            getattr(L, name)(int(device))
+
+
 def unpermute(stack_ptr, world, m, perm_ptr, n, out_ptr, ij_ptr, stream):
     """``sid_pm_unpermute`` on raw device(-visible) pointers (torch ``data_ptr()``) and a HIP stream handle."""
     _check(lib().sid_pm_unpermute(stack_ptr, int(world), int(m), perm_ptr, int(n), out_ptr, ij_ptr, stream))
@@ -182,7 +191,8 @@ def estimate_cost(border, img_size=34, n_angles=15):
 
 
 def estimate_residency(border, img_size=34, n_angles=15):
-    """Workgroups per CU (1 .. 4) of the launch class of each grid point (include/sid_pm.h sid_pm_estimate_residency)."""
+    """Launch class of each grid point (include/sid_pm.h sid_pm_estimate_residency): workgroups per CU (1 .. 4) in the low four
+    bits, + 16 for the launches that keep sum w'^2 in global memory; points of equal value share a launch."""
     b = _f64(border).ravel()
     out = np.empty(b.size, dtype=np.int32)
     _check(lib().sid_pm_estimate_residency(_p(b, _f64p), b.size, int(img_size), int(n_angles), _p(out, _i32p)))

@@ -1,7 +1,9 @@
 // first_guess.hip - evaluation of the first guess on gfx950 (C ABI: include/sid_fg.h; the reference's
 // lib.interpolation_near, lib.py:179-201, and pmlib.get_distance_to_nearest_keypoint, pmlib.py:61-77).
-// Both kernels are brute force over (query, simplex | seed) pairs - 1.6e9 pairs for 40 000 grid points against
-// 40 000 triangles, a few milliseconds of float64 VALU work - with the triangles / seeds staged through LDS.
+// Point location walks a uniform grid of buckets (round 4): every simplex is listed in the cells its bounding box touches, a
+// query tests the simplices of its own cell only - a dozen instead of all 6 x 10^4 (rounds 2-3: brute force over (query,
+// simplex) pairs, 1.7 ms per call; kept as the fallback for triangulations whose bucket lists would not fit).  The
+// nearest-key-point distance is brute force over (query, seed) pairs with the seeds staged through LDS.
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <float.h>
@@ -121,6 +123,90 @@ __global__ void k_eval(const Simp *simp, const int32_t *loc, const int32_t *near
     if (dbt) list[atomicAdd(nlist, 1)] = (int32_t)i;
 }
 
+// ---- uniform grid of buckets over the bounding box of the key points ----
+// A simplex is listed in every cell its bounding box - widened by far more than the location tolerance kTol can reach -
+// touches; cell indices come from ONE monotone function of the coordinate (cell_of), for simplices and queries alike, so a
+// query that lies within kTol of a simplex finds it in the list of its own cell.  Queries outside the box are clamped to the
+// border cells (they can only be outside the hull, or within kTol of it).
+constexpr int kGrid = 128;
+struct GridGeo { double x0, y0, ix, iy; };
+__device__ __forceinline__ int cell_of(double v, double v0, double inv)
+{
+    const double c = floor((v - v0) * inv);
+    return c < 0.0 ? 0 : (c > (double)(kGrid - 1) ? kGrid - 1 : (int)c);
+}
+__device__ __forceinline__ void simplex_cells(const double *pts, const int32_t *simp, int64_t k, const GridGeo g, int &cx0, int &cx1, int &cy0, int &cy1)
+{
+    const int a = simp[3 * k], b = simp[3 * k + 1], c = simp[3 * k + 2];
+    const double xa = pts[2 * a], ya = pts[2 * a + 1], xb = pts[2 * b], yb = pts[2 * b + 1], xc = pts[2 * c], yc = pts[2 * c + 1];
+    const double x_lo = fmin(xa, fmin(xb, xc)), x_hi = fmax(xa, fmax(xb, xc)), y_lo = fmin(ya, fmin(yb, yc)), y_hi = fmax(ya, fmax(yb, yc));
+    // kTol = 1e-9 of a barycentric coordinate moves a point by at most 1e-9 of the simplex's extent; 1e-6 of it (+ an
+    // absolute part for the rounding of large coordinates) is far on the safe side
+    const double m = 1e-6 * ((x_hi - x_lo) + (y_hi - y_lo)) + 1e-9 * (fabs(x_hi) + fabs(x_lo) + fabs(y_hi) + fabs(y_lo)) + 1e-12;
+    cx0 = cell_of(x_lo - m, g.x0, g.ix); cx1 = cell_of(x_hi + m, g.x0, g.ix);
+    cy0 = cell_of(y_lo - m, g.y0, g.iy); cy1 = cell_of(y_hi + m, g.y0, g.iy);
+}
+// pass 0: entries per cell; pass 1: the entries themselves (start[] = exclusive prefix sums of the counts, cursor[] zeroed)
+template <int PASS>
+__global__ void k_grid_build(const double *pts, const int32_t *simp, const Simp *tr, int64_t ns, GridGeo g, int32_t *count, const int32_t *start,
+                             int32_t *ids, int64_t cap)
+{
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= ns || !tr[k].ok) return;                                  // (degenerate simplices never match)
+    int cx0, cx1, cy0, cy1;
+    simplex_cells(pts, simp, k, g, cx0, cx1, cy0, cy1);
+    for (int cy = cy0; cy <= cy1; ++cy)
+        for (int cx = cx0; cx <= cx1; ++cx) {
+            const int cell = cy * kGrid + cx;
+            const int32_t pos = atomicAdd(&count[cell], 1);
+            if (PASS == 1) { const int64_t at = (int64_t)start[cell] + pos; if (at < cap) ids[at] = (int32_t)k; }
+        }
+}
+// exclusive prefix sums of the kGrid^2 counts (one workgroup; start[kGrid^2] = total), counts zeroed for the second pass
+__global__ __launch_bounds__(1024) void k_grid_scan(int32_t *count, int32_t *start)
+{
+    __shared__ int32_t part[1024];
+    constexpr int per = kGrid * kGrid / 1024;
+    const int t = threadIdx.x;
+    int32_t loc[per], sum = 0;
+    for (int j = 0; j < per; ++j) { loc[j] = sum; sum += count[t * per + j]; count[t * per + j] = 0; }
+    part[t] = sum;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {
+        const int32_t v = t >= d ? part[t - d] : 0;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    const int32_t base = part[t] - sum;
+    for (int j = 0; j < per; ++j) start[t * per + j] = base + loc[j];
+    if (t == 1023) start[kGrid * kGrid] = part[t];
+}
+// point location through the buckets: the lowest index of a containing simplex, as the brute-force pass finds it
+__global__ __launch_bounds__(256) void k_locate_grid(const Simp *simp, const int32_t *start, const int32_t *ids, GridGeo g,
+                                                      const double *q, int64_t nq, int32_t *loc, int32_t *near)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nq) return;
+    const double x = q[2 * i], y = q[2 * i + 1];
+    const double eps = 100.0 * DBL_EPSILON;
+    const int cell = cell_of(y, g.y0, g.iy) * kGrid + cell_of(x, g.x0, g.ix);
+    int32_t best = 0x7f7f7f7f;
+    bool close = false;
+    for (int32_t e = start[cell]; e < start[cell + 1]; ++e) {
+        const int32_t k = ids[e];
+        const Simp s = simp[k];
+        const double dx = x - s.rx, dy = y - s.ry;
+        const double c0 = s.t00 * dx + s.t01 * dy, c1 = s.t10 * dx + s.t11 * dy;
+        const double c2 = 1.0 - c0 - c1;
+        const double mc = fmin(c0, fmin(c1, c2));
+        if (mc >= -eps) best = k < best ? k : best;
+        close = close || mc >= -kTol;
+    }
+    loc[i] = best;
+    near[i] = (best == 0x7f7f7f7f && close) ? 1 : 0;
+}
+
 // Second look at the flagged queries (k_eval: on an edge, a vertex or the hull), against EVERY simplex, no early exit.  A
 // flagged query is RESOLVED - the caller need not ask SciPy - when whatever simplex SciPy's walk ends in, the ROUNDED result
 // is the same: (a) hull membership is clear - the best smallest barycentric coordinate over all simplices is not within
@@ -128,8 +214,10 @@ __global__ void k_eval(const Simp *simp, const int32_t *loc, const int32_t *near
 // integers (a shared vertex or edge interpolates to the same value from either side, up to the last bits); (c) no such
 // value lies within 1e-6 of a half-integer.  Resolved queries get the values of the lowest-index containing simplex (or
 // NaN); the others keep their flag.
+// start / ids (may be null): the bucket lists of k_grid_build - the flagged query then looks at the simplices of its cell only
 __global__ __launch_bounds__(256) void k_resolve(const Simp *simp, int64_t ns, const double *values, const double *q,
-                                                 const int32_t *list, const int32_t *nlist, double *out, int32_t *simplex, int32_t *doubt)
+                                                 const int32_t *list, const int32_t *nlist, double *out, int32_t *simplex, int32_t *doubt,
+                                                 const int32_t *start, const int32_t *ids, GridGeo g)
 {
     // one WAVEFRONT per flagged query: its 64 lanes share the simplices (lane l takes l, l + 64, ...: coalesced 64-byte
     // records) and merge what they found - one thread per query walking all 6 x 10^4 simplices took 19 of the 21 ms of the call
@@ -144,7 +232,10 @@ __global__ __launch_bounds__(256) void k_resolve(const Simp *simp, int64_t ns, c
         bool hull_unclear = false, disagree = false, near_half = false, any = false;
         double R0 = 0.0, R1 = 0.0, V0 = NAN, V1 = NAN;
         int32_t K = 0x7fffffff;                                         // this lane's lowest containing simplex
-        for (int64_t k = lane; k < ns; k += 64) {
+        int64_t e0 = 0, e1 = ns;
+        if (ids) { const int cell = cell_of(y, g.y0, g.iy) * kGrid + cell_of(x, g.x0, g.ix); e0 = start[cell]; e1 = start[cell + 1]; }
+        for (int64_t e = e0 + lane; e < e1; e += 64) {
+            const int64_t k = ids ? (int64_t)ids[e] : e;
             const Simp s = simp[k];
             if (!s.ok) continue;
             const double dx = x - s.rx, dy = y - s.ry;
@@ -160,7 +251,10 @@ __global__ __launch_bounds__(256) void k_resolve(const Simp *simp, int64_t ns, c
                 const double r0 = rint(o0), r1 = rint(o1);             // half to even, as np.round
                 near_half = near_half || fabs(o0 - floor(o0) - 0.5) < 1e-6 || fabs(o1 - floor(o1) - 0.5) < 1e-6 || !(fabs(o0) < 1e15) || !(fabs(o1) < 1e15);
                 if (!any) { any = true; R0 = r0; R1 = r1; V0 = o0; V1 = o1; K = (int32_t)k; }
-                else if (r0 != R0 || r1 != R1) disagree = true;
+                else {
+                    if (r0 != R0 || r1 != R1) disagree = true;
+                    if ((int32_t)k < K) { K = (int32_t)k; V0 = o0; V1 = o1; }   // (bucket lists are not in index order)
+                }
             }
         }
         // merge: the lowest containing simplex of all lanes gives the values; every lane's own first one (with which the
@@ -240,6 +334,19 @@ int pick_device(int device, int &prev)
 
 }  // namespace
 
+SID_EXPORT int sid_fg_release(int device)
+{
+    std::lock_guard<std::mutex> lock(g_pool_mu);
+    int prev = 0;
+    (void)hipGetDevice(&prev);
+    for (int d = 0; d < 16; ++d) {
+        if (device >= 0 && d != device) continue;
+        if (g_pool[d].p) { (void)hipSetDevice(d); (void)hipFree(g_pool[d].p); g_pool[d].p = nullptr; g_pool[d].cap = 0; }
+    }
+    (void)hipSetDevice(prev);
+    return SID_PM_OK;
+}
+
 SID_EXPORT const char *sid_fg_last_error(void) { return g_err; }
 
 SID_EXPORT int sid_fg_interp_linear(int device, const double *pts, int64_t n_pts, const int32_t *simplices, int64_t n_simp,
@@ -252,16 +359,33 @@ SID_EXPORT int sid_fg_interp_linear(int device, const double *pts, int64_t n_pts
     int rc = SID_PM_OK;
     std::lock_guard<std::mutex> lock(g_pool_mu);
     auto up = [](size_t b) { return (b + 255) / 256 * 256; };
+    // bucket lists of the uniform grid: room for 8 entries per simplex on average (a Delaunay triangle of scattered points
+    // touches 2-4 cells); a triangulation that needs more - long slivers across the whole box - takes the brute-force pass
+    const int64_t grid_cap = 8 * n_simp + kGrid * kGrid;
+    const bool want_grid = getenv("SID_FG_NO_GRID") == nullptr;
     const size_t need = up(sizeof(double) * 2 * n_pts) * 2 + up(sizeof(double) * 2 * n_q) * 2 + up(sizeof(int32_t) * 3 * n_simp) +
-                        up(sizeof(Simp) * n_simp) + up(sizeof(int32_t) * n_q) * 5 + 256;
+                        up(sizeof(Simp) * n_simp) + up(sizeof(int32_t) * n_q) * 5 + 256 +
+                        up(sizeof(int32_t) * (kGrid * kGrid + 1)) * 2 + up(sizeof(int32_t) * grid_cap);
     unsigned char *blk = nullptr;
     double *d_pts = nullptr, *d_val = nullptr, *d_q = nullptr, *d_out = nullptr; int32_t *d_simp = nullptr, *d_loc = nullptr, *d_near = nullptr, *d_sx = nullptr, *d_dbt = nullptr, *d_list = nullptr, *d_nlist = nullptr; Simp *d_t = nullptr;
+    int32_t *d_cnt = nullptr, *d_start = nullptr, *d_ids = nullptr;
+    bool use_grid = false;
+    GridGeo geo{0.0, 0.0, 0.0, 0.0};
     if ((rc = pool_reserve(device, need, &blk))) { (void)hipSetDevice(prev); return rc; }
     {
         Carver cv(blk);
         d_pts = cv.take<double>(2 * n_pts); d_val = cv.take<double>(2 * n_pts); d_q = cv.take<double>(2 * n_q); d_out = cv.take<double>(2 * n_q);
         d_simp = cv.take<int32_t>(3 * n_simp); d_t = cv.take<Simp>(n_simp); d_loc = cv.take<int32_t>(n_q);
         d_near = cv.take<int32_t>(n_q); d_sx = cv.take<int32_t>(n_q); d_dbt = cv.take<int32_t>(n_q); d_list = cv.take<int32_t>(n_q); d_nlist = cv.take<int32_t>(1);
+        d_cnt = cv.take<int32_t>(kGrid * kGrid + 1); d_start = cv.take<int32_t>(kGrid * kGrid + 1); d_ids = cv.take<int32_t>(grid_cap);
+    }
+    {   // grid geometry: the bounding box of the key points
+        double x_lo = pts[0], x_hi = pts[0], y_lo = pts[1], y_hi = pts[1];
+        for (int64_t k = 1; k < n_pts; ++k) {
+            x_lo = fmin(x_lo, pts[2 * k]); x_hi = fmax(x_hi, pts[2 * k]); y_lo = fmin(y_lo, pts[2 * k + 1]); y_hi = fmax(y_hi, pts[2 * k + 1]);
+        }
+        const double w = x_hi - x_lo, h = y_hi - y_lo;
+        if (want_grid && w > 0.0 && h > 0.0 && isfinite(w) && isfinite(h)) { geo = GridGeo{x_lo, y_lo, (double)kGrid / w, (double)kGrid / h}; use_grid = true; }
     }
     HIP_TRY(hipMemcpyAsync(d_pts, pts, sizeof(double) * 2 * n_pts, hipMemcpyHostToDevice, 0));
     HIP_TRY(hipMemcpyAsync(d_val, values, sizeof(double) * 2 * n_pts, hipMemcpyHostToDevice, 0));
@@ -269,20 +393,35 @@ SID_EXPORT int sid_fg_interp_linear(int device, const double *pts, int64_t n_pts
     HIP_TRY(hipMemcpyAsync(d_simp, simplices, sizeof(int32_t) * 3 * n_simp, hipMemcpyHostToDevice, 0));
     hipLaunchKernelGGL(k_transform, dim3((unsigned)((n_simp + 255) / 256)), dim3(256), 0, 0, d_pts, d_simp, n_simp, d_t);
     {
-        const unsigned qb = (unsigned)((n_q + 255) / 256);
-        unsigned ychunks = qb >= 2048 ? 1u : (2048u + qb - 1) / qb;                     // aim at >= 2048 blocks
-        const int64_t tiles = (n_simp + kTile - 1) / kTile;
-        if ((int64_t)ychunks > tiles) ychunks = (unsigned)tiles;
-        const int64_t chunk = ((tiles + ychunks - 1) / ychunks) * kTile;
-        ychunks = (unsigned)((n_simp + chunk - 1) / chunk);
-        HIP_TRY(hipMemsetAsync(d_loc, 0x7f, sizeof(int32_t) * n_q, 0));                 // 0x7f7f7f7f: above any index
-        HIP_TRY(hipMemsetAsync(d_near, 0, sizeof(int32_t) * n_q, 0));
-        hipLaunchKernelGGL(k_locate, dim3(qb, ychunks), dim3(256), 0, 0, d_t, n_simp, chunk, d_q, n_q, d_loc, d_near);
+        const unsigned qb = (unsigned)((n_q + 255) / 256), sb = (unsigned)((n_simp + 255) / 256);
+        if (use_grid) {
+            // bucket lists: count, prefix sums, fill; the total decides whether they fit (one 4-byte read-back)
+            int32_t total = 0;
+            HIP_TRY(hipMemsetAsync(d_cnt, 0, sizeof(int32_t) * (kGrid * kGrid + 1), 0));
+            hipLaunchKernelGGL(k_grid_build<0>, dim3(sb), dim3(256), 0, 0, d_pts, d_simp, d_t, n_simp, geo, d_cnt, d_start, d_ids, grid_cap);
+            hipLaunchKernelGGL(k_grid_scan, dim3(1), dim3(1024), 0, 0, d_cnt, d_start);
+            HIP_TRY(hipMemcpy(&total, d_start + kGrid * kGrid, sizeof total, hipMemcpyDeviceToHost));
+            if ((int64_t)total <= grid_cap) hipLaunchKernelGGL(k_grid_build<1>, dim3(sb), dim3(256), 0, 0, d_pts, d_simp, d_t, n_simp, geo, d_cnt, d_start, d_ids, grid_cap);
+            else use_grid = false;
+        }
+        if (use_grid) {
+            hipLaunchKernelGGL(k_locate_grid, dim3(qb), dim3(256), 0, 0, d_t, d_start, d_ids, geo, d_q, n_q, d_loc, d_near);
+        } else {
+            unsigned ychunks = qb >= 2048 ? 1u : (2048u + qb - 1) / qb;                 // aim at >= 2048 blocks
+            const int64_t tiles = (n_simp + kTile - 1) / kTile;
+            if ((int64_t)ychunks > tiles) ychunks = (unsigned)tiles;
+            const int64_t chunk = ((tiles + ychunks - 1) / ychunks) * kTile;
+            ychunks = (unsigned)((n_simp + chunk - 1) / chunk);
+            HIP_TRY(hipMemsetAsync(d_loc, 0x7f, sizeof(int32_t) * n_q, 0));             // 0x7f7f7f7f: above any index
+            HIP_TRY(hipMemsetAsync(d_near, 0, sizeof(int32_t) * n_q, 0));
+            hipLaunchKernelGGL(k_locate, dim3(qb, ychunks), dim3(256), 0, 0, d_t, n_simp, chunk, d_q, n_q, d_loc, d_near);
+        }
         HIP_TRY(hipMemsetAsync(d_nlist, 0, sizeof(int32_t), 0));
         hipLaunchKernelGGL(k_eval, dim3(qb), dim3(256), 0, 0, d_t, d_loc, d_near, d_val, d_q, n_q, d_out, d_sx, d_dbt, d_list, d_nlist);
         // (the number of flagged queries is only known on the device: enough wavefronts for a few thousand of them at once,
         // each taking every 4096th entry of the list)
-        hipLaunchKernelGGL(k_resolve, dim3(1024), dim3(256), 0, 0, d_t, n_simp, d_val, d_q, d_list, d_nlist, d_out, d_sx, d_dbt);
+        hipLaunchKernelGGL(k_resolve, dim3(1024), dim3(256), 0, 0, d_t, n_simp, d_val, d_q, d_list, d_nlist, d_out, d_sx, d_dbt,
+                           use_grid ? d_start : nullptr, use_grid ? d_ids : nullptr, geo);
     }
     HIP_TRY(hipGetLastError());
     if (simplex) HIP_TRY(hipMemcpyAsync(simplex, d_sx, sizeof(int32_t) * n_q, hipMemcpyDeviceToHost, 0));

@@ -308,6 +308,24 @@ SID_EXPORT int sid_ft_knn2_device(const uint8_t *d_desc1, int64_t n1, const uint
     return SID_PM_OK;
 }
 
+// device scratch of sid_ft_knn2: one grow-only block per device (sid_ft_release frees it)
+static std::mutex g_ft_mu[16];
+static unsigned char *g_ft_pool[16] = {nullptr};
+static size_t g_ft_cap[16] = {0};
+
+SID_EXPORT int sid_ft_release(int device)
+{
+    int prev = 0;
+    (void)hipGetDevice(&prev);
+    for (int d = 0; d < 16; ++d) {
+        if (device >= 0 && d != (device & 15)) continue;
+        std::lock_guard<std::mutex> lock(g_ft_mu[d]);
+        if (g_ft_pool[d]) { (void)hipSetDevice(d); (void)hipFree(g_ft_pool[d]); g_ft_pool[d] = nullptr; g_ft_cap[d] = 0; }
+    }
+    (void)hipSetDevice(prev);
+    return SID_PM_OK;
+}
+
 SID_EXPORT int sid_ft_knn2(int device, const uint8_t *desc1, int64_t n1, const uint8_t *desc2, int64_t n2,
                            int32_t *idx, int32_t *dist)
 {
@@ -322,9 +340,9 @@ SID_EXPORT int sid_ft_knn2(int device, const uint8_t *desc1, int64_t n1, const u
     (void)hipSetDevice(device);
     // device scratch: one grow-only block per device, kept between calls (five hipMalloc / hipFree cost about as much as
     // the matching of the reference notebook's 24 000 x 23 000 case); calls on one device are serialised by its mutex
-    static std::mutex mu[16];
-    static unsigned char *pool[16] = {nullptr};
-    static size_t pool_cap[16] = {0};
+    std::mutex *mu = g_ft_mu;
+    unsigned char **pool = g_ft_pool;
+    size_t *pool_cap = g_ft_cap;
     std::lock_guard<std::mutex> lock(mu[device & 15]);
     hipError_t e = hipSuccess;
     auto step = [&](hipError_t x) { if (e == hipSuccess) e = x; };

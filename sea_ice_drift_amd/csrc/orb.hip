@@ -283,7 +283,28 @@ OrbWs *ws_acquire(int device)
     g_ws.push_back(w);
     return w;
 }
-void ws_release(OrbWs *w) { if (w) { std::lock_guard<std::mutex> lock(g_ws_mu); w->busy = false; } }
+void ws_free(OrbWs *w)                                                 // (g_ws_mu held; the workspace is idle)
+{
+    int prev = 0; (void)hipGetDevice(&prev); (void)hipSetDevice(w->device);
+    if (w->stream) { (void)hipStreamSynchronize(w->stream); (void)hipStreamDestroy(w->stream); }
+    if (w->blk) (void)hipFree(w->blk);
+    if (w->h_small) (void)hipHostFree(w->h_small);
+    (void)hipSetDevice(prev);
+    delete w;
+}
+constexpr int kMaxIdleWs = 2;                                          // idle workspaces kept per device (the two images of a pair)
+void ws_release(OrbWs *w)
+{
+    if (!w) return;
+    std::lock_guard<std::mutex> lock(g_ws_mu);
+    w->busy = false;
+    int idle = 0;
+    for (OrbWs *o : g_ws) if (o->device == w->device && !o->busy) ++idle;
+    if (idle > kMaxIdleWs) {                                           // more threads than that detected at once: do not keep their ~7 B/pixel each
+        for (size_t k = 0; k < g_ws.size(); ++k) if (g_ws[k] == w) { g_ws.erase(g_ws.begin() + (long)k); break; }
+        ws_free(w);
+    }
+}
 hipError_t ws_reserve(OrbWs *w, size_t bytes)
 {
     if (w->cap >= bytes) return hipSuccess;
@@ -302,6 +323,17 @@ size_t up256(size_t b) { return (b + 255) / 256 * 256; }
 }  // namespace
 
 SID_EXPORT const char *sid_orb_last_error(void) { return g_err; }
+
+SID_EXPORT int sid_orb_release(int device)
+{
+    std::lock_guard<std::mutex> lock(g_ws_mu);
+    for (size_t k = 0; k < g_ws.size();) {
+        OrbWs *w = g_ws[k];
+        if (!w->busy && (device < 0 || w->device == device)) { g_ws.erase(g_ws.begin() + (long)k); ws_free(w); }
+        else ++k;
+    }
+    return SID_PM_OK;
+}
 
 SID_EXPORT int sid_orb_detect(int device, const uint8_t *img, int64_t rows, int64_t cols, int64_t stride,
                               const sid_orb_params *P, const int8_t *pattern, const int32_t *dirs,

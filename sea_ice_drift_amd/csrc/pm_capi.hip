@@ -102,6 +102,8 @@ struct sid_pm_ctx {
     DevBuf<double> out;
     DevBuf<int32_t> out_ij;
     DevBuf<int32_t> dbg_err;            // debugging builds only (SID_PM_DEBUG_CHECK=1)
+    DevBuf<uint32_t> gsii;              // row-pair kernel: sum w'^2 per placement of every resident point (PMArgs::gsii) ...
+    DevBuf<uint32_t> d_goff;            // ... and the offset of every launch position's block in it (units of 64 entries)
     int32_t *h_refused = nullptr;       // pinned, device-visible: valid points a launch could not hold (PMArgs::refused)
     double *user_out = nullptr;         // caller-owned result arrays (bind_results)
     int32_t *user_ij = nullptr;
@@ -181,6 +183,9 @@ int make_samp(const std::vector<double> &rot, int K, int s, std::vector<uint16_t
 // this differ in nothing.  The row-pair kernel's slot-group layouts (<= 7 angles) have a 128-VGPR build as well, for the
 // borders whose LDS footprint fits four times (SID_PM_NO_OCC4=1: off; A/B runs).
 constexpr int kMaxPerCu = 3;
+// four workgroups per CU need the 128-VGPR build of the row-pair kernel (pm_kernel_rp_occ4.hip): the slot-group layouts only.
+// (Round 4 measured it for the full operand table as well - with sum w'^2 in global memory borders 20-26 fit four per CU:
+// border 20 +1.6 %, border 26 +5 % against three per CU with the sums in LDS; not shipped.)  SID_PM_NO_OCC4=1: never (A/B runs)
 int max_per_cu(bool rp, int rpp) { return (rp && rpp > 0 && getenv("SID_PM_NO_OCC4") == nullptr) ? 4 : kMaxPerCu; }
 
 int blocks_per_cu(int lds)
@@ -241,9 +246,15 @@ int rp_paired(int K)
 // band argument of rp_lds_layout: output rows per sweep work item
 int rp_rows(int rpp, int band) { return rpp == 2 ? 16 : rpp == 1 ? 8 : band; }
 
-int lds_need(bool rp, int rpp, int wh, int ww, int s, int K, int band = 4, int pitch = 0)
+// own_hes of rp_lds_layout: the general Hessian (hes_smth / mcc_norm, several groups of angles) keeps the magnitudes in LDS of
+// their own (as the kernel decides: pm_kernel_rp prologue)
+bool rp_own_hes(int K, uint32_t flags) { return K > sid::kRpGroup || (flags & (SID_PM_HES_SMTH | SID_PM_MCC_NORM)) != 0u; }
+
+// gs: sum w'^2 per placement in global memory (rp_lds_layout; decided per window shape by rp_use_gs, and what the kernel
+// instantiation of the launch's window pitch does: sid::rp_pitch_is_gs)
+int lds_need(bool rp, int rpp, int wh, int ww, int s, int K, uint32_t flags, int band = 4, int pitch = 0, bool gs = true)
 {
-    if (rp) return sid::rp_lds_layout(wh, ww, s, K <= sid::kRpGroup, rp_rows(rpp, band), pitch, sid::rp_tab_pitch(rpp)).total;
+    if (rp) return sid::rp_lds_layout(wh, ww, s, K <= sid::kRpGroup, rp_rows(rpp, band), pitch, sid::rp_tab_pitch(rpp), rp_own_hes(K, flags), gs).total;
     return sid::mfma_lds_layout(wh, ww, s, band, use_paired(K) && band == 4).total;
 }
 
@@ -283,11 +294,44 @@ int fill_args(sid_pm_ctx *ctx, sid::PMArgs &A)
     A.out = ctx->user_out ? ctx->user_out : ctx->out.p;
     A.out_ij = ctx->user_out ? ctx->user_ij : ctx->out_ij.p;
     A.refused = ctx->h_refused;
+    A.gsii = ctx->gsii.p; A.gsii_off = ctx->d_goff.p;
     if (getenv("SID_PM_DEBUG_CHECK")) {
         if (!ctx->dbg_err.p && ctx->dbg_err.reserve(320) == SID_PM_OK) (void)hipMemset(ctx->dbg_err.p, 0, 320 * sizeof(int32_t));
         A.dbg_err = ctx->dbg_err.p;
     }
     return SID_PM_OK;
+}
+
+// Class of one window shape: band height of its sweep items, workgroups per CU, LDS bytes (natural window pitch) and - row-pair
+// kernel - whether sum w'^2 per placement lives in global memory (gs).  gs costs ~5 % where it changes nothing and buys
+// -10 .. -17 % where its smaller footprint lifts the shape into the next residency class, so it is chosen exactly there;
+// and wherever only a gs instantiation exists (window pitch above 112, the 8-row-band kernel, the run-time pitch).
+struct ShapeClass { bool gs; int band, cls, lds, nat_pitch; };
+ShapeClass shape_class(bool rp, int rpp, int wh, int ww, int s, int K, uint32_t flags, bool band8_ok, bool force_gs)
+{
+    auto eval = [&](bool gs) {
+        ShapeClass c{gs, 4, 0, lds_need(rp, rpp, wh, ww, s, K, flags, 4, 0, gs), 0};
+        // the two-per-CU class runs the 8-row-band kernel (two wavefronts per SIMD leave it 256 VGPRs); its
+        // window carries a few more zero rows, and a point that then no longer fits twice joins the one-per-CU
+        // class (a launch of their own for the few points in between costs more than it saves)
+        if (band8_ok && blocks_per_cu(c.lds) == 2) {
+            const int need8 = lds_need(rp, rpp, wh, ww, s, K, flags, 8, 0, gs);
+            if (blocks_per_cu(need8) >= 2) { c.lds = need8; c.band = 8; c.cls = 2; }
+            else c.cls = 1;
+        } else c.cls = std::max(1, std::min(max_per_cu(rp, rpp), blocks_per_cu(c.lds)));
+        if (rp) c.nat_pitch = sid::rp_lds_layout(wh, ww, s, K <= sid::kRpGroup, rp_rows(rpp, c.band), 0, sid::rp_tab_pitch(rpp), rp_own_hes(K, flags), gs).wpitch;
+        return c;
+    };
+    if (!rp) return eval(false);
+    ShapeClass g = eval(true);
+    g.cls = std::min(g.cls, 3);                                        // (no four-per-CU build with gs: see below)
+    if (force_gs || getenv("SID_PM_ALWAYS_GS") != nullptr) return g;
+    const ShapeClass l = eval(false);
+    if (l.band == 8 || l.nat_pitch > 112 || l.lds > sid::max_lds_bytes()) return g;   // (no instantiation without gs)
+    // a class the gs footprint reaches only pays where a kernel build exists for it: the four-per-CU build (128 VGPRs) is
+    // instantiated for the pitches without gs alone, so gs never buys the step from three to four
+    if (getenv("SID_PM_NO_GS") == nullptr && g.cls > l.cls) return g;
+    return l;
 }
 
 // Launch classes of the resident points for the pair that is current now: LDS footprint -> residency class
@@ -304,9 +348,10 @@ int classify_points(sid_pm_ctx *ctx)
     const bool rp = ctx->rp;
     const int rpp = ctx->rp_paired;
     const bool band8_ok = sid::mfma_band8_supported(s) && !no_band8 && (rp ? !ctx->rp_paired : !use_paired(K));   // (classic and row-pair kernels alike)
+    static const bool no_fixed_pitch = getenv("SID_PM_NO_FIXED_PITCH") != nullptr;         // (run-time pitch everywhere: gs instantiations; A/B runs)
     // Everything the launch needs to know about a point follows from the SHAPE of its search window, and a run has a few
     // dozen shapes (one per border): the LDS layouts are evaluated per shape, the points are only binned.
-    struct Shape { int wh, ww, lds, band, cls, nat_pitch, pitch; double work; std::vector<int32_t> idx; };
+    struct Shape { int wh, ww, lds, band, cls, nat_pitch, pitch; double work; std::vector<int32_t> idx; bool gs = false; };
     std::vector<Shape> shapes;
     std::vector<int32_t> slot_of((size_t)1 << 16, -1);                // (wh, ww) -> shape, direct-mapped on a hash of the pair
     auto find_shape = [&](int wh, int ww) -> int {
@@ -317,36 +362,28 @@ int classify_points(sid_pm_ctx *ctx)
             if (shapes[(size_t)k].wh == wh && shapes[(size_t)k].ww == ww) return k;
         }
     };
-    const int lds_min = lds_need(rp, rpp, s + 1, s + 1, s, K);
+    const uint32_t flags = ctx->flags;
+    const int lds_min = lds_need(rp, rpp, s + 1, s + 1, s, K, flags, 4, 0, false);
     {   // shape 0: points whose window does not lie inside image 2 (they write NaN at once; minimal footprint)
         Shape z{0, 0, lds_min, 4, std::min(kMaxPerCu, blocks_per_cu(lds_min)), 0, 0, 0.0, {}};   // (NaN writers: any class)
         shapes.push_back(z);
     }
     double macs = 0, bytes = 0, valid = 0;
     int lds_max = lds_min;
+    std::vector<uint32_t> npos_of((size_t)n, 0u);                     // placements of every point (0: NaN point)
     for (int64_t i = 0; i < n; ++i) {
         int wh = 0, ww = 0;
         if (!window_dims(c2fg[i], r2fg[i], border[i], s, rows2, cols2, wh, ww)) { shapes[0].idx.push_back((int32_t)i); continue; }
+        npos_of[(size_t)i] = (uint32_t)((wh - s + 1) * (ww - s + 1));
         int k = find_shape(wh, ww);
         if (k < 0) {
             Shape sh{wh, ww, 0, 4, 0, 0, 0, 0.0, {}};
-            const int need = lds_need(rp, rpp, wh, ww, s, K);
-            if (need > sid::max_lds_bytes())
+            const ShapeClass sc = shape_class(rp, rpp, wh, ww, s, K, flags, band8_ok, no_fixed_pitch);
+            if (sc.lds > sid::max_lds_bytes())
                 return fail(SID_PM_ERR_UNSUPPORTED, "point %lld: search window %dx%d needs %d bytes of LDS (> %d)",
-                            (long long)i, wh, ww, need, sid::max_lds_bytes());
-            sh.lds = need;
-            bool force1 = false, force2 = false;
-            // the two-per-CU class runs the 8-row-band kernel (two wavefronts per SIMD leave it 256 VGPRs); its
-            // window carries a few more zero rows, and a point that then no longer fits twice joins the one-per-CU
-            // class (a launch of their own for the few points in between costs more than it saves)
-            if (band8_ok && blocks_per_cu(need) == 2) {
-                const int need8 = lds_need(rp, rpp, wh, ww, s, K, 8);
-                if (blocks_per_cu(need8) >= 2) { sh.lds = need8; sh.band = 8; force2 = true; }
-                else force1 = true;
-            }
-            sh.cls = force1 ? 1 : (force2 ? 2 : std::min(max_per_cu(rp, rpp), blocks_per_cu(sh.lds)));
+                            (long long)i, wh, ww, sc.lds, sid::max_lds_bytes());
+            sh.lds = sc.lds; sh.band = sc.band; sh.cls = sc.cls; sh.gs = sc.gs; sh.nat_pitch = sc.nat_pitch;
             sh.work = (double)(wh - s + 1) * (double)(ww - s + 1);
-            if (rp) sh.nat_pitch = sid::rp_lds_layout(wh, ww, s, K <= sid::kRpGroup, rp_rows(rpp, sh.band), 0, sid::rp_tab_pitch(rpp)).wpitch;
             k = (int)shapes.size();
             shapes.push_back(sh);
         }
@@ -364,6 +401,7 @@ int classify_points(sid_pm_ctx *ctx)
         const Shape &x = shapes[(size_t)a], &y = shapes[(size_t)b];
         if (x.cls != y.cls) return x.cls < y.cls;
         if (x.band != y.band) return x.band < y.band;
+        if (x.gs != y.gs) return x.gs;                                // (gs first: the larger windows of a class)
         if (x.work != y.work) return x.work > y.work;
         return x.idx[0] < y.idx[0];
     });
@@ -371,26 +409,30 @@ int classify_points(sid_pm_ctx *ctx)
     // the sweep's and the winner's fragment loops is then an immediate).  The pitch of a launch = the smallest instantiated
     // pitch that holds the natural pitch of all of its points; if a footprint with that pitch no longer fits its residency
     // class, the whole launch keeps the run-time pitch (SID_PM_NO_FIXED_PITCH=1: always; A/B runs).
-    static const bool no_fixed_pitch = getenv("SID_PM_NO_FIXED_PITCH") != nullptr;
-    if (rp && !no_fixed_pitch) {
+    // gs groups take a pitch of 136 or more (or the run-time pitch): those instantiations keep sum w'^2 in global memory.
+    if (rp) {
         for (size_t a = 0; a < ord.size();) {
             size_t b = a + 1;
             const Shape &first = shapes[(size_t)ord[a]];
-            while (b < ord.size() && shapes[(size_t)ord[b]].cls == first.cls && shapes[(size_t)ord[b]].band == first.band) ++b;
-            int nat = 0;
+            while (b < ord.size() && shapes[(size_t)ord[b]].cls == first.cls && shapes[(size_t)ord[b]].band == first.band &&
+                   shapes[(size_t)ord[b]].gs == first.gs) ++b;
+            const bool gs = first.gs;
+            int nat = gs ? 136 : 0;
             for (size_t i = a; i < b; ++i) nat = std::max(nat, shapes[(size_t)ord[i]].nat_pitch);
-            int pitch = nat > 0 ? sid::rp_class_pitch(nat) : 0;
+            int pitch = (nat > 0 && !no_fixed_pitch) ? sid::rp_class_pitch(nat) : 0;
             if (pitch && !sid::rp_pitch_instantiated(first.band, rpp, pitch)) pitch = 0;
             for (size_t i = a; i < b && pitch; ++i) {
                 const Shape &sh = shapes[(size_t)ord[i]];
-                if (sh.wh > 0 && std::min(max_per_cu(rp, rpp), blocks_per_cu(lds_need(rp, rpp, sh.wh, sh.ww, s, K, sh.band, pitch))) < first.cls) pitch = 0;
+                if (sh.wh > 0 && std::min(max_per_cu(rp, rpp), blocks_per_cu(lds_need(rp, rpp, sh.wh, sh.ww, s, K, flags, sh.band, pitch, gs))) < first.cls) pitch = 0;
             }
-            if (pitch)
-                for (size_t i = a; i < b; ++i) {
-                    Shape &sh = shapes[(size_t)ord[i]];
-                    sh.pitch = pitch;
-                    if (sh.wh > 0) sh.lds = lds_need(rp, rpp, sh.wh, sh.ww, s, K, sh.band, pitch);
-                }
+            // (a group without gs that lost its compile-time pitch - it does not happen with the instantiated pitches - runs the
+            // run-time-pitch kernel, which is a gs one)
+            const bool gs_now = gs || pitch == 0;
+            for (size_t i = a; i < b; ++i) {
+                Shape &sh = shapes[(size_t)ord[i]];
+                sh.pitch = pitch; sh.gs = gs_now;
+                if (sh.wh > 0) sh.lds = lds_need(rp, rpp, sh.wh, sh.ww, s, K, flags, sh.band, pitch, gs_now);
+            }
             a = b;
         }
     }
@@ -409,7 +451,7 @@ int classify_points(sid_pm_ctx *ctx)
         size_t b = a + 1;
         const Shape &first = shapes[(size_t)ord[a]];
         while (b < ord.size() && shapes[(size_t)ord[b]].cls == first.cls && shapes[(size_t)ord[b]].band == first.band &&
-               shapes[(size_t)ord[b]].work == first.work) ++b;
+               shapes[(size_t)ord[b]].pitch == first.pitch && shapes[(size_t)ord[b]].work == first.work) ++b;
         const std::vector<int32_t> *src = &first.idx;
         if (b - a > 1) {
             run.clear();
@@ -439,9 +481,23 @@ int classify_points(sid_pm_ctx *ctx)
         } else order.insert(order.end(), src->begin(), src->end());
         a = b;
     }
+    // row-pair kernel: every launch position gets a block of global memory for its sum w'^2 values (256-byte granules)
+    std::vector<uint32_t> goff;
+    uint64_t gsii_granules = 0;
+    if (rp) {
+        goff.resize((size_t)n);
+        for (int64_t p = 0; p < n; ++p) {
+            goff[(size_t)p] = (uint32_t)gsii_granules;
+            gsii_granules += (npos_of[(size_t)order[(size_t)p]] * 4u + 255u) / 256u;
+        }
+        if (gsii_granules >= 0xffffffffull) return fail(SID_PM_ERR_UNSUPPORTED, "sum-of-squares scratch beyond 1 TB");
+        if (int rc = ctx->gsii.reserve((size_t)std::max<uint64_t>(gsii_granules, 1) * 64)) return rc;
+        if (int rc = ctx->d_goff.reserve((size_t)std::max<int64_t>(n, 1))) return rc;
+    }
     if (n > 0) {
         HIP_TRY(hipMemcpyAsync(ctx->d_order, order.data(), sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
-        HIP_TRY(hipStreamSynchronize(ctx->stream));               // `order` is a local
+        if (rp) HIP_TRY(hipMemcpyAsync(ctx->d_goff.p, goff.data(), sizeof(uint32_t) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));               // `order` and `goff` are locals
     }
     if (getenv("SID_PM_VERBOSE") != nullptr)                          // the launches of a step, one line each
         for (const Bucket &b : ctx->buckets)
@@ -530,7 +586,7 @@ SID_EXPORT void sid_pm_destroy(sid_pm_ctx *ctx)
     }
     for (auto &pair : ctx->own) for (auto &b : pair) b.release();
     ctx->arena.release();
-    ctx->out.release(); ctx->out_ij.release(); ctx->dbg_err.release();
+    ctx->out.release(); ctx->out_ij.release(); ctx->dbg_err.release(); ctx->gsii.release(); ctx->d_goff.release();
     if (ctx->h_refused) (void)hipHostFree(ctx->h_refused);
     delete ctx;
 }
@@ -678,6 +734,7 @@ SID_EXPORT int sid_pm_run(sid_pm_ctx *ctx)
         HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->slot_ready[ctx->cur_slot], 0));
     for (const Bucket &b : ctx->buckets) {
         A.order = ctx->d_order + b.offset;
+        A.gsii_off = ctx->d_goff.p ? ctx->d_goff.p + b.offset : nullptr;
         A.n_launch = b.count;
         const int lds_launch = std::min(b.lds, sid::max_lds_bytes());
         A.lds_bytes = lds_launch;
@@ -838,9 +895,9 @@ SID_EXPORT int sid_pm_debug_point(sid_pm_ctx *ctx, double c1, double r1, double 
     const int s = img_size, K = n_angles;
     const bool rp = use_rp(s, K);
     const int rpp = rp ? rp_paired(K) : 0;
-    int wh = 0, ww = 0, lds = lds_need(rp, rpp, s + 1, s + 1, s, K);
+    int wh = 0, ww = 0, lds = lds_need(rp, rpp, s + 1, s + 1, s, K, flags);
     if (window_dims(c2fg, r2fg, border, s, ctx->cur[1].rows, ctx->cur[1].cols, wh, ww))
-        lds = lds_need(rp, rpp, wh, ww, s, K);
+        lds = lds_need(rp, rpp, wh, ww, s, K, flags);
     if (lds > sid::max_lds_bytes()) return fail(SID_PM_ERR_UNSUPPORTED, "search window too large for LDS");
     std::vector<double> rotv;
     make_rot(angles, K, alpha0, s, rot, rotv);
@@ -854,15 +911,16 @@ SID_EXPORT int sid_pm_debug_point(sid_pm_ctx *ctx, double c1, double r1, double 
     if (!getenv("SID_PM_NO_SAMP_TABLE")) nflag = make_samp(rotv, K, s, sampv);
     DevBuf<float> dccm, dhes;
     DevBuf<long long> dcyc;
+    DevBuf<uint32_t> dgs;                                              // row-pair kernel: this point's sum w'^2 block + its offset (0)
     int rc = SID_PM_OK;
-    auto cleanup = [&]() { dv.release(); dang.release(); drot.release(); dout.release(); dord.release();
+    auto cleanup = [&]() { dv.release(); dang.release(); drot.release(); dout.release(); dord.release(); dgs.release();
                            dij.release(); dshape.release(); dt.release(); dccm.release(); dhes.release(); dcyc.release(); dsamp.release(); };
     const size_t tcount = (size_t)K * s * s;
     if ((rc = dv.reserve(5)) || (rc = dang.reserve((size_t)K)) || (rc = drot.reserve(4 * (size_t)K)) ||
         (rc = dout.reserve(5)) || (rc = dord.reserve(1)) || (rc = dij.reserve(3)) || (rc = dshape.reserve(2)) ||
         (rc = dt.reserve(tcount)) || (rc = dccm.reserve((size_t)std::max<int64_t>(cap, 1))) ||
         (rc = dhes.reserve((size_t)std::max<int64_t>(cap, 1))) || (rc = dcyc.reserve(32)) ||
-        (rc = dsamp.reserve(sampv.size() + 4))) { cleanup(); return rc; }
+        (rc = dsamp.reserve(sampv.size() + 4)) || (rc = dgs.reserve(64 + (size_t)(wh > s ? (wh - s + 1) * (ww - s + 1) : 1)))) { cleanup(); return rc; }
     const double v5[5] = {c1, r1, c2fg, r2fg, border};
     const int32_t zero = 0, shape0[2] = {0, 0};
     hipError_t e = hipSuccess;
@@ -873,6 +931,7 @@ SID_EXPORT int sid_pm_debug_point(sid_pm_ctx *ctx, double c1, double r1, double 
     step(hipMemcpy(dang.p, angles, sizeof(double) * K, hipMemcpyHostToDevice));
     step(hipMemcpy(drot.p, rotv.data(), sizeof(double) * rotv.size(), hipMemcpyHostToDevice));
     step(hipMemcpy(dord.p, &zero, sizeof zero, hipMemcpyHostToDevice));
+    step(hipMemset(dgs.p, 0, 64 * sizeof(uint32_t)));                  // entry 0 = the offset (0 granules); the block starts at entry 64
     if (!sampv.empty()) step(hipMemcpy(dsamp.p, sampv.data(), sizeof(uint16_t) * sampv.size(), hipMemcpyHostToDevice));
     step(hipMemcpy(dshape.p, shape0, sizeof shape0, hipMemcpyHostToDevice));
     step(hipMemset(dt.p, 0, tcount));
@@ -891,6 +950,7 @@ SID_EXPORT int sid_pm_debug_point(sid_pm_ctx *ctx, double c1, double r1, double 
         gauss_taps(A.gauss_w);
         A.samp = sampv.empty() ? nullptr : dsamp.p; A.samp_nflag = nflag;
         A.lds_bytes = lds;
+        A.gsii = dgs.p + 64; A.gsii_off = dgs.p;
         step((hipError_t)(rp ? sid::launch_pm_rp(A, lds, 256, 4, rpp, 0, 3, ctx->stream)
                                        : sid::launch_pm_mfma(A, lds, 256, 4, use_paired(K), ctx->stream)));
         step(hipStreamSynchronize(ctx->stream));
@@ -979,7 +1039,15 @@ static int estimate_points(const double *border, int64_t n, int img_size, int n_
     const int rpp = rp ? rp_paired(K) : 0;
     const int hws = (int)((double)s / 2.0);
     const int groups = (K + sid::kRpGroup - 1) / sid::kRpGroup;
-    constexpr double kSweep = 7.06e-3, kWinner = 8.64e-3, kPos = 3.28e-3, kFixed = 43.3, kTwoPerCu = 1.32, kOnePerCu = 1.69, kFourPerCu = 0.93;
+    // round 4 (transposed strip columns, sum w'^2 in global memory where it lifts the residency class): refitted to
+    // tools/border_cost.py on the shipped library, one set per kernel family - full table / two / four slot groups - within
+    // 2.3 / 4.3 / 7 % of the measured staircase (profiles/r04_border_cost.json)
+    struct Fit { double sweep, winner, pos, fixed, two, one, gs, four; };
+    static const Fit kFit[3] = {{3.4646e-3, 2.2848e-2, 7.6082e-3, 29.955, 1.1228, 1.2800, 1.06500, 0.93000},
+                                {3.9853e-3, 1.7996e-2, 7.6297e-3, 25.686, 1.2348, 1.3287, 0.99236, 0.95706},
+                                {2.5923e-3, 1.8513e-2, 6.4734e-3, 24.173, 1.2518, 1.3574, 1.00890, 0.98625}};
+    const Fit &F = kFit[rpp];
+    const double kSweep = F.sweep, kWinner = F.winner, kPos = F.pos, kFixed = F.fixed, kTwoPerCu = F.two, kOnePerCu = F.one, kFourPerCu = F.four;
     for (int64_t i = 0; i < n; ++i) {
         const double b = border[i];
         if (per_cu_out) per_cu_out[i] = kMaxPerCu;
@@ -989,9 +1057,10 @@ static int estimate_points(const double *border, int64_t n, int img_size, int n_
         double sweep, winner, cls_factor;
         int cls = kMaxPerCu;
         if (rp) {
-            const sid::RpLdsLayout L4 = sid::rp_lds_layout(wn, wn, s, K <= sid::kRpGroup, rp_rows(rpp, 4), 0, sid::rp_tab_pitch(rpp));
-            int per_cu = blocks_per_cu(L4.total), band = 4;
-            if (!rpp && per_cu == 2 && blocks_per_cu(sid::rp_lds_layout(wn, wn, s, K <= sid::kRpGroup, 8).total) >= 2) band = 8;
+            static const bool no_band8 = getenv("SID_PM_NO_BAND8") != nullptr;
+            const ShapeClass sc = shape_class(rp, rpp, wn, wn, s, K, 0, sid::mfma_band8_supported(s) && !no_band8 && !rpp, false);
+            const sid::RpLdsLayout L4 = sid::rp_lds_layout(wn, wn, s, K <= sid::kRpGroup, rp_rows(rpp, 4), 0, sid::rp_tab_pitch(rpp), rp_own_hes(K, 0), sc.gs);
+            const int per_cu = sc.cls, band = sc.band;
             const int rows = rp_rows(rpp, band), nb = (r + rows - 1) / rows, tiles = 2 * L4.npair + L4.nsingle;
             const double per_row_tile = (double)((s + 1) / 2 + s / 2 + 1) / 2.0 + (double)(((s - 32 + 1) / 2) * 2);
             // work items are dealt to the wavefronts of the workgroup: the busiest wavefront sets the pace
@@ -999,8 +1068,8 @@ static int estimate_points(const double *border, int64_t n, int img_size, int n_
             const int units = ((nb * tiles + nwaves - 1) / nwaves) * nwaves, wunits = ((((r + 15) / 16) * tiles + nwaves - 1) / nwaves) * nwaves;
             sweep = groups * (rpp == 2 ? 0.33 : rpp == 1 ? 0.55 : 1.0) * units * (rows * per_row_tile + 2.0);
             winner = wunits * 76.0;
-            cls_factor = (per_cu >= 4 && max_per_cu(rp, rpp) == 4) ? kFourPerCu : per_cu >= 3 ? 1.0 : per_cu == 2 ? kTwoPerCu : kOnePerCu;
-            cls = std::max(1, std::min(per_cu, max_per_cu(rp, rpp)));
+            cls_factor = ((per_cu >= 4 && max_per_cu(rp, rpp) == 4) ? kFourPerCu : per_cu >= 3 ? 1.0 : per_cu == 2 ? kTwoPerCu : kOnePerCu) * (sc.gs ? F.gs : 1.0);
+            cls = std::max(1, std::min(per_cu, max_per_cu(rp, rpp))) + (sc.gs ? 16 : 0);   // (+ 16: the launches that keep sum w'^2 in global memory are launches of their own)
         } else {
             const sid::MfmaLdsLayout L = sid::mfma_lds_layout(wn, wn, s, 4, use_paired(K));
             const int per_cu = blocks_per_cu(L.total), ntx = (r + 15) / 16;
@@ -1021,8 +1090,9 @@ SID_EXPORT int sid_pm_estimate_cost(const double *border, int64_t n, int img_siz
     return estimate_points(border, n, img_size, n_angles, cost_ns, nullptr);
 }
 
-// Workgroups per CU of the launch a point of that border joins (its LDS residency class: 1 .. 3, 4 for the slot-group
-// layouts): a launch runs 256 x that many points at a time, which is what the tail of a SHORT launch costs (dist.py).
+// Launch class of a point of that border: workgroups per CU (its LDS residency class: 1 .. 3, 4 for the slot-group layouts) in
+// the low four bits - a launch runs 256 x that many points at a time, which is what the tail of a SHORT launch costs (dist.py) -
+// plus 16 when the point runs in the launches that keep sum w'^2 in global memory (points of equal value share a launch).
 SID_EXPORT int sid_pm_estimate_residency(const double *border, int64_t n, int img_size, int n_angles, int32_t *per_cu)
 {
     if (n > 0 && !per_cu) return fail(SID_PM_ERR_ARG, "bad argument");

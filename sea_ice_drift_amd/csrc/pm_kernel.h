@@ -32,6 +32,12 @@ struct PMArgs {
     // pitch chosen by the host's classification): counted here - pinned host memory, read by sid_pm_sync / sid_pm_fetch /
     // sid_pm_check - so that a disagreement between host and device layout is an error, never a silent NaN
     int32_t *refused;
+    // row-pair kernel: sum w'^2 per placement of every point in global memory instead of LDS (7 .. 42 KB per point: the
+    // largest LDS item of a point with a large search border, written once and read twice).  gsii_off[j] = offset of launch
+    // position j's block in units of 64 entries (256 bytes); the block is written and read by the point's own workgroup
+    // only and stays in L2 in between.
+    uint32_t *gsii;
+    const uint32_t *gsii_off;
     // diagnostics (debug_point only; null in production launches)
     uint8_t *dbg_templates; float *dbg_ccm; float *dbg_hes; int32_t *dbg_shape; int64_t dbg_cap;
     long long *dbg_cycles;                          // [32] shader-clock stamps at phase boundaries
@@ -109,7 +115,9 @@ __host__ __device__ inline MfmaLdsLayout mfma_lds_layout(int wh, int ww, int s, 
 constexpr int kRpGroup = 15;    // angles per group of MFMA slots (the 16th slot is the all-ones template)
 struct RpLdsLayout {
     int wpitch, wrows;          // window pitch (multiple of 8) and rows written (window + zero rows)
-    int win_off, sii_off;
+    int win_off, sii_off;       // sii_off: sum w'^2 per placement (u32) in LDS; 0 when it lives in global memory (gs layouts, PMArgs::gsii)
+    int hes_off;                // Hessian magnitudes (f32 per placement): over the dead window + winner operands, or behind the histogram
+    int ccm_off;                // NCC matrix of the winning angle (f32 per placement), behind the winner's operands
     int wp_off, wp_pitch, wp_rows, wp_len;   // transposed window columns 32..: wp_rows rows (window column 32 + row) of wp_len bytes (one per window row)
     int u_off;                  // union: column sums | table + strip + patch + queue | winner operands + NCC matrix
     int tab_rows, tab_pitch;    // s + 3 rows of tab_pitch bytes (32 per stored slot)
@@ -148,8 +156,17 @@ __host__ __device__ constexpr int rp_class_limit(int lds_bytes)
 // groups - the lanes of the later groups read the first group's operands at a lagging address, so only those are stored
 __host__ __device__ constexpr int rp_tab_pitch(int paired) { return paired == 2 ? 128 : paired == 1 ? 256 : 512; }
 __host__ __device__ constexpr int rp_tab_shift(int paired) { return paired == 2 ? 7 : paired == 1 ? 8 : 9; }
+// gs: sum w'^2 per placement lives in GLOBAL memory (PMArgs::gsii) instead of LDS - 7 .. 42 KB less per point, which lifts
+// most borders above 27 into the next residency class (-10 .. -17 % there), at the price of ~5 % where it does not (measured
+// at border 20: the values are written once and read twice through L2).  The host chooses per launch (pm_capi.hip
+// classify_points); the kernel instantiations with a window pitch of 136 or more, or the run-time pitch, are the gs ones
+// (rp_pitch_is_gs).  Without gs the Hessian magnitudes take the LDS of the sums, as in rounds 2-3.
+// own_hes (gs only): the Hessian magnitudes get LDS of their own behind the winner's NCC matrix (the general ph_hessian -
+// hes_smth / mcc_norm, several groups of angles - keeps its histograms in the winner's operand block); otherwise they lie
+// over the window and the winner's operands, both dead by then (the NCC matrix moves up where those are too short).
+__host__ __device__ constexpr bool rp_pitch_is_gs(int pitch) { return pitch == 0 || pitch >= 136; }
 __host__ __device__ inline RpLdsLayout rp_lds_layout(int wh, int ww, int s, bool one_group, int band = 4, int force_pitch = 0,
-                                                     int tab_pitch = 512)
+                                                     int tab_pitch = 512, bool own_hes = false, bool gs = true)
 {
     RpLdsLayout L;
     const int rh = wh - s + 1, rw = ww - s + 1;
@@ -171,8 +188,8 @@ __host__ __device__ inline RpLdsLayout rp_lds_layout(int wh, int ww, int s, bool
     L.wrows = y0max + 2 * nst;                       // last step reads rows y0 + 2 (nst - 1) and + 1
     if (L.wrows < wh + 3) L.wrows = wh + 3;
     L.win_off = kMiscMfmaBytes;
-    L.sii_off = round_up(L.win_off + L.wrows * L.wpitch, 16);
-    L.u_off = round_up(L.sii_off + rh * rw * 4, 16);
+    L.sii_off = gs ? 0 : round_up(L.win_off + L.wrows * L.wpitch, 16);
+    L.u_off = gs ? round_up(L.win_off + L.wrows * L.wpitch, 16) : round_up(L.sii_off + rh * rw * 4, 16);
     L.ncp = (s - 32 + 1) / 2; L.nrg = 2;
     // transposed copy: one row per window column 32 .. 32 + rw - 1 + 2 ncp - 1 (the builder writes four rows at a time);
     // a lane reads 20 bytes (4-row band: shifts 0..3 + 16) or 24 (8-row band) from rho = y0 + 16 (g >> 1) (template rows
@@ -204,16 +221,29 @@ __host__ __device__ inline RpLdsLayout rp_lds_layout(int wh, int ww, int s, bool
         // are - with one group of angles the patch is dead by then and they lie over it, like the queue -, overwritten by
         // the winner's NCC matrix)
         L.wp_off = round_up(L.queue_off + cap * 16, 16);
-        int u = rh * ww * 4;
+        int u = wh * rw * 4;                                     // row sums of w'^2 (rp_sums)
         const int sweep = L.wp_off + L.wp_rows * L.wp_pitch - L.u_off;
         if (u < sweep) u = sweep;
         // winner: operands + NCC matrix, and (one group of angles: the fused Hessian, pm_kernel_rp prologue) 5 KB of
-        // histogram and key list behind them
-        const int winner = 2 * L.trow_bytes + round_up(rh * rw * 4, 16) + (one_group ? 5120 : 0);
+        // histogram and key list behind them; then the Hessian magnitudes unless they fit over the window + operands
+        int winner;
+        if (gs) {
+            // (the magnitudes start at the window; where window + operands are too short for them the NCC matrix moves up)
+            const int avail = L.u_off + 2 * L.trow_bytes - L.win_off;
+            const int extra = (own_hes || rh * rw * 4 <= avail) ? 0 : round_up(rh * rw * 4 - avail, 16);
+            L.ccm_off = L.u_off + 2 * L.trow_bytes + extra;
+            winner = L.ccm_off - L.u_off + round_up(rh * rw * 4, 16) + (one_group ? 5120 : 0);
+            L.hes_off = own_hes ? L.u_off + winner : L.win_off;
+            if (own_hes) winner += round_up(rh * rw * 4, 16);
+        } else {
+            L.ccm_off = L.u_off + 2 * L.trow_bytes;
+            L.hes_off = L.sii_off;
+            winner = 2 * L.trow_bytes + round_up(rh * rw * 4, 16) + (one_group ? 5120 : 0);
+        }
         if (u < winner) u = winner;
         L.total = round_up(L.u_off + u, 16);
     };
-    const int natural = L.strip_off + L.ncp * L.nrg * 1024 + 16, clear = round_up(L.u_off + rh * ww * 4, 16);   // (+ 16 scratch bytes)
+    const int natural = L.strip_off + L.ncp * L.nrg * 1024 + 16, clear = round_up(L.u_off + wh * rw * 4, 16);   // (+ 16 scratch bytes)
     // the candidate queue takes what its residency class leaves: the smallest queue decides the class, then it grows
     auto place_q = [&](int patch_off) {
         place(patch_off, kRpQueueMin);

@@ -104,6 +104,7 @@ struct Geo {
     int band;                        // output rows per sweep work item (kernel template parameter)
     int wp_off, wp_pitch, wp_rows, strip_off, wrows, npair, nsingle;   // row-pair kernel (RpLdsLayout)
     int queue_cap;                   // row-pair kernel: entries of the candidate queue (RpLdsLayout::queue_cap)
+    int hes_off, ccm_off;            // Hessian magnitudes and NCC matrix of the winning angle (f32 per placement)
     int hist_off;                    // 5 KB behind the NCC matrix of the winning angle for ph_hessian_fast (0: none - the general ph_hessian runs)
     long long r0, c0;                // window origin on image 2
     double c1, r1, nd;
@@ -540,7 +541,7 @@ __device__ __forceinline__ void ph_window(const uint8_t *img2, long long rows2, 
 // ---------------------------------------------------------------------------------------------
 // Phase 1: S_II' = box sums of w'^2 (running sums down the columns, then along the rows).
 // ---------------------------------------------------------------------------------------------
-__device__ __noinline__ void ph_sums()
+[[maybe_unused]] __device__ __noinline__ void ph_sums()
 {
     SID_PHASE_LOCALS;
     const uint8_t *win = smem + G.win_off;
@@ -1369,8 +1370,8 @@ __device__ __noinline__ void ph_hessian(unsigned flags, int iy, int ix, float be
                                         long long dbg_cap, long long *dbg_cycles)
 {
     SID_PHASE_LOCALS;
-    float *hes = reinterpret_cast<float *>(smem + G.sii_off);
-    const float *ccm = reinterpret_cast<const float *>(smem + G.u_off + 2 * G.trow_bytes);
+    float *hes = reinterpret_cast<float *>(smem + G.hes_off);
+    const float *ccm = reinterpret_cast<const float *>(smem + G.ccm_off);
     u32 *hist4 = reinterpret_cast<u32 *>(smem + G.u_off);             // winner operands are dead: 4 KB of histograms
     u32 *medlist = hist4 + 1024;                                       // + 1 KB of keys (2 * trow_bytes >= 5 KB for every s)
     const int rh = G.rh, rw = G.rw, npos = G.npos;
@@ -1394,7 +1395,7 @@ __device__ __noinline__ void ph_hessian(unsigned flags, int iy, int ix, float be
         // kernel in double ('reflect' boundary; centre tap first, then the pairs from the outermost inwards,
         // as scipy's correlate1d does for a symmetric kernel), rounded to float32 after each axis
         float *tmp = hes;                                              // the Hessian buffer is free until the gradient pass
-        float *cw = reinterpret_cast<float *>(smem + G.u_off + 2 * G.trow_bytes);
+        float *cw = reinterpret_cast<float *>(smem + G.ccm_off);
         const double w4 = m->gw[4], w3 = m->gw[3], w2 = m->gw[2], w1 = m->gw[1], w0 = m->gw[0];
         auto refl = [](int q, int n) { while (q < 0 || q >= n) { if (q < 0) q = -q - 1; if (q >= n) q = 2 * n - 1 - q; } return q; };
         __syncthreads();
@@ -1564,8 +1565,8 @@ __device__ __noinline__ void ph_hessian_fast(unsigned flags, int iy, int ix, flo
                                              long long dbg_cap, long long *dbg_cycles)
 {
     SID_PHASE_LOCALS;
-    float *hes = reinterpret_cast<float *>(smem + G.sii_off);
-    const float *ccm = reinterpret_cast<const float *>(smem + G.u_off + 2 * G.trow_bytes);
+    float *hes = reinterpret_cast<float *>(smem + G.hes_off);
+    const float *ccm = reinterpret_cast<const float *>(smem + G.ccm_off);
     u32 *hist = reinterpret_cast<u32 *>(smem + G.hist_off);            // 2048 16-bit counters, zero on entry; m->sel_cle = 0
     u32 *list = hist + 1024;                                           // kMedList keys
     const int rh = G.rh, rw = G.rw, npos = G.npos;
@@ -1790,6 +1791,7 @@ __global__ __launch_bounds__(BAND == 8 ? 512 : kMaxBlockM, BAND == 8 ? 2 : kOccM
         G->gpitch = L.gpitch; G->arow0 = L.arow0; G->tab_rows = L.tab_rows; G->ones_slot = PAIRED ? 7 : 15;
         G->s = s; G->K = K;
         G->win_off = L.win_off; G->sii_off = L.sii_off; G->u_off = L.u_off; G->patch_off = L.patch_off;
+        G->hes_off = L.sii_off; G->ccm_off = L.u_off + 2 * L.trow_bytes;   // (the sums' LDS holds the Hessian magnitudes later)
         G->ppitch = L.ppitch; G->pdim = L.pdim; G->pradius = L.pradius; G->queue_off = L.queue_off;
         G->trow_bytes = L.trow_bytes;
         G->pr0 = (int)floor(r1) - L.pradius; G->pc0 = (int)floor(c1) - L.pradius;
@@ -1957,12 +1959,14 @@ __global__ void rsqrt_kernel(const double *x, double *y, int64_t n)
 }  // namespace
 
 #ifdef SID_OCC4_TU
-// the only export of the second compilation: its kernels (slot groups, window pitch 104)
+// the only export of the second compilation: its kernels (slot groups, window pitches 104 and 112)
 void (*rp_occ4_kernel(int img_size, int paired, int pitch))(const PMArgs)
 {
-    if (pitch != 104 || (paired != 1 && paired != 2)) return nullptr;
-    if (img_size == 34) return paired == 2 ? pm_kernel_rp<34, 4, 2, 104> : pm_kernel_rp<34, 4, 1, 104>;
-    if (img_size == 35) return paired == 2 ? pm_kernel_rp<35, 4, 2, 104> : pm_kernel_rp<35, 4, 1, 104>;
+    if ((pitch != 104 && pitch != 112) || (paired != 1 && paired != 2)) return nullptr;
+    if (img_size == 34) return paired == 2 ? (pitch == 104 ? pm_kernel_rp<34, 4, 2, 104> : pm_kernel_rp<34, 4, 2, 112>)
+                                           : (pitch == 104 ? pm_kernel_rp<34, 4, 1, 104> : pm_kernel_rp<34, 4, 1, 112>);
+    if (img_size == 35) return paired == 2 ? (pitch == 104 ? pm_kernel_rp<35, 4, 2, 104> : pm_kernel_rp<35, 4, 2, 112>)
+                                           : (pitch == 104 ? pm_kernel_rp<35, 4, 1, 104> : pm_kernel_rp<35, 4, 1, 112>);
     return nullptr;
 }
 #else
@@ -2044,7 +2048,7 @@ static void (*rp_kernel_for(int band, int paired, int pitch))(const PMArgs)
                           : pitch == 168 ? pm_kernel_rp<S, 4, 2, 168> : pitch == 0 ? pm_kernel_rp<S, 4, 2, 0> : nullptr;
     if (paired == 1) return pitch == 104 ? pm_kernel_rp<S, 4, 1, 104> : pitch == 112 ? pm_kernel_rp<S, 4, 1, 112> : pitch == 136 ? pm_kernel_rp<S, 4, 1, 136>
                           : pitch == 168 ? pm_kernel_rp<S, 4, 1, 168> : pitch == 0 ? pm_kernel_rp<S, 4, 1, 0> : nullptr;
-    if (band == 8) return pitch == 136 ? pm_kernel_rp<S, 8, 0, 136> : pitch == 0 ? pm_kernel_rp<S, 8, 0, 0> : nullptr;
+    if (band == 8) return pitch == 136 ? pm_kernel_rp<S, 8, 0, 136> : pitch == 168 ? pm_kernel_rp<S, 8, 0, 168> : pitch == 0 ? pm_kernel_rp<S, 8, 0, 0> : nullptr;
     return pitch == 104 ? pm_kernel_rp<S, 4, 0, 104> : pitch == 112 ? pm_kernel_rp<S, 4, 0, 112> : pitch == 136 ? pm_kernel_rp<S, 4, 0, 136>
          : pitch == 168 ? pm_kernel_rp<S, 4, 0, 168> : pitch == 0 ? pm_kernel_rp<S, 4, 0, 0> : nullptr;
 }

@@ -40,10 +40,11 @@ def _shard_times(cost, cls, cuts):
     t = np.zeros(len(cuts) - 1)
     for r in range(len(cuts) - 1):
         a, b = cuts[r], cuts[r + 1]
-        for c in np.unique(cls[a:b]):
+        for c in np.unique(cls[a:b]):                               # one launch per class (residency | 16 x global sums)
             sel = cost[a:b][cls[a:b] == c]
-            latency = 256.0 * c * sel.mean()
-            t[r] += max(sel.sum() + _TAIL_ROUNDS.get(int(c), 0.5) * latency, latency)
+            per_cu = int(c) & 15
+            latency = 256.0 * per_cu * sel.mean()
+            t[r] += max(sel.sum() + _TAIL_ROUNDS.get(per_cu, 0.5) * latency, latency)
     return t
 
 

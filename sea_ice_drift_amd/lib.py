@@ -159,6 +159,64 @@ def interpolation_poly(x1, y1, x2, y2, x1grd, y1grd, order=1, **kwargs):
     return fx.reshape(np.shape(x1grd)), fy.reshape(np.shape(x1grd))
 
 
+# Triangulations started ahead of their use (``prefetch_triangulation``): key = digest of the point array, value = a
+# one-element future.  SeaIceDrift.get_drift_FT starts the triangulation of its matched key points on a worker thread the
+# moment the filters return - the Delaunay triangulation (Qhull, 30-85 ms for 2-3 x 10^4 points) is the longest step of the
+# pattern-matching prelude, and whatever the caller does between the two calls now runs beside it.
+_TRI_CACHE = {}
+_TRI_LOCK = None
+
+
+def _tri_key(src):
+    import hashlib
+    a = np.ascontiguousarray(src, dtype=np.float64)
+    return hashlib.blake2b(a.tobytes(), digest_size=16).digest() + str(a.shape).encode()
+
+
+def prefetch_triangulation(src):
+    """Start ``scipy.spatial.Delaunay(src)`` on a worker thread; ``_triangulation(src)`` with the SAME points (bit for bit)
+    picks the result up.  At most two are kept."""
+    import threading
+    global _TRI_LOCK
+    if _TRI_LOCK is None:
+        _TRI_LOCK = threading.Lock()
+    src = np.array(src, dtype=np.float64)
+    if src.ndim != 2 or src.shape[0] < 4 or src.shape[1] != 2:
+        return None
+    key = _tri_key(src)
+    box = {}
+
+    def work():
+        from scipy.spatial import Delaunay
+        try:
+            box['tri'] = Delaunay(src)
+        except Exception as e:                   # noqa: BLE001 - the consumer triangulates itself and raises what it raises
+            box['err'] = e
+    t = threading.Thread(target=work, name='sid-delaunay', daemon=True)
+    with _TRI_LOCK:
+        while len(_TRI_CACHE) >= 2:
+            _TRI_CACHE.pop(next(iter(_TRI_CACHE)))
+        _TRI_CACHE[key] = (t, box)
+    t.start()
+    return key
+
+
+def _triangulation(src):
+    """``scipy.spatial.Delaunay(src)`` - the one started by ``prefetch_triangulation`` for these very points, if any."""
+    from scipy.spatial import Delaunay
+    if _TRI_CACHE:
+        key = _tri_key(src)
+        with _TRI_LOCK:
+            hit = _TRI_CACHE.pop(key, None)
+        if hit is not None:
+            t, box = hit
+            t.join()
+            tri = box.get('tri')
+            if tri is not None and tri.points.shape == np.shape(src) and np.array_equal(tri.points, src):
+                return tri
+    return Delaunay(src)
+
+
 def interpolation_near(x1, y1, x2, y2, x1grd, y1grd, method='linear', first_guess_device=None, **kwargs):
     """scipy griddata of x2/y2 from the keypoints onto the grid points; NaN outside the
     convex hull (reference lib.py:179-201; note the (row, col) point order).
@@ -172,9 +230,13 @@ def interpolation_near(x1, y1, x2, y2, x1grd, y1grd, method='linear', first_gues
         # The reference calls griddata twice, i.e. triangulates the same keypoints twice - the slowest
         # step of the whole prelude.  One Delaunay triangulation serves both components; every component
         # is the same barycentric sum, so the values are bit-identical to the two separate calls.
-        from scipy.spatial import Delaunay
-        tri = Delaunay(src)
+        tri = _triangulation(src)
         vals = np.array([x2, y2], dtype=np.float64).T
+        if first_guess_device is not None and _has_degenerate_simplex(tri):
+            # SciPy gives a (nearly) flat simplex a NaN barycentric transform and then accepts queries in its neighbours
+            # with a much wider tolerance (sqrt(eps)) towards it; the device's flags do not model that,
+            # so such a triangulation - collinear or duplicated key points - is evaluated by SciPy alone
+            first_guess_device = None
         if first_guess_device is not None:
             # Point location and barycentric evaluation on the GPU.  Queries whose result could depend on SciPy's own choice
             # of simplex (on an edge, a vertex or the hull) or on the last bit of its arithmetic (value next to a
@@ -196,6 +258,20 @@ def interpolation_near(x1, y1, x2, y2, x1grd, y1grd, method='linear', first_gues
             both = LinearNDInterpolator(tri, vals)(dst)
         return both[..., 0].T, both[..., 1].T
     return griddata(src, x2, dst, method=method).T, griddata(src, y2, dst, method=method).T
+
+
+def _has_degenerate_simplex(tri, rcond_limit=1e-10):
+    """True when some simplex of the 2-D triangulation is so flat that SciPy may treat it as degenerate: SciPy's test is
+    LAPACK's reciprocal condition estimate of the 2 x 2 edge matrix below 1000 eps (qhull.pyx, _get_barycentric_transforms);
+    here the exact 1-norm condition number with a limit three orders of magnitude more careful."""
+    p = tri.points[tri.simplices]                                     # [ns, 3, 2]
+    a, b = p[:, 0] - p[:, 2], p[:, 1] - p[:, 2]                       # columns of the matrix SciPy factorises
+    det = a[:, 0] * b[:, 1] - a[:, 1] * b[:, 0]
+    n1 = np.maximum(np.abs(a).sum(axis=1), np.abs(b).sum(axis=1))     # ||M||_1; the adjugate has the same column sums, permuted
+    nadj = np.maximum(np.abs(b[:, 1]) + np.abs(a[:, 1]), np.abs(b[:, 0]) + np.abs(a[:, 0]))
+    with np.errstate(divide='ignore', invalid='ignore'):
+        rcond = np.abs(det) / (n1 * nadj)
+    return bool((~np.isfinite(rcond) | (rcond < rcond_limit)).any())
 
 
 def _fill_gpi(shape, gpi, data):

@@ -213,24 +213,36 @@ _REGISTRY_LOCK = threading.Lock()
 
 
 def _shared_context(device):
-    """(handle, lock) of ``device``."""
+    """(handle, lock) of ``device``.  The lock object of a device is created once and never replaced."""
     with _REGISTRY_LOCK:
+        lock = _CONTEXT_LOCKS.get(device)
+        if lock is None:
+            lock = _CONTEXT_LOCKS[device] = threading.RLock()
         ctx = _CONTEXTS.get(device)
         if ctx is None:
             ctx = _CONTEXTS[device] = _capi.PMContext(device)
-            _CONTEXT_LOCKS[device] = threading.RLock()
-        return ctx, _CONTEXT_LOCKS[device]
+        return ctx, lock
 
 
-def release_contexts():
-    """Destroy the per-device handles (each keeps two image-pair slots resident in HBM).  Registered with atexit;
-    safe to call at any time no call is in flight - the next call creates a fresh handle."""
+def release_contexts(timeout=5.0):
+    """Destroy the per-device handles (each keeps two image-pair slots resident in HBM) and hand back the cached device
+    memory of the detector, the matcher and the first-guess evaluation.  Registered with atexit; the next call creates a
+    fresh handle.  Every handle is closed under its own device's lock - the one its users hold from upload to fetch - so a
+    call in flight on another thread finishes first; a lock that stays held for ``timeout`` seconds (a worker stuck at
+    interpreter exit) is given up on and its handle left to the process teardown."""
     with _REGISTRY_LOCK:
-        items = list(_CONTEXTS.items())
-        _CONTEXTS.clear()
-    for device, ctx in items:
-        with _CONTEXT_LOCKS[device]:
-            ctx.close()
+        items = [(device, ctx, _CONTEXT_LOCKS[device]) for device, ctx in _CONTEXTS.items()]
+        _CONTEXTS.clear()                                             # (the locks stay: a device's lock is never replaced)
+    for device, ctx, lock in items:
+        if lock.acquire(timeout=timeout):
+            try:
+                ctx.close()
+            finally:
+                lock.release()
+    try:
+        _capi.release_workspaces(-1)
+    except Exception:                                                 # noqa: BLE001 - at exit the library may be gone already
+        pass
 
 
 atexit.register(release_contexts)
@@ -274,7 +286,23 @@ def use_mcc(c1, r1, c2fg, r2fg, border, img1, img2, img_size, alpha0, **kwargs):
 def pattern_matching(lon_pm1, lat_pm1, n1, c1, r1, n2, c2, r2,
                      margin=0, img_size=35, threads=5, srs=DEFAULT_SRS, **kwargs):
     """Run pattern matching on two images; same arguments and returns as the reference
-    (pmlib.py:326-392): u, v, a, r, h, lon2_dst, lat2_dst, each shaped like lon_pm1."""
+    (pmlib.py:326-392): u, v, a, r, h, lon2_dst, lat2_dst, each shaped like lon_pm1.
+
+    Keyword arguments that are NOT the reference's:
+
+    ``first_guess_on`` = 'auto' (default) | 'device' | 'host' - where the first guess of the prelude is evaluated
+        (``prepare_first_guess``, reference pmlib.py:249-324).  'host' is the reference's own code path: SciPy's
+        ``griddata`` for the displacement field and a KD-tree for the distance to the nearest key point.  'device'
+        evaluates both on the GPU (include/sid_fg.h): point location and barycentric interpolation in the SAME SciPy
+        triangulation, exact nearest-key-point distances.  'auto' means 'device' whenever a GPU is visible, so this
+        keyword changes the code path with the machine - on purpose, and without changing the result: for the default
+        ``old_border=True`` the first guess that reaches the kernel is the ROUNDED interpolation (pmlib.py:285-288), and
+        the device path flags every query whose rounded value could depend on SciPy's choice of simplex or on the last bit
+        of its arithmetic and evaluates exactly those with SciPy itself (lib.interpolation_near; fixture G4 pins the
+        prelude with both paths, tests/test_gpu_first_guess.py the flagging).  A triangulation with a degenerate simplex
+        and ``old_border=False`` (unrounded values) are evaluated by SciPy alone.
+    ``device`` (GPU index, default 0) and ``context`` (a ``_capi.PMContext`` of the caller's, for two calls in flight on
+        one GPU)."""
     t0 = time.time()
     img1, img2 = n1[1], n2[1]
     _sweep_options(kwargs)                                            # unsupported options fail before any work

@@ -8,7 +8,7 @@ constructor takes two Nansat-like objects (``sea_ice_drift_amd.domain.ArrayNansa
 is outside the scope of this package - passing file names raises with a pointer to what to pass instead.
 """
 from sea_ice_drift_amd.ftlib import feature_tracking
-from sea_ice_drift_amd.lib import get_drift_vectors
+from sea_ice_drift_amd.lib import get_drift_vectors, prefetch_triangulation
 from sea_ice_drift_amd.pmlib import pattern_matching
 
 
@@ -32,7 +32,26 @@ class SeaIceDrift(object):
         selects the units of u, v as in the reference (``lib.get_drift_vectors``)."""
         x1, y1, x2, y2 = feature_tracking(self.n1, self.n2, **kwargs)
         kwargs.pop('find_key_points', None)
-        return get_drift_vectors(self.n1, x1, y1, self.n2, x2, y2, **kwargs)
+        out = get_drift_vectors(self.n1, x1, y1, self.n2, x2, y2, **kwargs)
+        self._prefetch_first_guess(out[2], out[3])
+        return out
+
+    def _prefetch_first_guess(self, lon1, lat1):
+        """The usual next call is ``get_drift_PM(lons, lats, lon1, lat1, lon2, lat2)`` with these very vectors; its prelude
+        triangulates the key points of image 1 carried into the pixel space of image 2 (pmlib.py:280-288 through
+        lib.interpolation_near) - the longest step of the call.  The same arithmetic on the same numbers, started now on a
+        worker thread: whatever the caller does before ``get_drift_PM`` runs beside the triangulation, and the call picks
+        the result up when its points are bit-identical (otherwise it triangulates as before).  Results are unchanged."""
+        try:
+            import numpy as np
+            if len(lon1) < 4:
+                return
+            x1, y1 = self.n1.transform_points(lon1, lat1, 1)             # get_drift_PM (seaicedrift.py:85)
+            lon, lat = self.n1.transform_points(x1, y1)                  # prepare_first_guess (pmlib.py:280-282)
+            c1n2, r1n2 = self.n2.transform_points(lon, lat, 1)
+            prefetch_triangulation(np.array([r1n2, c1n2]).T)             # interpolation_near's point order (lib.py:195)
+        except Exception:                                                # noqa: BLE001 - a convenience, never an error
+            pass
 
     def get_drift_PM(self, lons, lats, lon1, lat1, lon2, lat2, **kwargs):
         """Same arguments and returns as the reference (seaicedrift.py:62-88):

@@ -21,17 +21,26 @@ int main()
                         const int hws = s / 2, wh = 2 * hws + 2 * b + 1, ww = wh - dw;
                         if (ww < s + 1) continue;
                         const int rows = paired == 2 ? 16 : paired == 1 ? 8 : band, tp = rp_tab_pitch(paired);
-                        for (int one_group = 0; one_group <= 1; ++one_group) {
-                        const RpLdsLayout N = rp_lds_layout(wh, ww, s, one_group != 0, rows, 0, tp);
+                        // several angle groups | one group | one group + own Hessian buffer (all with sum w'^2 in global memory: gs) |
+                        // one group, sums in LDS | several groups, sums in LDS
+                        for (int variant = 0; variant <= 4; ++variant) {
+                        const int one_group = variant == 1 || variant == 2 || variant == 3;
+                        const bool gs = variant <= 2;
+                        const bool own_hes = gs && variant != 1;
+                        const RpLdsLayout N = rp_lds_layout(wh, ww, s, one_group != 0, rows, 0, tp, own_hes, gs);
                         const int cp = rp_class_pitch(N.wpitch);
                         for (int pitch : {0, cp}) {
                             if (pitch && pitch < N.wpitch) continue;
-                            const RpLdsLayout L = rp_lds_layout(wh, ww, s, one_group != 0, rows, pitch, tp);
+                            const RpLdsLayout L = rp_lds_layout(wh, ww, s, one_group != 0, rows, pitch, tp, own_hes, gs);
                             const int rh = wh - s + 1, rw = ww - s + 1;
-                            char tag[96]; snprintf(tag, sizeof tag, "s=%d paired=%d band=%d b=%d dw=%d pitch=%d groups=%s", s, paired, band, b, dw, pitch, one_group ? "one" : "several");
+                            char tag[96]; snprintf(tag, sizeof tag, "s=%d paired=%d band=%d b=%d dw=%d pitch=%d variant=%d", s, paired, band, b, dw, pitch, variant);
                             CHECK(L.wpitch >= ww && L.wpitch % 8 == 0 && (!pitch || L.wpitch == pitch), "%s: window pitch %d", tag, L.wpitch);
-                            CHECK(L.win_off >= kMiscMfmaBytes && L.sii_off >= L.win_off + L.wrows * L.wpitch, "%s: window overlaps the sums", tag);
-                            CHECK(L.u_off >= L.sii_off + rh * rw * 4, "%s: sums overlap the union", tag);
+                            // (gs: sum w'^2 per placement lives in global memory and the union follows the window)
+                            if (gs) CHECK(L.win_off >= kMiscMfmaBytes && L.u_off >= L.win_off + L.wrows * L.wpitch && L.sii_off == 0, "%s: window overlaps the union", tag);
+                            else {
+                                CHECK(L.win_off >= kMiscMfmaBytes && L.sii_off >= L.win_off + L.wrows * L.wpitch, "%s: window overlaps the sums", tag);
+                                CHECK(L.u_off >= L.sii_off + rh * rw * 4, "%s: sums overlap the union", tag);
+                            }
                             CHECK(L.tab_pitch == tp && L.strip_off == L.u_off + L.tab_rows * tp, "%s: table", tag);
                             CHECK(L.patch_off >= L.strip_off + L.ncp * L.nrg * 1024 + 16, "%s: patch overlaps the strip operands", tag);
                             CHECK(L.queue_cap >= kRpQueueMin && L.queue_cap <= kQueueCap, "%s: queue of %d entries", tag, L.queue_cap);
@@ -43,23 +52,30 @@ int main()
                             // last strip read: 24 bytes from y0max + 32 (rp_item_strip); y0max <= rh - 1 rounded up to the band
                             CHECK(L.wp_pitch >= rp_band_y0((rh + rows - 1) / rows - 1, (rh + rows - 1) / rows, rh, rows) + 56, "%s: transposed row too short", tag);
                             CHECK(L.wp_off + L.wp_rows * L.wp_pitch <= L.total, "%s: transposed columns beyond the end", tag);
-                            CHECK(L.u_off + rh * ww * 4 <= L.total, "%s: column sums beyond the end", tag);
-                            CHECK(L.u_off + 2 * L.trow_bytes + rh * rw * 4 + (one_group ? 5120 : 0) <= L.total, "%s: winner + histogram beyond the end", tag);
+                            CHECK(L.u_off + wh * rw * 4 <= L.total, "%s: row sums beyond the end", tag);
+                            CHECK(L.ccm_off >= L.u_off + 2 * L.trow_bytes && L.ccm_off + rh * rw * 4 + (one_group ? 5120 : 0) <= L.total, "%s: winner + histogram beyond the end", tag);
+                            // the Hessian magnitudes: over the window + winner operands (never into the NCC matrix), or LDS of their own
+                            if (!gs) CHECK(L.hes_off == L.sii_off && L.ccm_off == L.u_off + 2 * L.trow_bytes, "%s: Hessian magnitudes take the LDS of the sums", tag);
+                            else if (own_hes) CHECK(L.hes_off >= L.ccm_off + rh * rw * 4 + (one_group ? 5120 : 0) && L.hes_off + rh * rw * 4 <= L.total, "%s: own Hessian buffer", tag);
+                            else CHECK(L.hes_off == L.win_off && L.hes_off + rh * rw * 4 <= L.ccm_off, "%s: Hessian magnitudes reach the NCC matrix", tag);
                             CHECK(L.total % 16 == 0, "%s: total %d", tag, L.total);
                             if (b <= 50 && dw == 0) CHECK(L.total <= 160 * 1024, "%s: %d bytes do not fit the LDS", tag, L.total);
                         }
                         }
                     }
     // residency classes of the benchmark's borders (the numbers DESIGN.md quotes)
-    auto total = [](int b, int paired) {
+    auto total = [](int b, int paired, bool gs) {
         const int w = 35 + 2 * b, rows = paired == 2 ? 16 : paired == 1 ? 8 : 4, tp = rp_tab_pitch(paired);
-        const int cp = rp_class_pitch(rp_lds_layout(w, w, 34, true, rows, 0, tp).wpitch);
-        return rp_lds_layout(w, w, 34, true, rows, cp, tp).total;
+        int cp = rp_class_pitch(rp_lds_layout(w, w, 34, true, rows, 0, tp, false, gs).wpitch);
+        if (gs && cp < 136) cp = 136;                                  // (the gs instantiations start at pitch 136)
+        return rp_lds_layout(w, w, 34, true, rows, cp, tp, false, gs).total;
     };
-    CHECK(total(20, 0) <= 42 * 1280 && total(27, 0) <= 42 * 1280 && total(28, 0) > 42 * 1280, "15 angles: borders 20..27 three per CU");
-    CHECK(total(28, 0) <= 64 * 1280 && total(38, 0) <= 64 * 1280 && total(39, 0) > 64 * 1280, "15 angles: borders 28..38 two per CU");
-    CHECK(total(20, 1) <= 32 * 1280 && total(21, 1) <= 32 * 1280 && total(22, 1) > 32 * 1280, "7 angles: borders 20, 21 four per CU");
-    CHECK(total(20, 2) <= 32 * 1280 && total(21, 2) <= 32 * 1280, "3 angles: borders 20, 21 four per CU");
+    // sums in LDS: borders 20..27 three per CU; with the sums in global memory 28..36 as well, 37..47 two per CU
+    CHECK(total(20, 0, false) <= 42 * 1280 && total(27, 0, false) <= 42 * 1280 && total(28, 0, false) > 42 * 1280, "15 angles, LDS sums: borders 20..27 three per CU");
+    CHECK(total(28, 0, true) <= 42 * 1280 && total(36, 0, true) <= 42 * 1280 && total(37, 0, true) > 42 * 1280, "15 angles, gs: borders 28..36 three per CU");
+    CHECK(total(37, 0, true) <= 64 * 1280 && total(47, 0, true) <= 64 * 1280 && total(48, 0, true) > 64 * 1280, "15 angles, gs: borders 37..47 two per CU");
+    CHECK(total(20, 1, false) <= 32 * 1280 && total(21, 1, false) <= 32 * 1280 && total(22, 1, false) > 32 * 1280, "7 angles, LDS sums: borders 20, 21 four per CU");
+    CHECK(total(20, 2, false) <= 32 * 1280 && total(21, 2, false) <= 32 * 1280, "3 angles, LDS sums: borders 20, 21 four per CU");
     printf("%d violations\n", bad);
     return bad > 100 ? 100 : bad;
 }

@@ -69,7 +69,9 @@ def test_cost_shards_partition_and_balance():
         t = _shard_times(point_cost(border[order]), _capi.estimate_residency(border[order]), cuts)
         assert t.max() / t.min() < 1.02
         cost = [point_cost(border[p]).sum() for p in parts]
-        assert max(cost) / min(cost) < 1.25                                   # (at 8 shards a two-launch shard carries two tails)
+        # (at 8 shards the rank with the largest borders runs two launches of few slots - one workgroup per CU, two per CU -
+        # whose tails are a third of its step: it gets that much less work than a rank of border-20 points)
+        assert max(cost) / min(cost) < 1.45
         if world > 1:
             assert cost[0] < cost[-1]                                         # (largest borders: fewest slots, longest tail)
         if world == 8:                                          # a rank holds neighbouring borders, not a bit of each

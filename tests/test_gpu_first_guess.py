@@ -72,6 +72,34 @@ def test_lattice_keypoints_are_resolved_or_flagged():
     np.testing.assert_array_equal(np.round(np.stack([xg, yg], axis=1)[fin]), np.round(exp[fin]))
 
 
+def test_bucket_walk_equals_the_brute_force_pass(monkeypatch):
+    """Round 4: point location walks a uniform grid of buckets instead of testing every simplex.  Values, located simplices
+    and doubt flags must be those of the brute-force pass (SID_FG_NO_GRID=1) on scattered and on lattice key points, with
+    queries inside, outside, on vertices and far outside the bounding box; a triangulation whose bucket lists would not fit
+    (one huge sliver fan) falls back to the brute-force pass by itself."""
+    rng = np.random.default_rng(28)
+    cases = []
+    src = rng.uniform(0, 9000, (30000, 2))
+    cases.append((src, np.concatenate([rng.uniform(-500, 9500, (40000, 2)), src[:2000], rng.uniform(-1e5, 1e5, (500, 2))])))
+    lat = np.unique(np.floor(rng.uniform(0, 400, (6000, 2))), axis=0)
+    qx, qy = np.meshgrid(np.arange(2.0, 398.0, 2.0), np.arange(2.0, 398.0, 2.0))
+    cases.append((lat, np.stack([qy.ravel(), qx.ravel()], axis=1)))
+    # a few points far away: long thin hull triangles across the whole box
+    far = np.concatenate([rng.uniform(0, 100, (3000, 2)), [[1e6, 50.0], [-1e6, 50.0], [50.0, 1e6]]])
+    cases.append((far, rng.uniform(-10, 110, (5000, 2))))
+    for src, q in cases:
+        vals = np.stack([src[:, 1] * 1.01 + rng.normal(0, 2, len(src)), src[:, 0] * 0.99 + rng.normal(0, 2, len(src))], axis=1)
+        tri = Delaunay(src)
+        monkeypatch.delenv('SID_FG_NO_GRID', raising=False)
+        got, sx, doubt = _capi.fg_interp_linear(tri.points, tri.simplices, vals, q, details=True)
+        monkeypatch.setenv('SID_FG_NO_GRID', '1')
+        exp, esx, edoubt = _capi.fg_interp_linear(tri.points, tri.simplices, vals, q, details=True)
+        monkeypatch.delenv('SID_FG_NO_GRID')
+        np.testing.assert_array_equal(doubt, edoubt)
+        np.testing.assert_array_equal(sx, esx)
+        np.testing.assert_array_equal(got, exp)                           # (NaN positions and bits alike)
+
+
 def test_nearest_keypoint_distance_is_exact():
     rng = np.random.default_rng(9)
     seeds = np.floor(rng.uniform(0, 3000, (5000, 2)))

@@ -185,3 +185,20 @@ def test_shared_handle_is_held_by_one_call_at_a_time(monkeypatch):
     for k in range(0, len(log), 4):                       # every call's four steps are contiguous and of one caller
         steps = log[k:k + 4]
         assert [s[0] for s in steps] == ['upload', 'set', 'run', 'fetch'] and len({s[1] for s in steps}) == 1
+
+
+def test_flat_simplices_send_the_first_guess_to_scipy():
+    """SciPy treats a (nearly) flat simplex as degenerate and widens its tolerance around it; the device's
+    doubt flags do not model that, so a triangulation that holds one is evaluated by SciPy alone (lib.interpolation_near)."""
+    import types
+    from sea_ice_drift_amd import lib
+    pts = np.array([[0.0, 0.0], [10.0, 0.0], [0.0, 10.0], [10.0, 10.0], [5.0, 5e-12]])
+    good = types.SimpleNamespace(points=pts, simplices=np.array([[0, 1, 2], [1, 3, 2]]))
+    flat = types.SimpleNamespace(points=pts, simplices=np.array([[0, 1, 2], [0, 1, 4]]))      # (0,0), (10,0), (5, 5e-12)
+    dup = types.SimpleNamespace(points=pts, simplices=np.array([[0, 0, 2]]))                  # zero area: rcond = 0
+    assert not lib._has_degenerate_simplex(good)
+    assert lib._has_degenerate_simplex(flat) and lib._has_degenerate_simplex(dup)
+    from scipy.spatial import Delaunay
+    rng = np.random.default_rng(5)
+    assert not lib._has_degenerate_simplex(Delaunay(rng.uniform(0, 3000, (4000, 2))))
+    assert not lib._has_degenerate_simplex(Delaunay(np.stack(np.meshgrid(np.arange(40.0), np.arange(40.0)), -1).reshape(-1, 2)))
