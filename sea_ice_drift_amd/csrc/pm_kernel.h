@@ -50,6 +50,7 @@ __host__ __device__ inline int round_up(int v, int m) { return (v + m - 1) / m *
 constexpr int kMiscMfmaBytes = 2688;
 constexpr int kTrowPad = 36;         // zero rows around a winner operand block: 16 above, 20 below (the step loop runs in fours)
 constexpr int kQueueCap = 192;       // arg-max candidates waiting for exact evaluation (16 B each)
+constexpr int kRpQueueWithSi = 128;  // ... and the sums kept for the winner (RpLdsLayout::si_off) leave it at least this
 constexpr int kRpQueueMin = 64;      // row-pair kernel: the queue shrinks to this where it decides the residency class (overflow is evaluated in place)
 
 struct MfmaLdsLayout {
@@ -116,6 +117,7 @@ constexpr int kRpGroup = 15;    // angles per group of MFMA slots (the 16th slot
 struct RpLdsLayout {
     int wpitch, wrows;          // window pitch (multiple of 8) and rows written (window + zero rows)
     int win_off, sii_off;       // sii_off: sum w'^2 per placement (u32) in LDS; 0 when it lives in global memory (gs layouts, PMArgs::gsii)
+    int si_off;                 // sum w' per placement (i32) kept from the sweep for the winner's matrix, where the residency class has room for it (else 0)
     int hes_off;                // Hessian magnitudes (f32 per placement): over the dead window + winner operands, or behind the histogram
     int ccm_off;                // NCC matrix of the winning angle (f32 per placement), behind the winner's operands
     int wp_off, wp_pitch, wp_rows, wp_len;   // transposed window columns 32..: wp_rows rows (window column 32 + row) of wp_len bytes (one per window row)
@@ -244,10 +246,19 @@ __host__ __device__ inline RpLdsLayout rp_lds_layout(int wh, int ww, int s, bool
         L.total = round_up(L.u_off + u, 16);
     };
     const int natural = L.strip_off + L.ncp * L.nrg * 1024 + 16, clear = round_up(L.u_off + wh * rw * 4, 16);   // (+ 16 scratch bytes)
-    // the candidate queue takes what its residency class leaves: the smallest queue decides the class, then it grows
+    // Sum w' per placement - the output of the all-ones slot, which the sweep computes for every placement anyway - is kept
+    // for the winner's matrix where the residency class has 4 B per placement to spare (full table, sums in LDS: border 20,
+    // 58 % of the benchmark's points): the winner then multiplies no all-ones operand, half of its matrix instructions.
+    // It goes behind sum w'^2 and everything from the union on moves up (applied at the end).
+    const int si_pad = (!gs && one_group && tab_pitch == 512) ? round_up(rh * rw * 4, 16) : 0;
+    bool si_fits = false;
+    // the candidate queue takes what its residency class leaves: the smallest queue decides the class, then the kept sums
+    // take their share, then the queue grows
     auto place_q = [&](int patch_off) {
         place(patch_off, kRpQueueMin);
-        const int room = (rp_class_limit(L.total) - L.wp_rows * L.wp_pitch - L.queue_off) / 16;   // entries that keep the class
+        const int limit = rp_class_limit(L.total);
+        si_fits = si_pad > 0 && L.total + si_pad + (kRpQueueWithSi - kRpQueueMin) * 16 <= limit;   // (not at the price of a short queue)
+        const int room = (limit - (si_fits ? si_pad : 0) - L.wp_rows * L.wp_pitch - L.queue_off) / 16;   // entries that keep the class
         const int cap = room > kQueueCap ? kQueueCap : room;
         if (cap > kRpQueueMin) place(patch_off, cap);
     };
@@ -256,6 +267,11 @@ __host__ __device__ inline RpLdsLayout rp_lds_layout(int wh, int ww, int s, bool
         const int limit = rp_class_limit(L.total);
         place_q(clear);
         if (L.total > limit) place_q(natural);
+    }
+    L.si_off = 0;
+    if (si_fits) {
+        L.si_off = L.u_off;
+        L.u_off += si_pad; L.strip_off += si_pad; L.patch_off += si_pad; L.queue_off += si_pad; L.wp_off += si_pad; L.ccm_off += si_pad; L.total += si_pad;
     }
     return L;
 }

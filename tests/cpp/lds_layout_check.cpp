@@ -40,7 +40,11 @@ int main()
                             else {
                                 CHECK(L.win_off >= kMiscMfmaBytes && L.sii_off >= L.win_off + L.wrows * L.wpitch, "%s: window overlaps the sums", tag);
                                 CHECK(L.u_off >= L.sii_off + rh * rw * 4, "%s: sums overlap the union", tag);
+                                // sum w' kept for the winner: behind sum w'^2, in front of the union, never at the price of a residency class
+                                if (L.si_off) CHECK(L.si_off >= L.sii_off + rh * rw * 4 && L.u_off >= L.si_off + rh * rw * 4 && one_group && tp == 512 &&
+                                                    rp_class_limit(L.total) == rp_class_limit(L.total - ((rh * rw * 4 + 15) / 16) * 16), "%s: kept sums", tag);
                             }
+                            if (gs) CHECK(L.si_off == 0, "%s: kept sums with the sums in global memory", tag);
                             CHECK(L.tab_pitch == tp && L.strip_off == L.u_off + L.tab_rows * tp, "%s: table", tag);
                             CHECK(L.patch_off >= L.strip_off + L.ncp * L.nrg * 1024 + 16, "%s: patch overlaps the strip operands", tag);
                             CHECK(L.queue_cap >= kRpQueueMin && L.queue_cap <= kQueueCap, "%s: queue of %d entries", tag, L.queue_cap);
@@ -76,6 +80,10 @@ int main()
     CHECK(total(37, 0, true) <= 64 * 1280 && total(47, 0, true) <= 64 * 1280 && total(48, 0, true) > 64 * 1280, "15 angles, gs: borders 37..47 two per CU");
     CHECK(total(20, 1, false) <= 32 * 1280 && total(21, 1, false) <= 32 * 1280 && total(22, 1, false) > 32 * 1280, "7 angles, LDS sums: borders 20, 21 four per CU");
     CHECK(total(20, 2, false) <= 32 * 1280 && total(21, 2, false) <= 32 * 1280, "3 angles, LDS sums: borders 20, 21 four per CU");
+    {   // border 20 (58 % of the benchmark's points) keeps sum w' for the winner and stays at three per CU; border 21 has no room
+        const RpLdsLayout a = rp_lds_layout(75, 75, 34, true, 4, 112, 512, false, false), b = rp_lds_layout(77, 77, 34, true, 4, 112, 512, false, false);
+        CHECK(a.si_off != 0 && a.total <= 42 * 1280 && b.si_off == 0, "kept sums at border 20 only (%d, %d)", a.total, b.total);
+    }
     printf("%d violations\n", bad);
     return bad > 100 ? 100 : bad;
 }

@@ -254,3 +254,45 @@ def test_results_written_straight_into_pinned_host_memory(pm_ctx, c_oracle):
     pm_ctx.sync()
     np.testing.assert_array_equal(out.numpy(), ref)
     np.testing.assert_array_equal(ij.numpy(), ref_ij)
+
+
+@pytest.mark.parametrize('s,angles', [(34, ANGLES15), (34, [-3, 0, 3]), (35, ANGLES7)])
+def test_every_launch_class_incl_global_sums_and_borders_up_to_68(pm_ctx, c_oracle, monkeypatch, s, angles):
+    """Round 4: borders 28 .. 47 run launches that keep the per-placement sum of squares in GLOBAL memory (the smaller LDS
+    footprint lifts them into the next residency class), the Hessian magnitudes lie over the dead window, and search borders up
+    to 68 fit the 160 KB of LDS (58 before).  Every border 20 .. 68 in one call - all launch classes, both forms of the sums -
+    against the oracle; then the same points with the global form forced everywhere (SID_PM_ALWAYS_GS) and forbidden wherever an
+    LDS instantiation exists (SID_PM_NO_GS): bit-identical results.  A point the device refused would raise in fetch
+    (sid_pm_check)."""
+    size = 1400
+    img1, img2 = syn.make_pair(size, size, seed=23)
+    rng = np.random.default_rng(3)
+    borders = np.repeat(np.arange(20, 69), 2).astype(np.float64)
+    n = len(borders)
+    c1 = np.rint(rng.uniform(250, size - 250, n)); r1 = np.rint(rng.uniform(250, size - 250, n))
+    dc, dr = syn.true_displacement(c1, r1)
+    c2 = c1 + np.rint(dc) + rng.integers(-2, 3, n); r2 = r1 + np.rint(dr) + rng.integers(-2, 3, n)
+    rot = rot_for(angles, 0.0, s)
+    exp, exp_ij = c_oracle.pm_batch(img1, img2, c1, r1, c2, r2, borders, s, 0.0, angles, rot=rot, nthreads=8)
+    assert np.isfinite(exp[:, 0]).sum() > n * 0.9
+    pm_ctx.upload_pair(img1, img2)
+    results = []
+    for env in (None, 'SID_PM_ALWAYS_GS', 'SID_PM_NO_GS'):
+        for k in ('SID_PM_ALWAYS_GS', 'SID_PM_NO_GS'):
+            monkeypatch.delenv(k, raising=False)
+        if env:
+            monkeypatch.setenv(env, '1')
+        pm_ctx.set_points(c1, r1, c2, r2, borders, s, 0.0, angles, rot=rot)
+        pm_ctx.run()
+        got, got_ij = pm_ctx.fetch()
+        assert_parity(got, got_ij, exp, exp_ij)
+        results.append((got, got_ij))
+    for got, got_ij in results[1:]:
+        np.testing.assert_array_equal(got_ij, results[0][1])
+        np.testing.assert_array_equal(got[:, :4], results[0][0][:, :4])
+    for k in ('SID_PM_ALWAYS_GS', 'SID_PM_NO_GS'):
+        monkeypatch.delenv(k, raising=False)
+    # one more border does not fit any more: an error, not a NaN
+    with pytest.raises(_capi.SidPmError) as e:
+        pm_ctx.set_points(c1[:1], r1[:1], c2[:1], r2[:1], [75.0], s, 0.0, angles, rot=rot)
+    assert e.value.code == -4

@@ -8,15 +8,15 @@ OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 # HBM traffic first: bench.py quotes profiles/traffic.json and checks that it was collected on the library it runs
-rocprofv3 --pmc FETCH_SIZE -d /tmp/pf_$TAG -o pf -- python3 $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
-rocprofv3 --pmc WRITE_SIZE -d /tmp/pw_$TAG -o pw -- python3 $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
+rocprofv3 --pmc FETCH_SIZE -d /tmp/pf_$TAG -o pf -- python3 $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-also-defaults --check 0 > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE -d /tmp/pw_$TAG -o pw -- python3 $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-also-defaults --check 0 > /dev/null 2>&1
 python3 $R/tools/pmc_traffic.py $(find /tmp/pf_$TAG -name "*.db" | head -1) $(find /tmp/pw_$TAG -name "*.db" | head -1) pm_kernel > $OUT/pmc_traffic.json
 python3 - "$OUT/pmc_traffic.json" "$R" > $OUT/traffic.json <<'PY'
 import hashlib, json, sys
 raw = json.load(open(sys.argv[1])); root = sys.argv[2]
 fetch_kb = sum(v.get('fetch_kb', 0.0) for v in raw.values()); write_kb = sum(v.get('write_kb', 0.0) for v in raw.values())
 disp = sum(v.get('dispatches', 0) for v in raw.values())
-steps = 5                                   # --steps 4 --warmup 1
+steps = 6                                   # --steps 4 --warmup 1 + the poisoned step the parity check reads
 launches = disp / steps
 fetch = fetch_kb * 1024.0 * 2.0 / steps     # FETCH_SIZE x 2 on gfx950 (MI355X_MICROARCH.md; calibration in profiles/r01_hbm_counter_calibration.json)
 write = write_kb * 1024.0 / steps
@@ -25,12 +25,12 @@ print(json.dumps({
  'so_md5': hashlib.md5(open(root + '/sea_ice_drift_amd/libsid_pm.so', 'rb').read()).hexdigest(),
  'launches_per_step': launches, 'fetch_bytes_per_step_raw': fetch / 2.0, 'fetch_correction': 2.0, 'fetch_bytes_per_step': fetch,
  'write_bytes_per_step': write, 'hbm_bytes_per_step': fetch + write, 'hbm_bytes_per_launch': (fetch + write) / max(launches, 1),
- 'source': 'rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `python3 bench.py --steps 4 --warmup 1 --no-cpu-baseline` (%d dispatches), summed with tools/pmc_traffic.py (tools/collect_profiles.sh)' % disp,
- 'note': 'fetch: search windows, image-1 patches, sampling table; write: 52 B of results per point (+ callee-saved register saves); algorithmic bytes = both images once (0.2 GB per step)'}, indent=1))
+ 'source': 'rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `python3 bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-also-defaults --check 0` (%d dispatches = 6 steps: warm-up, 4 timed, 1 for the parity check), summed with tools/pmc_traffic.py (tools/collect_profiles.sh)' % disp,
+ 'note': 'fetch: search windows, image-1 patches, sampling table, the sums of squares of the points that keep them in global memory (read back from L2 / HBM); write: 52 B of results per point + those sums (4 B per placement of ~8 500 points: round 4) + register spills; algorithmic bytes = both images once (0.2 GB per step)'}, indent=1))
 PY
 cp $OUT/traffic.json $R/profiles/traffic.json
 python3 $R/bench.py --steps 20 --warmup 3 > $OUT/bench.json 2> $OUT/bench.err
-for cfg in "--border 20" "--border 50" "--angles 3" "--border 20 --angles 3" "--angles 1" "--border 20 --angles 1" "--img-size 35" "--img-size 35 --angles 1"; do
+for cfg in "--border 20" "--border 30" "--border 50" "--angles 3" "--border 20 --angles 3" "--angles 1" "--border 20 --angles 1" "--img-size 35" "--img-size 35 --angles 1"; do
   python3 $R/bench.py --steps 30 --warmup 5 --no-cpu-baseline $cfg 2>/dev/null | python3 -c "
 import sys, json
 d = json.loads(sys.stdin.read())
@@ -40,12 +40,12 @@ python3 $R/bench.py --mode stream --pairs 16 --steps 2 --warmup 1 --check 32 > $
 python3 $R/bench.py --gpus 2 --steps 5 --warmup 1 --no-cpu-baseline > $OUT/dryrun_2ranks_1gpu.json 2>> $OUT/bench.err
 python3 $R/bench.py --gpus 1 --force-collective --steps 20 --warmup 3 --no-cpu-baseline > $OUT/force_collective_rccl_1gpu.json 2>> $OUT/bench.err
 python3 $R/bench.py --mode ftpm --check 400 > $OUT/ftpm_bench.json 2>> $OUT/bench.err
-rocprofv3 --kernel-trace --stats -d /tmp/kt_$TAG -o kt -- python3 $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
+rocprofv3 --kernel-trace --stats -d /tmp/kt_$TAG -o kt -- python3 $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-also-defaults --check 0 > /dev/null 2>&1
 python3 $R/tools/rocpd_summary.py $(find /tmp/kt_$TAG -name "*.db" | head -1) > $OUT/kernel_trace_stats.txt
-rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU -d /tmp/p1_$TAG -o p1 -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
-rocprofv3 --pmc SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_LDS -d /tmp/p2_$TAG -o p2 -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
-rocprofv3 --pmc SQ_VALU_MFMA_COEXEC_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_CYCLES -d /tmp/p3_$TAG -o p3 -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
-rocprofv3 --pmc SQC_ICACHE_REQ SQC_ICACHE_MISSES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE -d /tmp/p4_$TAG -o p4 -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
+rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU -d /tmp/p1_$TAG -o p1 -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-also-defaults --check 0 > /dev/null 2>&1
+rocprofv3 --pmc SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_LDS -d /tmp/p2_$TAG -o p2 -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-also-defaults --check 0 > /dev/null 2>&1
+rocprofv3 --pmc SQ_VALU_MFMA_COEXEC_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_CYCLES -d /tmp/p3_$TAG -o p3 -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-also-defaults --check 0 > /dev/null 2>&1
+rocprofv3 --pmc SQC_ICACHE_REQ SQC_ICACHE_MISSES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE -d /tmp/p4_$TAG -o p4 -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-also-defaults --check 0 > /dev/null 2>&1
 for p in p1 p2 p3 p4; do python3 $R/tools/rocpd_summary.py $(find /tmp/${p}_$TAG -name "*.db" | head -1) | sed -n '/PMC per dispatch/,$p' >> $OUT/pmc_counters.txt; done
 python3 $R/tools/e2e_bench.py > $OUT/e2e_pattern_matching.json 2>> $OUT/bench.err
 ls -la $OUT

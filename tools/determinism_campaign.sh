@@ -28,4 +28,16 @@ run 4000 200 --angles 1 --border 38
 run 10000 100 --angles 1
 run 10000 100 --angles 3
 run 10000 40 --angles 1 --img-size 35
+# round 4: the launches that keep sum w'^2 in global memory (borders 28 .. 47), the transposed strip columns, the new class boundaries
+run 4000 300 --angles 7 --border 27
+run 4000 300 --angles 7 --border 30
+run 4000 200 --angles 7 --border 34
+run 4000 150 --angles 7 --border 42
+run 4000 100 --angles 7 --border 47
+run 4000 300 --angles 3 --border 30
+run 4000 200 --angles 1 --border 42
+SID_PM_ALWAYS_GS=1 run 4000 300 --angles 7 --border 20
+SID_PM_ALWAYS_GS=1 run 4000 300 --angles 3
+SID_PM_NO_GS=1 run 4000 300 --angles 7
+echo "library md5 $(md5sum $R/sea_ice_drift_amd/libsid_pm.so | cut -d' ' -f1)" >> $OUT
 cat $OUT
