@@ -97,13 +97,14 @@ struct sid_pm_ctx {
     int samp_nflag = 0;
     // host copies of what the classification needs: the launch classes depend on the shape of image 2, so a
     // pair of another shape (select_pair / bind_pair / upload_pair after set_points) is re-classified at run()
-    std::vector<double> h_c2fg, h_r2fg, h_border;
+    std::vector<double> h_c2fg, h_r2fg, h_border, h_c1, h_r1;
     int64_t cls_rows2 = -1, cls_cols2 = -1;
     DevBuf<double> out;
     DevBuf<int32_t> out_ij;
     DevBuf<int32_t> dbg_err;            // debugging builds only (SID_PM_DEBUG_CHECK=1)
     DevBuf<uint32_t> gsii;              // row-pair kernel: sum w'^2 per placement of every resident point (PMArgs::gsii) ...
     DevBuf<uint32_t> d_goff;            // ... and the offset of every launch position's block in it (units of 64 entries)
+    DevBuf<sid::PointRec> d_rec;        // row-pair kernel: one record per launch position (index, block offset, the five inputs)
     int32_t *h_refused = nullptr;       // pinned, device-visible: valid points a launch could not hold (PMArgs::refused)
     double *user_out = nullptr;         // caller-owned result arrays (bind_results)
     int32_t *user_ij = nullptr;
@@ -294,7 +295,7 @@ int fill_args(sid_pm_ctx *ctx, sid::PMArgs &A)
     A.out = ctx->user_out ? ctx->user_out : ctx->out.p;
     A.out_ij = ctx->user_out ? ctx->user_ij : ctx->out_ij.p;
     A.refused = ctx->h_refused;
-    A.gsii = ctx->gsii.p; A.gsii_off = ctx->d_goff.p;
+    A.gsii = ctx->gsii.p; A.gsii_off = ctx->d_goff.p; A.rec = ctx->d_rec.p;
     if (getenv("SID_PM_DEBUG_CHECK")) {
         if (!ctx->dbg_err.p && ctx->dbg_err.reserve(320) == SID_PM_OK) (void)hipMemset(ctx->dbg_err.p, 0, 320 * sizeof(int32_t));
         A.dbg_err = ctx->dbg_err.p;
@@ -493,10 +494,21 @@ int classify_points(sid_pm_ctx *ctx)
         if (gsii_granules >= 0xffffffffull) return fail(SID_PM_ERR_UNSUPPORTED, "sum-of-squares scratch beyond 1 TB");
         if (int rc = ctx->gsii.reserve((size_t)std::max<uint64_t>(gsii_granules, 1) * 64)) return rc;
         if (int rc = ctx->d_goff.reserve((size_t)std::max<int64_t>(n, 1))) return rc;
+        if (int rc = ctx->d_rec.reserve((size_t)std::max<int64_t>(n, 1))) return rc;
+    }
+    std::vector<sid::PointRec> recs;
+    if (rp) {
+        const double *c1v = ctx->h_c1.data(), *r1v = ctx->h_r1.data();
+        recs.resize((size_t)n);
+        for (int64_t p = 0; p < n; ++p) {
+            const int32_t i = order[(size_t)p];
+            recs[(size_t)p] = sid::PointRec{i, goff[(size_t)p], c1v[i], r1v[i], c2fg[i], r2fg[i], border[i]};
+        }
     }
     if (n > 0) {
         HIP_TRY(hipMemcpyAsync(ctx->d_order, order.data(), sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
         if (rp) HIP_TRY(hipMemcpyAsync(ctx->d_goff.p, goff.data(), sizeof(uint32_t) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+        if (rp) HIP_TRY(hipMemcpyAsync(ctx->d_rec.p, recs.data(), sizeof(sid::PointRec) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
         HIP_TRY(hipStreamSynchronize(ctx->stream));               // `order` and `goff` are locals
     }
     if (getenv("SID_PM_VERBOSE") != nullptr)                          // the launches of a step, one line each
@@ -586,7 +598,7 @@ SID_EXPORT void sid_pm_destroy(sid_pm_ctx *ctx)
     }
     for (auto &pair : ctx->own) for (auto &b : pair) b.release();
     ctx->arena.release();
-    ctx->out.release(); ctx->out_ij.release(); ctx->dbg_err.release(); ctx->gsii.release(); ctx->d_goff.release();
+    ctx->out.release(); ctx->out_ij.release(); ctx->dbg_err.release(); ctx->gsii.release(); ctx->d_goff.release(); ctx->d_rec.release();
     if (ctx->h_refused) (void)hipHostFree(ctx->h_refused);
     delete ctx;
 }
@@ -699,6 +711,7 @@ SID_EXPORT int sid_pm_set_points(sid_pm_ctx *ctx, const double *c1, const double
     ctx->d_samp = reinterpret_cast<uint16_t *>(ctx->arena.p + o_smp);
     ctx->have_samp = !sampv.empty(); ctx->samp_nflag = nflag;
     ctx->h_c2fg.assign(c2fg, c2fg + n); ctx->h_r2fg.assign(r2fg, r2fg + n); ctx->h_border.assign(border, border + n);
+    ctx->h_c1.assign(c1, c1 + n); ctx->h_r1.assign(r1, r1 + n);
 
     ctx->user_out = nullptr; ctx->user_ij = nullptr;
     ctx->n = n; ctx->img_size = s; ctx->n_angles = K; ctx->flags = flags; ctx->rp = use_rp(s, K); ctx->rp_paired = ctx->rp ? rp_paired(K) : 0;
@@ -735,6 +748,7 @@ SID_EXPORT int sid_pm_run(sid_pm_ctx *ctx)
     for (const Bucket &b : ctx->buckets) {
         A.order = ctx->d_order + b.offset;
         A.gsii_off = ctx->d_goff.p ? ctx->d_goff.p + b.offset : nullptr;
+        A.rec = ctx->d_rec.p ? ctx->d_rec.p + b.offset : nullptr;
         A.n_launch = b.count;
         const int lds_launch = std::min(b.lds, sid::max_lds_bytes());
         A.lds_bytes = lds_launch;
@@ -912,15 +926,16 @@ SID_EXPORT int sid_pm_debug_point(sid_pm_ctx *ctx, double c1, double r1, double 
     DevBuf<float> dccm, dhes;
     DevBuf<long long> dcyc;
     DevBuf<uint32_t> dgs;                                              // row-pair kernel: this point's sum w'^2 block + its offset (0)
+    DevBuf<sid::PointRec> drec;                                        // ... and its record
     int rc = SID_PM_OK;
-    auto cleanup = [&]() { dv.release(); dang.release(); drot.release(); dout.release(); dord.release(); dgs.release();
+    auto cleanup = [&]() { dv.release(); dang.release(); drot.release(); dout.release(); dord.release(); dgs.release(); drec.release();
                            dij.release(); dshape.release(); dt.release(); dccm.release(); dhes.release(); dcyc.release(); dsamp.release(); };
     const size_t tcount = (size_t)K * s * s;
     if ((rc = dv.reserve(5)) || (rc = dang.reserve((size_t)K)) || (rc = drot.reserve(4 * (size_t)K)) ||
         (rc = dout.reserve(5)) || (rc = dord.reserve(1)) || (rc = dij.reserve(3)) || (rc = dshape.reserve(2)) ||
         (rc = dt.reserve(tcount)) || (rc = dccm.reserve((size_t)std::max<int64_t>(cap, 1))) ||
         (rc = dhes.reserve((size_t)std::max<int64_t>(cap, 1))) || (rc = dcyc.reserve(32)) ||
-        (rc = dsamp.reserve(sampv.size() + 4)) || (rc = dgs.reserve(64 + (size_t)(wh > s ? (wh - s + 1) * (ww - s + 1) : 1)))) { cleanup(); return rc; }
+        (rc = dsamp.reserve(sampv.size() + 4)) || (rc = dgs.reserve(64 + (size_t)(wh > s ? (wh - s + 1) * (ww - s + 1) : 1))) || (rc = drec.reserve(1))) { cleanup(); return rc; }
     const double v5[5] = {c1, r1, c2fg, r2fg, border};
     const int32_t zero = 0, shape0[2] = {0, 0};
     hipError_t e = hipSuccess;
@@ -932,6 +947,10 @@ SID_EXPORT int sid_pm_debug_point(sid_pm_ctx *ctx, double c1, double r1, double 
     step(hipMemcpy(drot.p, rotv.data(), sizeof(double) * rotv.size(), hipMemcpyHostToDevice));
     step(hipMemcpy(dord.p, &zero, sizeof zero, hipMemcpyHostToDevice));
     step(hipMemset(dgs.p, 0, 64 * sizeof(uint32_t)));                  // entry 0 = the offset (0 granules); the block starts at entry 64
+    {
+        const sid::PointRec r1rec{0, 0u, c1, r1, c2fg, r2fg, border};
+        step(hipMemcpy(drec.p, &r1rec, sizeof r1rec, hipMemcpyHostToDevice));
+    }
     if (!sampv.empty()) step(hipMemcpy(dsamp.p, sampv.data(), sizeof(uint16_t) * sampv.size(), hipMemcpyHostToDevice));
     step(hipMemcpy(dshape.p, shape0, sizeof shape0, hipMemcpyHostToDevice));
     step(hipMemset(dt.p, 0, tcount));
@@ -950,7 +969,7 @@ SID_EXPORT int sid_pm_debug_point(sid_pm_ctx *ctx, double c1, double r1, double 
         gauss_taps(A.gauss_w);
         A.samp = sampv.empty() ? nullptr : dsamp.p; A.samp_nflag = nflag;
         A.lds_bytes = lds;
-        A.gsii = dgs.p + 64; A.gsii_off = dgs.p;
+        A.gsii = dgs.p + 64; A.gsii_off = dgs.p; A.rec = drec.p;
         step((hipError_t)(rp ? sid::launch_pm_rp(A, lds, 256, 4, rpp, 0, 3, ctx->stream)
                                        : sid::launch_pm_mfma(A, lds, 256, 4, use_paired(K), ctx->stream)));
         step(hipStreamSynchronize(ctx->stream));

@@ -6,6 +6,11 @@ namespace sid {
 
 constexpr int kMaxAngles = 64;
 
+// Row-pair kernel: everything a workgroup needs to know about its point in ONE record per launch position - the point's index,
+// the offset of its sum w'^2 block (PMArgs::gsii, units of 64 entries) and its five input values - so that the prologue
+// waits for one memory round trip (launch position -> record) instead of two (position -> index -> five vectors).
+struct PointRec { int32_t pt; uint32_t gsii_off; double c1, r1, c2fg, r2fg, border; };
+
 // Arguments of one launch (one block per grid point of this launch).
 struct PMArgs {
     const uint8_t *img1; int64_t rows1, cols1, stride1;
@@ -38,6 +43,7 @@ struct PMArgs {
     // only and stays in L2 in between.
     uint32_t *gsii;
     const uint32_t *gsii_off;
+    const PointRec *rec;                            // [n_launch] row-pair kernel: one record per launch position (above)
     // diagnostics (debug_point only; null in production launches)
     uint8_t *dbg_templates; float *dbg_ccm; float *dbg_hes; int32_t *dbg_shape; int64_t dbg_cap;
     long long *dbg_cycles;                          // [32] shader-clock stamps at phase boundaries
