@@ -708,6 +708,13 @@ def main(argv=None):
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
 
+    # stdout carries ONE JSON line: whatever libraries print there - gloo's connection lines at init_process_group, RCCL's
+    # version banner (flushed when the process ends), progress lines of host code - goes to stderr for the whole life of
+    # the process; the line itself is written to the saved descriptor
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     import torch.distributed as dist
     if not torch.cuda.is_available():
@@ -726,22 +733,12 @@ def main(argv=None):
         # RCCL cannot put two ranks on one device: the dry run on a smaller box uses gloo for the collectives
         dist.init_process_group('gloo' if shared else 'nccl', **({} if shared else {'device_id': dev}))
     fn = {'stream': stream_mode, 'ftpm': ftpm_mode}.get(args.mode, grid_mode)
-    # stdout carries ONE JSON line: whatever libraries print there meanwhile (RCCL's version banner at the first
-    # collective, progress lines of host code) is sent to stderr
-    sys.stdout.flush()
-    saved_stdout = os.dup(1)
-    os.dup2(2, 1)
-    try:
-        line = fn(args, torch, dist, dev, world, rank, local_dev)
-    finally:
-        sys.stdout.flush()
-        os.dup2(saved_stdout, 1)
-        os.close(saved_stdout)
+    line = fn(args, torch, dist, dev, world, rank, local_dev)
     if rank == 0 and line is not None:
         if world > 1 and dist.get_backend() == 'gloo':
             line['config']['parallelism'] += ' [DRY RUN: %d ranks share %d device(s), gloo collectives]' % (
                 world, torch.cuda.device_count())
-        print(json.dumps(line))
+        os.write(real_stdout, (json.dumps(line) + '\n').encode())
     if world > 1 or args.force_collective:
         dist.barrier()
         dist.destroy_process_group()

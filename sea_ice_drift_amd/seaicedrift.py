@@ -43,8 +43,9 @@ class SeaIceDrift(object):
         worker thread: whatever the caller does before ``get_drift_PM`` runs beside the triangulation, and the call picks
         the result up when its points are bit-identical (otherwise it triangulates as before).  Results are unchanged."""
         try:
+            import os
             import numpy as np
-            if len(lon1) < 4:
+            if len(lon1) < 4 or os.environ.get('SID_NO_TRI_PREFETCH'):   # (the switch: A/B runs)
                 return
             x1, y1 = self.n1.transform_points(lon1, lat1, 1)             # get_drift_PM (seaicedrift.py:85)
             lon, lat = self.n1.transform_points(x1, y1)                  # prepare_first_guess (pmlib.py:280-282)

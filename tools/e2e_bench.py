@@ -20,8 +20,12 @@ lon, lat = n1.transform_points(cg.ravel(), rg.ravel(), 0)
 lon, lat = lon.reshape(cg.shape), lat.reshape(cg.shape)
 angles = list(range(-7, 8))
 
-def timed(label, fn):
-    t0 = time.perf_counter(); out = fn(); return out, time.perf_counter() - t0
+def timed(label, fn, reps=3):
+    """Best of `reps` runs (the boxes' hosts are noisy: single shots of a 50 ms call scatter by 30 %)."""
+    best, out = 1e9, None
+    for _ in range(reps):
+        t0 = time.perf_counter(); out = fn(); best = min(best, time.perf_counter() - t0)
+    return out, best
 
 with contextlib.redirect_stdout(io.StringIO()):
     pmlib.pattern_matching(lon, lat, n1, c1, r1, n2, c2, r2, img_size=34, angles=angles)   # warm-up (library load)
@@ -37,7 +41,7 @@ u, v = full[0], full[1]
 ok = np.isfinite(u)
 tdc, tdr = syn.true_displacement(cg, rg)
 err = np.hypot(u[ok] - tdc[ok], v[ok] - tdr[ok])
-print(json.dumps({'metric': 'pattern_matching end to end, 200x200 grid on a 10000x10000 pair, K=15, %d FT points' % nkp,
+print(json.dumps({'metric': 'pattern_matching end to end, 200x200 grid on a 10000x10000 pair, K=15, %d FT points (best of 3 runs each)' % nkp,
                   'valid_points': int(ok.sum()), 'total_s': t_full, 'prelude_s': t_pre, 'total_s_first_guess_on_host': t_full_host, 'prelude_s_first_guess_on_host': t_pre_host,
                   'dispatch_s_incl_200MB_upload_and_context': t_disp, 'postlude_s': t_post,
                   'grid_points_per_s_end_to_end': float(ok.sum()) / t_full,
