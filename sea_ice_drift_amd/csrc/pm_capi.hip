@@ -51,7 +51,7 @@ struct Image {
     int64_t rows = 0, cols = 0, stride = 0;
 };
 
-struct Bucket { int offset, count, lds, band, pitch, occ; };   // occ: wavefronts per SIMD of the kernel build (3; 4: the four-per-CU class of the slot-group layouts); band: output rows per sweep work item of this launch (4 or 8); pitch: compile-time window pitch of the row-pair kernel (0: run-time)
+struct Bucket { int offset, count, lds, band, pitch, occ; uint32_t gs_stride = 0; };   // gs_stride: largest sum w'^2 block of the launch's points, in u32 entries (gs launches; 0 otherwise)   // occ: wavefronts per SIMD of the kernel build (3; 4: the four-per-CU class of the slot-group layouts); band: output rows per sweep work item of this launch (4 or 8); pitch: compile-time window pitch of the row-pair kernel (0: run-time)
 
 template <typename T>
 struct DevBuf {
@@ -105,6 +105,7 @@ struct sid_pm_ctx {
     DevBuf<uint32_t> gsii;              // row-pair kernel: sum w'^2 per placement of every resident point (PMArgs::gsii) ...
     DevBuf<uint32_t> d_goff;            // ... and the offset of every launch position's block in it (units of 64 entries)
     DevBuf<sid::PointRec> d_rec;        // row-pair kernel: one record per launch position (index, block offset, the five inputs)
+    DevBuf<uint32_t> gs_pool;           // pool of sum w'^2 blocks indexed by where a workgroup runs (PMArgs::gs_pool)
     int32_t *h_refused = nullptr;       // pinned, device-visible: valid points a launch could not hold (PMArgs::refused)
     double *user_out = nullptr;         // caller-owned result arrays (bind_results)
     int32_t *user_ij = nullptr;
@@ -296,6 +297,7 @@ int fill_args(sid_pm_ctx *ctx, sid::PMArgs &A)
     A.out_ij = ctx->user_out ? ctx->user_ij : ctx->out_ij.p;
     A.refused = ctx->h_refused;
     A.gsii = ctx->gsii.p; A.gsii_off = ctx->d_goff.p; A.rec = ctx->d_rec.p;
+    A.gs_pool = ctx->gs_pool.p; A.gs_pool_stride = 0;
     if (getenv("SID_PM_DEBUG_CHECK")) {
         if (!ctx->dbg_err.p && ctx->dbg_err.reserve(320) == SID_PM_OK) (void)hipMemset(ctx->dbg_err.p, 0, 320 * sizeof(int32_t));
         A.dbg_err = ctx->dbg_err.p;
@@ -471,6 +473,11 @@ int classify_points(sid_pm_ctx *ctx)
         Bucket &bk = ctx->buckets.back();
         bk.count += (int)src->size();
         bk.lds = std::max(bk.lds, lds_run);
+        if (rp && first.gs)                                           // (launches that keep sum w'^2 in global memory: the largest block)
+            for (size_t i = a; i < b; ++i) {
+                const Shape &sh = shapes[(size_t)ord[i]];
+                if (sh.wh > 0) bk.gs_stride = std::max<uint32_t>(bk.gs_stride, (uint32_t)(((sh.wh - s + 1) * (sh.ww - s + 1) * 4 + 255) / 256 * 64));
+            }
         constexpr int64_t kXcd = 8;
         const int64_t L = (int64_t)src->size(), m = (L + kXcd - 1) / kXcd;
         if (!no_xcd && L >= 4 * kXcd) {
@@ -495,6 +502,13 @@ int classify_points(sid_pm_ctx *ctx)
         if (int rc = ctx->gsii.reserve((size_t)std::max<uint64_t>(gsii_granules, 1) * 64)) return rc;
         if (int rc = ctx->d_goff.reserve((size_t)std::max<int64_t>(n, 1))) return rc;
         if (int rc = ctx->d_rec.reserve((size_t)std::max<int64_t>(n, 1))) return rc;
+        // pool of blocks indexed by where a workgroup runs (SID_PM_NO_GS_POOL=1: exclusive blocks only - A/B runs): 8 XCDs x
+        // kGsPoolSlots slots of the largest block of any gs launch
+        uint32_t stride_max = 0;
+        for (const Bucket &bk : ctx->buckets) stride_max = std::max(stride_max, bk.gs_stride);
+        if (stride_max && getenv("SID_PM_NO_GS_POOL") == nullptr) {
+            if (int rc = ctx->gs_pool.reserve((size_t)8 * sid::kGsPoolSlots * stride_max)) return rc;
+        } else if (getenv("SID_PM_NO_GS_POOL") != nullptr) { ctx->gs_pool.release(); }
     }
     std::vector<sid::PointRec> recs;
     if (rp) {
@@ -598,7 +612,7 @@ SID_EXPORT void sid_pm_destroy(sid_pm_ctx *ctx)
     }
     for (auto &pair : ctx->own) for (auto &b : pair) b.release();
     ctx->arena.release();
-    ctx->out.release(); ctx->out_ij.release(); ctx->dbg_err.release(); ctx->gsii.release(); ctx->d_goff.release(); ctx->d_rec.release();
+    ctx->out.release(); ctx->out_ij.release(); ctx->dbg_err.release(); ctx->gsii.release(); ctx->d_goff.release(); ctx->d_rec.release(); ctx->gs_pool.release();
     if (ctx->h_refused) (void)hipHostFree(ctx->h_refused);
     delete ctx;
 }
@@ -749,6 +763,7 @@ SID_EXPORT int sid_pm_run(sid_pm_ctx *ctx)
         A.order = ctx->d_order + b.offset;
         A.gsii_off = ctx->d_goff.p ? ctx->d_goff.p + b.offset : nullptr;
         A.rec = ctx->d_rec.p ? ctx->d_rec.p + b.offset : nullptr;
+        A.gs_pool_stride = ctx->gs_pool.p ? b.gs_stride : 0u;
         A.n_launch = b.count;
         const int lds_launch = std::min(b.lds, sid::max_lds_bytes());
         A.lds_bytes = lds_launch;

@@ -44,6 +44,15 @@ struct PMArgs {
     uint32_t *gsii;
     const uint32_t *gsii_off;
     const PointRec *rec;                            // [n_launch] row-pair kernel: one record per launch position (above)
+    // Pool of sum w'^2 blocks indexed by WHERE the workgroup runs (round 4): slot = (XCD, CU of the XCD, which of the CU's
+    // LDS allocations) - read from the hardware registers XCC_ID, HW_ID and LDS_ALLOC, no atomics - so that the 768 blocks in
+    // flight are always the same 768 and stay in their XCD's L2, instead of 175 MB of write-once blocks travelling to HBM and
+    // back every step.  Two co-resident workgroups never share a slot (they cannot share an LDS allocation of one CU:
+    // tools/ubench/resident_slot.hip, 0 collisions in 8 x 10^4 workgroups), and a slot is only ever touched through ONE XCD's L2
+    // (the eight L2s are not coherent with each other inside a kernel).  gs_pool_stride = 0: no pool - the exclusive block of
+    // the launch position (gsii_off), which is also what a workgroup uses whose registers read unexpectedly.
+    uint32_t *gs_pool;                              // [8 XCDs][kGsPoolSlots][gs_pool_stride]
+    uint32_t gs_pool_stride;                        // u32 entries per slot in this launch (the largest block of its points, 256-byte granules)
     // diagnostics (debug_point only; null in production launches)
     uint8_t *dbg_templates; float *dbg_ccm; float *dbg_hes; int32_t *dbg_shape; int64_t dbg_cap;
     long long *dbg_cycles;                          // [32] shader-clock stamps at phase boundaries
@@ -56,6 +65,7 @@ __host__ __device__ inline int round_up(int v, int m) { return (v + m - 1) / m *
 constexpr int kMiscMfmaBytes = 2688;
 constexpr int kTrowPad = 36;         // zero rows around a winner operand block: 16 above, 20 below (the step loop runs in fours)
 constexpr int kQueueCap = 192;       // arg-max candidates waiting for exact evaluation (16 B each)
+constexpr int kGsPoolSlots = 128;    // slots per XCD in the pool of sum w'^2 blocks: 32 CUs x 4 LDS allocations
 constexpr int kRpQueueWithSi = 128;  // ... and the sums kept for the winner (RpLdsLayout::si_off) leave it at least this
 constexpr int kRpQueueMin = 64;      // row-pair kernel: the queue shrinks to this where it decides the residency class (overflow is evaluated in place)
 

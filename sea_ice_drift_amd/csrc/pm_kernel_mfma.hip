@@ -446,10 +446,13 @@ __device__ __forceinline__ void take_better(Score &sc, float rv, int key)
 // ---------------------------------------------------------------------------------------------
 // PATCH: the image-1 patch (ph_patch's fast path; the caller checked that it lies inside image 1 and that its LDS
 // region is free already) is fetched in the same round trip: its loads are issued before the window's.
-template <bool PATCH>
+// PRIO >= 0: the wave priority of the phases up to the sweep, set here - inside a non-inlined phase - rather than in the kernel
+// body (pm_kernel_rp.inc: SID_SETPRIO_TS)
+template <bool PATCH, int PRIO = -1>
 __device__ __noinline__ void ph_window_t(const uint8_t *img2, long long rows2, long long cols2, long long stride2,
                                          const uint8_t *img1, long long rows1, long long cols1, long long stride1)
 {
+    if (PRIO >= 0) __builtin_amdgcn_s_setprio(PRIO);
     SID_PHASE_LOCALS;
     constexpr int kPat = 4;                                            // patch dwords per thread and trip (ph_patch)
     u32 plo[kPat] = {}, phi[kPat] = {}, psh[kPat] = {};
@@ -1367,9 +1370,11 @@ __device__ __noinline__ void ph_winner(int ka, long long *dbg_cycles)
 // Phase 5: Hessian at the peak (pmlib.py:36-59, :167) and the optional MCC normalisation.
 // hes aliases sii.  Returns h, r in m->red_f[0..1].
 // ---------------------------------------------------------------------------------------------
+template <int PRIO = -1>
 __device__ __noinline__ void ph_hessian(unsigned flags, int iy, int ix, float best_r, float *dbg_ccm, float *dbg_hes,
                                         long long dbg_cap, long long *dbg_cycles)
 {
+    if (PRIO >= 0) __builtin_amdgcn_s_setprio(PRIO);
     SID_PHASE_LOCALS;
     float *hes = reinterpret_cast<float *>(smem + G.hes_off);
     const float *ccm = reinterpret_cast<const float *>(smem + G.ccm_off);
@@ -1562,9 +1567,11 @@ __device__ __forceinline__ u32 hes_bucket(u32 bits)
 // compacted and ranked by wavefront 0, which also forms the result.  Buckets too full for the list (massive ties, flat
 // matrices, magnitudes below 2^-15) fall back to the radix select.
 // ---------------------------------------------------------------------------------------------
+template <int PRIO = -1>
 __device__ __noinline__ void ph_hessian_fast(unsigned flags, int iy, int ix, float best_r, float *dbg_ccm, float *dbg_hes,
                                              long long dbg_cap, long long *dbg_cycles)
 {
+    if (PRIO >= 0) __builtin_amdgcn_s_setprio(PRIO);
     SID_PHASE_LOCALS;
     float *hes = reinterpret_cast<float *>(smem + G.hes_off);
     const float *ccm = reinterpret_cast<const float *>(smem + G.ccm_off);
@@ -1871,7 +1878,7 @@ __global__ __launch_bounds__(BAND == 8 ? 512 : kMaxBlockM, BAND == 8 ? 2 : kOccM
     SID_STAMP(6);
     if (A.dbg_shape && tid == 0) { A.dbg_shape[0] = rh; A.dbg_shape[1] = rw; }
 #ifndef SID_ABLATE_HESSIAN
-    ph_hessian(A.flags, iy, ix, best_r, A.dbg_ccm, A.dbg_hes, A.dbg_cap, A.dbg_cycles);
+    ph_hessian<>(A.flags, iy, ix, best_r, A.dbg_ccm, A.dbg_hes, A.dbg_cap, A.dbg_cycles);
 #endif
     SID_STAMP(7);
     if (tid == 0) {
