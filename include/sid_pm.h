@@ -168,8 +168,8 @@ int sid_pm_work_info(sid_pm_ctx *ctx, double info[6]);
 int sid_pm_estimate_cost(const double *border, int64_t n, int img_size, int n_angles, double *cost_ns);
 /* Launch class of a point of that border: low four bits = workgroups per CU (1 .. 4) of its launch - a launch has 256 x that
  * many points in flight, which prices the tail of a short launch when the points are cut into shards -, + 16 when the point
- * runs in the launches that keep the per-placement sum of squares in global memory (round 4).  Points of equal value share a
- * launch.  Host arithmetic as well.                                                                                     */
+ * runs in the launches that keep the per-placement sum of squares in global memory (round 4), + 32 for the launch of the search
+ * borders beyond 68 px, whose other per-placement tables live there as well.  Points of equal value share a launch.  Host arithmetic as well.                                                                                     */
 int sid_pm_estimate_residency(const double *border, int64_t n, int img_size, int n_angles, int32_t *per_cu);
 
 /* ---- diagnostics used by the parity tests ---- */

@@ -51,7 +51,7 @@ struct Image {
     int64_t rows = 0, cols = 0, stride = 0;
 };
 
-struct Bucket { int offset, count, lds, band, pitch, occ; uint32_t gs_stride = 0; };   // gs_stride: largest sum w'^2 block of the launch's points, in u32 entries (gs launches; 0 otherwise)   // occ: wavefronts per SIMD of the kernel build (3; 4: the four-per-CU class of the slot-group layouts); band: output rows per sweep work item of this launch (4 or 8); pitch: compile-time window pitch of the row-pair kernel (0: run-time)
+struct Bucket { int offset, count, lds, band, pitch, occ; uint32_t gs_stride = 0; bool big = false; };   // gs_stride: largest sum w'^2 block of the launch's points, in u32 entries (gs launches; 0 otherwise)   // occ: wavefronts per SIMD of the kernel build (3; 4: the four-per-CU class of the slot-group layouts); band: output rows per sweep work item of this launch (4 or 8); pitch: compile-time window pitch of the row-pair kernel (0: run-time)
 
 template <typename T>
 struct DevBuf {
@@ -260,6 +260,12 @@ int lds_need(bool rp, int rpp, int wh, int ww, int s, int K, uint32_t flags, int
     return sid::mfma_lds_layout(wh, ww, s, band, use_paired(K) && band == 4).total;
 }
 
+// big layouts (rp_lds_layout): every per-placement table in the point's block of global memory; always the full-table 4-row kernel
+sid::RpLdsLayout big_layout(int wh, int ww, int s, int K, uint32_t flags)
+{
+    return sid::rp_lds_layout(wh, ww, s, K <= sid::kRpGroup, 4, 0, 512, rp_own_hes(K, flags), true, true);
+}
+
 int check_sweep(int img_size, const double *angles, int n_angles, uint32_t flags)
 {
     if (!angles || n_angles < 1)
@@ -267,7 +273,7 @@ int check_sweep(int img_size, const double *angles, int n_angles, uint32_t flags
                                     "leaves best_result undefined for an empty list)");
     if (n_angles > sid::kMaxAngles) return fail(SID_PM_ERR_UNSUPPORTED, "more than %d angles", sid::kMaxAngles);
     if (!sid::mfma_img_size_supported(img_size))
-        return fail(SID_PM_ERR_UNSUPPORTED, "img_size=%d: the kernel supports 2..49", img_size);
+        return fail(SID_PM_ERR_UNSUPPORTED, "img_size=%d: the kernel supports 2..64", img_size);
     if (flags & ~(SID_PM_HES_NORM | SID_PM_HES_SMTH | SID_PM_MCC_NORM)) return fail(SID_PM_ERR_ARG, "unknown flag bits");
     return SID_PM_OK;
 }
@@ -309,7 +315,7 @@ int fill_args(sid_pm_ctx *ctx, sid::PMArgs &A)
 // kernel - whether sum w'^2 per placement lives in global memory (gs).  gs costs ~5 % where it changes nothing and buys
 // -10 .. -17 % where its smaller footprint lifts the shape into the next residency class, so it is chosen exactly there;
 // and wherever only a gs instantiation exists (window pitch above 112, the 8-row-band kernel, the run-time pitch).
-struct ShapeClass { bool gs; int band, cls, lds, nat_pitch; };
+struct ShapeClass { bool gs; int band, cls, lds, nat_pitch; bool big = false; };   // big: cls 0, a launch of its own (one workgroup per CU)
 ShapeClass shape_class(bool rp, int rpp, int wh, int ww, int s, int K, uint32_t flags, bool band8_ok, bool force_gs)
 {
     auto eval = [&](bool gs) {
@@ -328,6 +334,10 @@ ShapeClass shape_class(bool rp, int rpp, int wh, int ww, int s, int K, uint32_t 
     if (!rp) return eval(false);
     ShapeClass g = eval(true);
     g.cls = std::min(g.cls, 3);                                        // (no four-per-CU build with gs: see below)
+    if (g.lds > sid::max_lds_bytes() && getenv("SID_PM_NO_BIG") == nullptr) {   // beyond the LDS even so: the tables go to global memory
+        const sid::RpLdsLayout B = big_layout(wh, ww, s, K, flags);
+        if (B.total <= sid::max_lds_bytes()) return ShapeClass{true, 4, 0, B.total, B.wpitch, true};
+    }
     if (force_gs || getenv("SID_PM_ALWAYS_GS") != nullptr) return g;
     const ShapeClass l = eval(false);
     if (l.band == 8 || l.nat_pitch > 112 || l.lds > sid::max_lds_bytes()) return g;   // (no instantiation without gs)
@@ -354,7 +364,7 @@ int classify_points(sid_pm_ctx *ctx)
     static const bool no_fixed_pitch = getenv("SID_PM_NO_FIXED_PITCH") != nullptr;         // (run-time pitch everywhere: gs instantiations; A/B runs)
     // Everything the launch needs to know about a point follows from the SHAPE of its search window, and a run has a few
     // dozen shapes (one per border): the LDS layouts are evaluated per shape, the points are only binned.
-    struct Shape { int wh, ww, lds, band, cls, nat_pitch, pitch; double work; std::vector<int32_t> idx; bool gs = false; };
+    struct Shape { int wh, ww, lds, band, cls, nat_pitch, pitch; double work; std::vector<int32_t> idx; bool gs = false, big = false; };
     std::vector<Shape> shapes;
     std::vector<int32_t> slot_of((size_t)1 << 16, -1);                // (wh, ww) -> shape, direct-mapped on a hash of the pair
     auto find_shape = [&](int wh, int ww) -> int {
@@ -373,11 +383,10 @@ int classify_points(sid_pm_ctx *ctx)
     }
     double macs = 0, bytes = 0, valid = 0;
     int lds_max = lds_min;
-    std::vector<uint32_t> npos_of((size_t)n, 0u);                     // placements of every point (0: NaN point)
+    std::vector<uint32_t> gran_of((size_t)n, 0u);                     // 256-byte granules of every point's block of global memory (row-pair kernel; 0: NaN point)
     for (int64_t i = 0; i < n; ++i) {
         int wh = 0, ww = 0;
         if (!window_dims(c2fg[i], r2fg[i], border[i], s, rows2, cols2, wh, ww)) { shapes[0].idx.push_back((int32_t)i); continue; }
-        npos_of[(size_t)i] = (uint32_t)((wh - s + 1) * (ww - s + 1));
         int k = find_shape(wh, ww);
         if (k < 0) {
             Shape sh{wh, ww, 0, 4, 0, 0, 0, 0.0, {}};
@@ -385,13 +394,14 @@ int classify_points(sid_pm_ctx *ctx)
             if (sc.lds > sid::max_lds_bytes())
                 return fail(SID_PM_ERR_UNSUPPORTED, "point %lld: search window %dx%d needs %d bytes of LDS (> %d)",
                             (long long)i, wh, ww, sc.lds, sid::max_lds_bytes());
-            sh.lds = sc.lds; sh.band = sc.band; sh.cls = sc.cls; sh.gs = sc.gs; sh.nat_pitch = sc.nat_pitch;
+            sh.lds = sc.lds; sh.band = sc.band; sh.cls = sc.cls; sh.gs = sc.gs; sh.nat_pitch = sc.nat_pitch; sh.big = sc.big;
             sh.work = (double)(wh - s + 1) * (double)(ww - s + 1);
             k = (int)shapes.size();
             shapes.push_back(sh);
         }
         Shape &sh = shapes[(size_t)k];
         sh.idx.push_back((int32_t)i);
+        gran_of[(size_t)i] = sh.big ? (uint32_t)(big_layout(wh, ww, s, K, flags).big_bytes / 256) : ((uint32_t)((wh - s + 1) * (ww - s + 1)) * 4u + 255u) / 256u;
         macs += (double)K * sh.work * s * s;
         // window + bounding box of the rotated template + 5 inputs + outputs
         bytes += (double)wh * ww + 51.0 * 51.0 + 40.0 + 52.0;
@@ -422,7 +432,7 @@ int classify_points(sid_pm_ctx *ctx)
             const bool gs = first.gs;
             int nat = gs ? 136 : 0;
             for (size_t i = a; i < b; ++i) nat = std::max(nat, shapes[(size_t)ord[i]].nat_pitch);
-            int pitch = (nat > 0 && !no_fixed_pitch) ? sid::rp_class_pitch(nat) : 0;
+            int pitch = (nat > 0 && !no_fixed_pitch && !first.big) ? sid::rp_class_pitch(nat) : 0;
             if (pitch && !sid::rp_pitch_instantiated(first.band, rpp, pitch)) pitch = 0;
             for (size_t i = a; i < b && pitch; ++i) {
                 const Shape &sh = shapes[(size_t)ord[i]];
@@ -434,7 +444,7 @@ int classify_points(sid_pm_ctx *ctx)
             for (size_t i = a; i < b; ++i) {
                 Shape &sh = shapes[(size_t)ord[i]];
                 sh.pitch = pitch; sh.gs = gs_now;
-                if (sh.wh > 0) sh.lds = lds_need(rp, rpp, sh.wh, sh.ww, s, K, flags, sh.band, pitch, gs_now);
+                if (sh.wh > 0 && !sh.big) sh.lds = lds_need(rp, rpp, sh.wh, sh.ww, s, K, flags, sh.band, pitch, gs_now);
             }
             a = b;
         }
@@ -471,12 +481,14 @@ int classify_points(sid_pm_ctx *ctx)
                                           (rp && first.cls >= 4 && sid::rp_pitch_instantiated(first.band, rpp, first.pitch, 4)) ? 4 : 3});
         ctx->info[5] = (double)first.cls;                             // (class of the bucket being filled)
         Bucket &bk = ctx->buckets.back();
+        bk.big = first.big;
         bk.count += (int)src->size();
         bk.lds = std::max(bk.lds, lds_run);
         if (rp && first.gs)                                           // (launches that keep sum w'^2 in global memory: the largest block)
             for (size_t i = a; i < b; ++i) {
                 const Shape &sh = shapes[(size_t)ord[i]];
-                if (sh.wh > 0) bk.gs_stride = std::max<uint32_t>(bk.gs_stride, (uint32_t)(((sh.wh - s + 1) * (sh.ww - s + 1) * 4 + 255) / 256 * 64));
+                if (sh.wh > 0) bk.gs_stride = std::max<uint32_t>(bk.gs_stride, sh.big ? (uint32_t)(big_layout(sh.wh, sh.ww, s, K, flags).big_bytes / 4)
+                                                                                      : (uint32_t)(((sh.wh - s + 1) * (sh.ww - s + 1) * 4 + 255) / 256 * 64));
             }
         constexpr int64_t kXcd = 8;
         const int64_t L = (int64_t)src->size(), m = (L + kXcd - 1) / kXcd;
@@ -496,7 +508,7 @@ int classify_points(sid_pm_ctx *ctx)
         goff.resize((size_t)n);
         for (int64_t p = 0; p < n; ++p) {
             goff[(size_t)p] = (uint32_t)gsii_granules;
-            gsii_granules += (npos_of[(size_t)order[(size_t)p]] * 4u + 255u) / 256u;
+            gsii_granules += gran_of[(size_t)order[(size_t)p]];
         }
         if (gsii_granules >= 0xffffffffull) return fail(SID_PM_ERR_UNSUPPORTED, "sum-of-squares scratch beyond 1 TB");
         if (int rc = ctx->gsii.reserve((size_t)std::max<uint64_t>(gsii_granules, 1) * 64)) return rc;
@@ -774,7 +786,7 @@ SID_EXPORT int sid_pm_run(sid_pm_ctx *ctx)
         const int per_cu = std::max(1, std::min(b.band == 8 ? 2 : 8, blocks_per_cu(b.lds)));
         const int nthreads = b.band == 8 ? 256 : (per_cu == 1 ? 768 : 256);
         const int e = ctx->rp
-                          ? sid::launch_pm_rp(A, lds_launch, nthreads, b.band, ctx->rp_paired, b.pitch, b.occ, ctx->stream)
+                          ? sid::launch_pm_rp(A, lds_launch, nthreads, b.band, b.big ? 0 : ctx->rp_paired, b.pitch, b.occ, ctx->stream, b.big)
                           : sid::launch_pm_mfma(A, lds_launch, nthreads, b.band, use_paired(ctx->n_angles), ctx->stream);
         if (e != 0) return fail(SID_PM_ERR_HIP, "kernel launch failed: %s", hipGetErrorString((hipError_t)e));
     }
@@ -1081,6 +1093,7 @@ static int estimate_points(const double *border, int64_t n, int img_size, int n_
                                 {3.9853e-3, 1.7996e-2, 7.6297e-3, 25.686, 1.2348, 1.3287, 0.99236, 0.95706},
                                 {2.5923e-3, 1.8513e-2, 6.4734e-3, 24.173, 1.2518, 1.3574, 1.00890, 0.98625}};
     const Fit &F = kFit[rpp];
+    constexpr double kBigFactor = 1.25;   // every per-placement table through L2 / HBM (measured at borders 70 .. 100: tools/border_cost.py)
     const double kSweep = F.sweep, kWinner = F.winner, kPos = F.pos, kFixed = F.fixed, kTwoPerCu = F.two, kOnePerCu = F.one, kFourPerCu = F.four;
     for (int64_t i = 0; i < n; ++i) {
         const double b = border[i];
@@ -1094,16 +1107,16 @@ static int estimate_points(const double *border, int64_t n, int img_size, int n_
             static const bool no_band8 = getenv("SID_PM_NO_BAND8") != nullptr;
             const ShapeClass sc = shape_class(rp, rpp, wn, wn, s, K, 0, sid::mfma_band8_supported(s) && !no_band8 && !rpp, false);
             const sid::RpLdsLayout L4 = sid::rp_lds_layout(wn, wn, s, K <= sid::kRpGroup, rp_rows(rpp, 4), 0, sid::rp_tab_pitch(rpp), rp_own_hes(K, 0), sc.gs);
-            const int per_cu = sc.cls, band = sc.band;
-            const int rows = rp_rows(rpp, band), nb = (r + rows - 1) / rows, tiles = 2 * L4.npair + L4.nsingle;
+            const int per_cu = std::max(1, sc.cls), band = sc.band;            // (big layouts - class 0 - run one workgroup per CU, full table)
+            const int rows = sc.big ? 4 : rp_rows(rpp, band), nb = (r + rows - 1) / rows, tiles = 2 * L4.npair + L4.nsingle;
             const double per_row_tile = (double)((s + 1) / 2 + s / 2 + 1) / 2.0 + (double)(((s - 32 + 1) / 2) * 2);
             // work items are dealt to the wavefronts of the workgroup: the busiest wavefront sets the pace
             const int nwaves = per_cu == 1 ? 12 : 4;
             const int units = ((nb * tiles + nwaves - 1) / nwaves) * nwaves, wunits = ((((r + 15) / 16) * tiles + nwaves - 1) / nwaves) * nwaves;
-            sweep = groups * (rpp == 2 ? 0.33 : rpp == 1 ? 0.55 : 1.0) * units * (rows * per_row_tile + 2.0);
+            sweep = groups * (sc.big ? 1.0 : rpp == 2 ? 0.33 : rpp == 1 ? 0.55 : 1.0) * units * (rows * per_row_tile + 2.0);
             winner = wunits * 76.0;
-            cls_factor = ((per_cu >= 4 && max_per_cu(rp, rpp) == 4) ? kFourPerCu : per_cu >= 3 ? 1.0 : per_cu == 2 ? kTwoPerCu : kOnePerCu) * (sc.gs ? F.gs : 1.0);
-            cls = std::max(1, std::min(per_cu, max_per_cu(rp, rpp))) + (sc.gs ? 16 : 0);   // (+ 16: the launches that keep sum w'^2 in global memory are launches of their own)
+            cls_factor = ((per_cu >= 4 && max_per_cu(rp, rpp) == 4) ? kFourPerCu : per_cu >= 3 ? 1.0 : per_cu == 2 ? kTwoPerCu : kOnePerCu) * (sc.gs ? F.gs : 1.0) * (sc.big ? kBigFactor : 1.0);
+            cls = std::max(1, std::min(per_cu, max_per_cu(rp, rpp))) + (sc.gs ? 16 : 0) + (sc.big ? 32 : 0);   // (+ 16: the launches that keep sum w'^2 in global memory are launches of their own)
         } else {
             const sid::MfmaLdsLayout L = sid::mfma_lds_layout(wn, wn, s, 4, use_paired(K));
             const int per_cu = blocks_per_cu(L.total), ntx = (r + 15) / 16;

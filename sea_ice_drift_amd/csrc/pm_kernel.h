@@ -143,6 +143,7 @@ struct RpLdsLayout {
     int patch_off, ppitch, pdim, pradius, queue_off, trow_bytes;
     int queue_cap;              // candidate-queue entries (16 B each): kRpQueueMin .. kQueueCap, as many as the residency class leaves room for
     int npair, nsingle;         // x tiling of a band: npair items of 32 placements, then nsingle (0/1) of 16
+    int big_bytes;              // big layouts (below): bytes of the point's block of global memory; 0 otherwise
     int total;
 };
 
@@ -183,10 +184,15 @@ __host__ __device__ constexpr int rp_tab_shift(int paired) { return paired == 2 
 // hes_smth / mcc_norm, several groups of angles - keeps its histograms in the winner's operand block); otherwise they lie
 // over the window and the winner's operands, both dead by then (the NCC matrix moves up where those are too short).
 __host__ __device__ constexpr bool rp_pitch_is_gs(int pitch) { return pitch == 0 || pitch >= 136; }
+// big (gs only; search borders 69 .. ~100 at s = 34, whose per-placement tables no longer fit the 160 KB): the row sums of
+// rp_sums, the NCC matrix of the winning angle and the Hessian magnitudes live in the point's block of GLOBAL memory as well
+// - [sum w'^2 | row sums, later the NCC matrix | Hessian magnitudes], 256-byte aligned; ccm_off / hes_off are byte offsets
+// into that block - and LDS holds the window, the sweep's operands and the winner's operands + histogram only.
 __host__ __device__ inline RpLdsLayout rp_lds_layout(int wh, int ww, int s, bool one_group, int band = 4, int force_pitch = 0,
-                                                     int tab_pitch = 512, bool own_hes = false, bool gs = true)
+                                                     int tab_pitch = 512, bool own_hes = false, bool gs = true, bool big = false)
 {
     RpLdsLayout L;
+    L.big_bytes = 0;
     const int rh = wh - s + 1, rw = ww - s + 1;
     const int nE = (s + 1) / 2, nO = s / 2 + 1, nst = (nE > nO ? nE : nO) + band / 2 - 1;
     const int rem = rw % 32;
@@ -239,13 +245,18 @@ __host__ __device__ inline RpLdsLayout rp_lds_layout(int wh, int ww, int s, bool
         // are - with one group of angles the patch is dead by then and they lie over it, like the queue -, overwritten by
         // the winner's NCC matrix)
         L.wp_off = round_up(L.queue_off + cap * 16, 16);
-        int u = wh * rw * 4;                                     // row sums of w'^2 (rp_sums)
+        int u = big ? 0 : wh * rw * 4;                           // row sums of w'^2 (rp_sums)
         const int sweep = L.wp_off + L.wp_rows * L.wp_pitch - L.u_off;
         if (u < sweep) u = sweep;
         // winner: operands + NCC matrix, and (one group of angles: the fused Hessian, pm_kernel_rp prologue) 5 KB of
         // histogram and key list behind them; then the Hessian magnitudes unless they fit over the window + operands
         int winner;
-        if (gs) {
+        if (big) {
+            L.ccm_off = round_up(rh * rw * 4, 256);
+            L.hes_off = L.ccm_off + round_up(wh * rw * 4, 256);
+            L.big_bytes = L.hes_off + round_up(rh * rw * 4, 256);
+            winner = 2 * L.trow_bytes + (one_group ? 5120 : 0);
+        } else if (gs) {
             // (the magnitudes start at the window; where window + operands are too short for them the NCC matrix moves up)
             const int avail = L.u_off + 2 * L.trow_bytes - L.win_off;
             const int extra = (own_hes || rh * rw * 4 <= avail) ? 0 : round_up(rh * rw * 4 - avail, 16);
@@ -300,7 +311,7 @@ __host__ __device__ inline int rp_class_pitch(int natural)
 }
 // paired: 0 = one group of 16 slots, 1 = two groups (at most 7 angles), 2 = four groups (at most 3 angles)
 // occ: wavefronts per SIMD the build allows - 3, or 4 (128 VGPRs; slot groups with pitch 104 only: four workgroups per CU)
-int launch_pm_rp(const PMArgs &args, int lds_bytes, int nthreads, int band, int paired, int pitch, int occ, void *stream);
+int launch_pm_rp(const PMArgs &args, int lds_bytes, int nthreads, int band, int paired, int pitch, int occ, void *stream, bool big = false);
 bool rp_pitch_instantiated(int band, int paired, int pitch, int occ = 3);
 
 __host__ __device__ inline int samp_pitch(int s) { return round_up(s, 4); }

@@ -109,7 +109,15 @@ struct Geo {
     int hist_off;                    // 5 KB behind the NCC matrix of the winning angle for ph_hessian_fast (0: none - the general ph_hessian runs)
     long long r0, c0;                // window origin on image 2
     double c1, r1, nd;
+    unsigned long long big;          // row-pair kernel, big layouts (rp_lds_layout): the point's block of global memory
 };
+// per-placement table at `off`: LDS, or - big layouts of the row-pair kernel - the point's block of global memory
+template <bool BIG, typename T>
+__device__ __forceinline__ T *tab_ptr(const Geo &G, unsigned char *smem, int off)
+{
+    if constexpr (BIG) return reinterpret_cast<T *>(reinterpret_cast<unsigned char *>(G.big) + (unsigned)off);
+    else return reinterpret_cast<T *>(smem + off);
+}
 constexpr int kGeoOff = 2432;
 static_assert(sizeof(MiscM) <= kGeoOff, "misc header too large");
 static_assert(kGeoOff + sizeof(Geo) <= kMiscMfmaBytes, "geometry block does not fit the LDS header");
@@ -1370,14 +1378,14 @@ __device__ __noinline__ void ph_winner(int ka, long long *dbg_cycles)
 // Phase 5: Hessian at the peak (pmlib.py:36-59, :167) and the optional MCC normalisation.
 // hes aliases sii.  Returns h, r in m->red_f[0..1].
 // ---------------------------------------------------------------------------------------------
-template <int PRIO = -1>
+template <int PRIO = -1, bool BIG = false>
 __device__ __noinline__ void ph_hessian(unsigned flags, int iy, int ix, float best_r, float *dbg_ccm, float *dbg_hes,
                                         long long dbg_cap, long long *dbg_cycles)
 {
     if (PRIO >= 0) __builtin_amdgcn_s_setprio(PRIO);
     SID_PHASE_LOCALS;
-    float *hes = reinterpret_cast<float *>(smem + G.hes_off);
-    const float *ccm = reinterpret_cast<const float *>(smem + G.ccm_off);
+    float *hes = tab_ptr<BIG, float>(G, smem, G.hes_off);
+    const float *ccm = tab_ptr<BIG, float>(G, smem, G.ccm_off);
     u32 *hist4 = reinterpret_cast<u32 *>(smem + G.u_off);             // winner operands are dead: 4 KB of histograms
     u32 *medlist = hist4 + 1024;                                       // + 1 KB of keys (2 * trow_bytes >= 5 KB for every s)
     const int rh = G.rh, rw = G.rw, npos = G.npos;
@@ -1401,7 +1409,7 @@ __device__ __noinline__ void ph_hessian(unsigned flags, int iy, int ix, float be
         // kernel in double ('reflect' boundary; centre tap first, then the pairs from the outermost inwards,
         // as scipy's correlate1d does for a symmetric kernel), rounded to float32 after each axis
         float *tmp = hes;                                              // the Hessian buffer is free until the gradient pass
-        float *cw = reinterpret_cast<float *>(smem + G.ccm_off);
+        float *cw = tab_ptr<BIG, float>(G, smem, G.ccm_off);
         const double w4 = m->gw[4], w3 = m->gw[3], w2 = m->gw[2], w1 = m->gw[1], w0 = m->gw[0];
         auto refl = [](int q, int n) { while (q < 0 || q >= n) { if (q < 0) q = -q - 1; if (q >= n) q = 2 * n - 1 - q; } return q; };
         __syncthreads();
@@ -1567,14 +1575,14 @@ __device__ __forceinline__ u32 hes_bucket(u32 bits)
 // compacted and ranked by wavefront 0, which also forms the result.  Buckets too full for the list (massive ties, flat
 // matrices, magnitudes below 2^-15) fall back to the radix select.
 // ---------------------------------------------------------------------------------------------
-template <int PRIO = -1>
+template <int PRIO = -1, bool BIG = false>
 __device__ __noinline__ void ph_hessian_fast(unsigned flags, int iy, int ix, float best_r, float *dbg_ccm, float *dbg_hes,
                                              long long dbg_cap, long long *dbg_cycles)
 {
     if (PRIO >= 0) __builtin_amdgcn_s_setprio(PRIO);
     SID_PHASE_LOCALS;
-    float *hes = reinterpret_cast<float *>(smem + G.hes_off);
-    const float *ccm = reinterpret_cast<const float *>(smem + G.ccm_off);
+    float *hes = tab_ptr<BIG, float>(G, smem, G.hes_off);
+    const float *ccm = tab_ptr<BIG, float>(G, smem, G.ccm_off);
     u32 *hist = reinterpret_cast<u32 *>(smem + G.hist_off);            // 2048 16-bit counters, zero on entry; m->sel_cle = 0
     u32 *list = hist + 1024;                                           // kMedList keys
     const int rh = G.rh, rw = G.rw, npos = G.npos;
@@ -2004,7 +2012,7 @@ int launch_hypot_selftest(unsigned long long seed, int blocks, int per_thread, u
     return (int)hipGetLastError();
 }
 
-bool mfma_img_size_supported(int s) { return s >= 2 && s + 15 <= 64; }
+bool mfma_img_size_supported(int s) { return s >= 2 && s <= 64; }   // K = 64 template columns per matrix instruction
 
 // The dynamic-LDS limit belongs to the function and the device, not to the stream: it is raised to the maximum once per
 // (kernel, device) - always the maximum, so that launches of different footprints from different host threads cannot
@@ -2069,7 +2077,7 @@ bool rp_pitch_instantiated(int band, int paired, int pitch, int occ)
     return rp_kernel_for<34>(band, paired, pitch) != nullptr;
 }
 
-int launch_pm_rp(const PMArgs &args, int lds_bytes, int nthreads, int band, int paired, int pitch, int occ, void *stream)
+int launch_pm_rp(const PMArgs &args, int lds_bytes, int nthreads, int band, int paired, int pitch, int occ, void *stream, bool big)
 {
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (args.n_launch <= 0) return (int)hipSuccess;
@@ -2077,7 +2085,9 @@ int launch_pm_rp(const PMArgs &args, int lds_bytes, int nthreads, int band, int 
     if ((band != 4 && band != 8) || (band == 8 && nthreads != 256)) return (int)hipErrorInvalidValue;
     if ((occ != 3 && occ != 4) || (occ == 4 && (nthreads != 256 || band != 4))) return (int)hipErrorInvalidValue;
     if (paired && (band != 4 || args.n_angles > (paired == 2 ? kQuadMaxAngles : kPairedMaxAngles))) return (int)hipErrorInvalidValue;
-    void (*kern)(const PMArgs) = occ == 4 ? rp_occ4_kernel(args.img_size, paired, pitch)
+    if (big && (band != 4 || paired || pitch || occ != 3)) return (int)hipErrorInvalidValue;
+    void (*kern)(const PMArgs) = big ? (args.img_size == 34 ? pm_kernel_rp<34, 4, 0, 0, true> : pm_kernel_rp<35, 4, 0, 0, true>)
+                               : occ == 4 ? rp_occ4_kernel(args.img_size, paired, pitch)
                                : args.img_size == 34 ? rp_kernel_for<34>(band, paired, pitch) : rp_kernel_for<35>(band, paired, pitch);
     if (!kern) return (int)hipErrorInvalidValue;
     const hipError_t e = allow_max_lds(kern);

@@ -13,7 +13,7 @@ The structure is  prelude (host, NumPy)  ->  dispatch (GPU)  ->  postlude (host,
   kernel behind the C ABI (``_capi``).  ``threads`` is accepted for signature compatibility
   and ignored.  There is no CPU fallback: without the HIP library / a gfx950 device this
   raises.  Options the kernel does not implement (``rot_order != 0``, a
-  user ``template_matcher``, ``img_size`` outside 2..49) raise ``NotImplementedError``;
+  user ``template_matcher``, ``img_size`` outside 2..64) raise ``NotImplementedError``;
 * ``pm_postlude``  turns the (N,5) result block into the seven output grids as
                    pmlib.py:451-497 does.
 """

@@ -67,6 +67,29 @@ int main()
                         }
                         }
                     }
+    // big layouts (search borders beyond the LDS: 69 .. 111 at s = 34 / 35): the per-placement tables - sum w'^2, the row sums of
+    // rp_sums / the NCC matrix of the winning angle, the Hessian magnitudes - are 256-byte aligned pieces of a block of global
+    // memory; LDS holds the window, the sweep's operands and the winner's operands + histogram
+    for (int s = 34; s <= 35; ++s)
+        for (int b = 40; b <= 111; ++b)
+            for (int variant = 0; variant < 3; ++variant) {
+                const int w = 2 * (s / 2) + 2 * b + 1, wh = w, ww = w - (variant == 2 ? 5 : 0), rh = wh - s + 1, rw = ww - s + 1;
+                const bool one_group = variant != 1;
+                const RpLdsLayout L = rp_lds_layout(wh, ww, s, one_group, 4, 0, 512, !one_group, true, true);
+                char tag[96]; snprintf(tag, sizeof tag, "big s=%d b=%d variant=%d", s, b, variant);
+                CHECK(L.total <= 160 * 1024 && L.total % 16 == 0, "%s: %d bytes of LDS", tag, L.total);
+                CHECK(L.sii_off == 0 && L.si_off == 0 && L.u_off >= L.win_off + L.wrows * L.wpitch, "%s: window / union", tag);
+                CHECK(L.ccm_off % 256 == 0 && L.hes_off % 256 == 0 && L.big_bytes % 256 == 0, "%s: alignment of the global pieces", tag);
+                CHECK(L.ccm_off >= rh * rw * 4 && L.hes_off >= L.ccm_off + wh * rw * 4 && L.big_bytes >= L.hes_off + rh * rw * 4, "%s: global pieces overlap", tag);
+                CHECK(L.wp_off + L.wp_rows * L.wp_pitch <= L.total && L.wp_off >= L.queue_off + L.queue_cap * 16, "%s: transposed columns", tag);
+                CHECK(L.u_off + 2 * L.trow_bytes + (one_group ? 5120 : 0) <= L.total, "%s: winner operands + histogram", tag);
+                CHECK(L.patch_off + L.pdim * L.ppitch + 1 <= L.total && L.patch_off >= L.strip_off + L.ncp * L.nrg * 1024 + 16, "%s: patch", tag);
+                if (!one_group) CHECK(L.queue_off >= L.patch_off + L.pdim * L.ppitch + 1, "%s: queue overlaps the live patch", tag);
+                CHECK(rh * rw < 65536, "%s: %d placements (16-bit histogram counters, reciprocal divisions)", tag, rh * rw);
+            }
+    CHECK(rp_lds_layout(259, 259, 34, true, 4, 0, 512, false, true, true).total > 160 * 1024, "border 112 fits the LDS?");
+    CHECK(rp_lds_layout(171, 171, 34, true, 4, 0, 512, false, true, false).total <= 160 * 1024 &&
+          rp_lds_layout(173, 173, 34, true, 4, 0, 512, false, true, false).total > 160 * 1024, "tables in LDS: up to border 68");
     // residency classes of the benchmark's borders (the numbers DESIGN.md quotes)
     auto total = [](int b, int paired, bool gs) {
         const int w = 35 + 2 * b, rows = paired == 2 ? 16 : paired == 1 ? 8 : 4, tp = rp_tab_pitch(paired);

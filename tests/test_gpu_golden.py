@@ -89,7 +89,7 @@ def test_unsupported_sizes_and_flags_are_errors(pm_ctx):
     pm_ctx.upload_pair(img1, img2)
     one = ([150.0], [150.0], [150.0], [150.0], [20.0])
     with pytest.raises(_capi.SidPmError) as e:
-        pm_ctx.set_points(*one, 50, 0.0, [0.0])
+        pm_ctx.set_points(*one, 65, 0.0, [0.0])
     assert e.value.code == -4
     with pytest.raises(_capi.SidPmError):
         pm_ctx.set_points(*one, 34, 0.0, [])
@@ -97,7 +97,7 @@ def test_unsupported_sizes_and_flags_are_errors(pm_ctx):
         pm_ctx.set_points(*one, 34, 0.0, [0.0], flags=8)
     assert e.value.code == -1
     with pytest.raises(_capi.SidPmError) as e:                     # border too large for LDS
-        pm_ctx.set_points([150.0], [150.0], [150.0], [150.0], [100.0], 34, 0.0, [0.0])
+        pm_ctx.set_points([150.0], [150.0], [150.0], [150.0], [112.0], 34, 0.0, [0.0])
     assert e.value.code == -4
 
 

@@ -15,14 +15,18 @@ def rot_for(angles, alpha0, s):
     return np.array([po.rotation_terms(a - alpha0, s) for a in angles])
 
 
-def assert_parity(got, got_ij, exp, exp_ij):
-    """Integer outputs bit-exact; c2, r2, a exact; r exact (float32 spec); h within 1e-5."""
+def assert_parity(got, got_ij, exp, exp_ij, mcc_norm=False):
+    """Integer outputs bit-exact; c2, r2, a exact; r exact (float32 spec; within 1e-5 when mcc_norm divides it by a float32
+    standard deviation, as in test_hessian_options_incl_gaussian_smoothing); h within 1e-5."""
     np.testing.assert_array_equal(got_ij, exp_ij)
     nan_e = np.isnan(exp[:, 0])
     np.testing.assert_array_equal(np.isnan(got[:, 0]), nan_e)
     g, e = got[~nan_e], exp[~nan_e]
     np.testing.assert_array_equal(g[:, :3], e[:, :3])
-    np.testing.assert_array_equal(g[:, 3], e[:, 3])
+    if mcc_norm:
+        np.testing.assert_allclose(g[:, 3], e[:, 3], rtol=1e-5, atol=1e-5)
+    else:
+        np.testing.assert_array_equal(g[:, 3], e[:, 3])
     np.testing.assert_allclose(g[:, 4], e[:, 4], rtol=1e-5, atol=1e-5)
 
 
@@ -129,11 +133,13 @@ def test_one_shot_batch_entry(c_oracle):
     assert_parity(got, got_ij, exp, exp_ij)
 
 
-@pytest.mark.parametrize('s,nang', [(21, 5), (33, 7), (36, 15), (49, 3), (34, 17), (35, 31)])
+@pytest.mark.parametrize('s,nang', [(21, 5), (33, 7), (36, 15), (49, 3), (34, 17), (35, 31), (51, 7), (64, 15), (64, 3)])
 def test_other_template_sizes_and_angle_counts(pm_ctx, c_oracle, s, nang):
-    """Generic-size code path (s not 34/35) and more than 15 angles (several template groups)."""
-    img1, img2 = syn.make_pair(500, 500, seed=21)
-    g = syn.make_grid(500, 500, 7, margin=95, border=20 if s > 40 else 'mixed')
+    """Generic-size code path (s not 34/35; up to 64 = the K of one matrix instruction, round 4) and more than 15 angles
+    (several template groups)."""
+    size = 500 if s < 50 else 700
+    img1, img2 = syn.make_pair(size, size, seed=21)
+    g = syn.make_grid(size, size, 7, margin=95 if s < 50 else 140, border=20 if 40 < s < 50 else 'mixed')
     half = nang // 2
     angles = [0.5 * k for k in range(-half, nang - half)]
     rot = rot_for(angles, 1.25, s)
@@ -257,7 +263,7 @@ def test_results_written_straight_into_pinned_host_memory(pm_ctx, c_oracle):
 
 
 @pytest.mark.parametrize('s,angles', [(34, ANGLES15), (34, [-3, 0, 3]), (35, ANGLES7)])
-def test_every_launch_class_incl_global_sums_and_borders_up_to_68(pm_ctx, c_oracle, monkeypatch, s, angles):
+def test_every_launch_class_incl_global_sums_borders_20_to_68(pm_ctx, c_oracle, monkeypatch, s, angles):
     """Round 4: borders 28 .. 47 run launches that keep the per-placement sum of squares in GLOBAL memory (the smaller LDS
     footprint lifts them into the next residency class), the Hessian magnitudes lie over the dead window, and search borders up
     to 68 fit the 160 KB of LDS (58 before).  Every border 20 .. 68 in one call - all launch classes, both forms of the sums -
@@ -292,7 +298,41 @@ def test_every_launch_class_incl_global_sums_and_borders_up_to_68(pm_ctx, c_orac
         np.testing.assert_array_equal(got[:, :4], results[0][0][:, :4])
     for k in ('SID_PM_ALWAYS_GS', 'SID_PM_NO_GS'):
         monkeypatch.delenv(k, raising=False)
+
+
+@pytest.mark.parametrize('s,angles,flags', [(34, ANGLES15, 1), (35, [-3, 0, 3], 1), (34, ANGLES7, 7), (35, [0.5 * k for k in range(-8, 9)], 3)])
+def test_borders_69_to_111_keep_their_tables_in_global_memory(pm_ctx, c_oracle, monkeypatch, s, angles, flags):
+    """Round 4: beyond border 68 the per-placement tables of a point (sum w'^2, the row sums, the NCC matrix of the winning angle,
+    the Hessian magnitudes) no longer fit the 160 KB of LDS next to the window; those points run `pm_kernel_rp<S, 4, 0, 0, true>`,
+    which keeps them in the point's block of global memory (a slot of the per-XCD pool, or - SID_PM_NO_GS_POOL - the exclusive
+    block of the launch position).  Borders up to 111 (reference kwarg max_border; its default is 50), any angle set (slot-group
+    sets run the full-table kernel there), both Hessian routes, several groups of angles."""
+    size = 1700
+    img1, img2 = syn.make_pair(size, size, seed=29)
+    rng = np.random.default_rng(4)
+    borders = np.concatenate([np.arange(66, 112, 3 if len(angles) > 7 else 2), [111, 111]]).astype(np.float64)
+    n = len(borders)
+    c1 = np.rint(rng.uniform(420, size - 420, n)); r1 = np.rint(rng.uniform(420, size - 420, n))
+    dc, dr = syn.true_displacement(c1, r1)
+    c2 = c1 + np.rint(dc) + rng.integers(-2, 3, n); r2 = r1 + np.rint(dr) + rng.integers(-2, 3, n)
+    rot = rot_for(angles, 0.0, s)
+    exp, exp_ij = c_oracle.pm_batch(img1, img2, c1, r1, c2, r2, borders, s, 0.0, angles, rot=rot, nthreads=8, flags=flags)
+    assert np.isfinite(exp[:, 0]).sum() > n * 0.9
+    pm_ctx.upload_pair(img1, img2)
+    results = []
+    for env in (None, 'SID_PM_NO_GS_POOL'):
+        monkeypatch.delenv('SID_PM_NO_GS_POOL', raising=False)
+        if env:
+            monkeypatch.setenv(env, '1')
+        pm_ctx.set_points(c1, r1, c2, r2, borders, s, 0.0, angles, rot=rot, flags=flags)
+        pm_ctx.run()
+        got, got_ij = pm_ctx.fetch()
+        assert_parity(got, got_ij, exp, exp_ij, mcc_norm=bool(flags & 4))
+        results.append((got, got_ij))
+    np.testing.assert_array_equal(results[1][1], results[0][1])
+    np.testing.assert_array_equal(results[1][0], results[0][0])
+    monkeypatch.delenv('SID_PM_NO_GS_POOL', raising=False)
     # one more border does not fit any more: an error, not a NaN
     with pytest.raises(_capi.SidPmError) as e:
-        pm_ctx.set_points(c1[:1], r1[:1], c2[:1], r2[:1], [75.0], s, 0.0, angles, rot=rot)
+        pm_ctx.set_points(c1[:1], r1[:1], c2[:1], r2[:1], [112.0], s, 0.0, angles, rot=rot)
     assert e.value.code == -4
