@@ -34,8 +34,17 @@ void sid_stage_destroy(sid_stage_ws *ws);
 int sid_stage_begin(sid_stage_ws *ws, const float *d_img, int64_t rows, int64_t cols, int64_t stride, int64_t *n_valid,
                     void *hip_stream);
 
-/* Exact order statistics of the image of the last sid_stage_begin: values[k] (host) = the ranks[k]-th smallest
- * (0-based) non-NaN pixel; two more passes over the image per group of up to eight ranks. */
+/* The same with a hint (round 4): the order statistics that will be asked for lie near these fractions (numpy percentile p ->
+ * p / 100; at most 4) of the non-NaN pixels.  A sample of 8192 pixels brackets every fraction by a key range, and ONE pass
+ * over the image counts the non-NaN pixels, the pixels below each range and a 2048-bin histogram inside it; a rank that falls
+ * into a range then costs one more pass (none when a bin is a single key) instead of two.  The results are exact either way:
+ * a rank outside every range takes the three-pass route of sid_stage_begin (its first pass is then run on demand).
+ * SID_STAGE_NO_HINT=1 in the environment makes this entry point sid_stage_begin (A/B runs).                              */
+int sid_stage_begin_hint(sid_stage_ws *ws, const float *d_img, int64_t rows, int64_t cols, int64_t stride,
+                         const double *fractions, int n_fractions, int64_t *n_valid, void *hip_stream);
+
+/* Exact order statistics of the image of the last sid_stage_begin / sid_stage_begin_hint: values[k] (host) = the ranks[k]-th smallest
+ * (0-based) non-NaN pixel; two more passes over the image per group of up to eight ranks (one after a hint that holds). */
 int sid_stage_order_stats_ws(sid_stage_ws *ws, const int64_t *ranks, int n_ranks, float *values);
 
 /* One-shot forms of the above (a temporary workspace per call). */

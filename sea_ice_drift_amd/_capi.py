@@ -30,7 +30,7 @@ SYMBOLS = (
 FT_SYMBOLS = ('sid_ft_knn2', 'sid_ft_knn2_device', 'sid_ft_workspace_bytes', 'sid_ft_last_error', 'sid_ft_release')
 
 # every symbol include/sid_stage.h declares (uint8 staging, same library)
-STAGE_SYMBOLS = ('sid_stage_create', 'sid_stage_destroy', 'sid_stage_begin', 'sid_stage_order_stats_ws',
+STAGE_SYMBOLS = ('sid_stage_create', 'sid_stage_destroy', 'sid_stage_begin', 'sid_stage_begin_hint', 'sid_stage_order_stats_ws',
                  'sid_stage_count_valid', 'sid_stage_order_stats', 'sid_stage_scale_u8', 'sid_stage_last_error')
 
 # every symbol include/sid_orb.h declares (key-point detector, same library)
@@ -121,6 +121,9 @@ def lib():
     L.sid_stage_destroy.restype = None
     L.sid_stage_begin.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.POINTER(C.c_int64), C.c_void_p]
     L.sid_stage_order_stats_ws.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.c_int, _f32p]
+    if hasattr(L, 'sid_stage_begin_hint'):
+        L.sid_stage_begin_hint.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.POINTER(C.c_double), C.c_int,
+                                           C.POINTER(C.c_int64), C.c_void_p]
     L.sid_orb_detect.argtypes = [C.c_int, _u8p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.POINTER(C.c_int8), _i32p,
                                  _f32p, _i32p, C.POINTER(C.c_int64), _u8p, C.c_int64, C.POINTER(C.c_int64)]
     L.sid_orb_last_error.restype = C.c_char_p
@@ -468,10 +471,17 @@ class StageWorkspace(object):
         except TypeError:                                  # interpreter shutdown: the module globals are already gone
             pass
 
-    def begin(self, ptr, rows, cols, stride, stream=0):
-        """First pass: number of non-NaN pixels; keeps the leading-digit histogram for order_stats."""
+    def begin(self, ptr, rows, cols, stride, stream=0, fractions=None):
+        """First pass: number of non-NaN pixels; keeps what order_stats needs - the leading-digit histogram, or (``fractions``:
+        where the wanted order statistics lie, as fractions of the non-NaN pixels) the histograms inside sampled key ranges
+        around them, which saves order_stats one of its two passes (include/sid_stage.h sid_stage_begin_hint)."""
         n = C.c_int64(0)
-        _stage_check(lib().sid_stage_begin(self._h, C.c_void_p(int(ptr)), rows, cols, stride, C.byref(n), C.c_void_p(int(stream))))
+        if fractions is not None and len(fractions) > 0:
+            f = np.ascontiguousarray(fractions, dtype=np.float64)
+            _stage_check(lib().sid_stage_begin_hint(self._h, C.c_void_p(int(ptr)), rows, cols, stride,
+                                                    f.ctypes.data_as(C.POINTER(C.c_double)), len(f), C.byref(n), C.c_void_p(int(stream))))
+        else:
+            _stage_check(lib().sid_stage_begin(self._h, C.c_void_p(int(ptr)), rows, cols, stride, C.byref(n), C.c_void_p(int(stream))))
         return int(n.value)
 
     def order_stats(self, ranks):

@@ -335,8 +335,9 @@ def get_uint8_image(image, vmin, vmax, pmin, pmax, device=0):
         ws = _STAGE_WS.get(dev_index)
         if ws is None:
             ws = _STAGE_WS[dev_index] = _capi.StageWorkspace(dev_index)
-        n = ws.begin(t.data_ptr(), rows, cols, stride, stream)
         want = [p for p, v in ((pmin, vmin), (pmax, vmax)) if v is None]
+        # (the percentiles as fractions: the first pass then already counts inside sampled key ranges around them)
+        n = ws.begin(t.data_ptr(), rows, cols, stride, stream, fractions=[float(p) / 100.0 for p in want])
         if n == 0:
             vals = {p: ftype(np.nan) for p in want}
         else:

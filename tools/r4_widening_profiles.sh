@@ -60,6 +60,8 @@ res = {}
 px = 1e8
 for k, calls, total, avg in kernels('stage'):
     if 'hist_kernel' in k: res.setdefault('stage.hip hist_kernel', []).append({'avg_ns': avg, 'calls': calls, 'bytes_per_launch': 4 * px, 'GBps': 4 * px / avg, 'frac_of_8TBps': 4 * px / avg / HBM, 'bound': 'hbm'})
+    if 'range_kernel' in k: res.setdefault('stage.hip range_kernel', []).append({'name': k[:60], 'avg_ns': avg, 'calls': calls, 'bytes_per_launch': 4 * px, 'GBps': 4 * px / avg, 'frac_of_8TBps': 4 * px / avg / HBM, 'bound': 'hbm'})
+    if 'sample_kernel' in k: res.setdefault('stage.hip sample_kernel', []).append({'avg_ns': avg, 'calls': calls, 'bound': 'latency (one workgroup: 8192 scattered pixels, three-digit radix select in LDS)'})
     if 'scale_kernel' in k: res.setdefault('stage.hip scale_kernel', []).append({'avg_ns': avg, 'calls': calls, 'bytes_per_launch': 5 * px, 'GBps': 5 * px / avg, 'frac_of_8TBps': 5 * px / avg / HBM, 'bound': 'hbm'})
 for k, calls, total, avg in kernels('ft_match'):
     pairs = 24183.0 * 22694.0

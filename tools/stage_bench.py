@@ -28,6 +28,6 @@ t0 = time.perf_counter(); exp, vmin, vmax = so.get_uint8_image(img.copy(), None,
 ok = bool(np.array_equal(out.cpu().numpy(), exp) and np.array_equal(out_h, exp))
 px = float(n) * n
 print(json.dumps({'metric': 'get_uint8_image (percentile-driven) on a %dx%d float32 image' % (n, n),
-                  'device_resident_ms': t_dev * 1e3, 'bytes_moved_model': '3 passes x 4 B/px (11 + 11 + 10-bit radix digits; the first pass also counts) + 5 B/px scale = 17 B/px',
-                  'effective_GBps': 17 * px / t_dev / 1e9, 'hbm_frac_of_8TBps': 17 * px / t_dev / 8e12, 'host_array_call_ms_incl_pcie': t_host_call * 1e3,
+                  'device_resident_ms': t_dev * 1e3, 'bytes_moved_model': '2 passes x 4 B/px (round 4: counts + histograms inside sampled key ranges, then the chosen bins; 3 passes before) + 5 B/px scale = 13 B/px',
+                  'effective_GBps': 13 * px / t_dev / 1e9, 'hbm_frac_of_8TBps': 13 * px / t_dev / 8e12, 'host_array_call_ms_incl_pcie': t_host_call * 1e3,
                   'numpy_reference_recipe_s': t_numpy, 'bit_exact_vs_oracle': ok}))
