@@ -3,8 +3,10 @@
 // the header).  Every step is integer arithmetic with the specification of oracle/orb_oracle.py.
 //
 // Data flow per pyramid level: resample -> FAST-9 score map -> 3x3 non-maximum suppression + Harris response ->
-// candidate list (device) -> host: sort by (response desc, y, x), keep the level's share -> device: orientation
-// (intensity centroid, 32 directions) -> binomial blur -> 256 comparisons through the pre-rotated pattern.
+// candidate list -> the level's share in (response desc, y, x) order (radix selection + ranking by counting, all on the
+// device since round 4: detect_on_device; the host-side route of rounds 2-3 remains as SID_ORB_HOST_SELECT=1 and as the
+// fallback for a selection that overflows) -> orientation (intensity centroid, 32 directions) -> binomial blur -> 256
+// comparisons through the pre-rotated pattern.  One synchronisation per image.
 // All kernels are streaming passes over uint8 images (one thread per pixel or per key point); the detector runs once
 // per image and is a small part of the feature-tracking + pattern-matching chain (tools/ftpm_bench.py).
 #include <hip/hip_runtime.h>
@@ -251,6 +253,232 @@ __global__ void k_describe(const uint8_t *blur, int cols, const int32_t *kp, con
     if (!(lane & 1)) desc[(long long)i * 32 + (lane >> 1)] = (uint8_t)(bits | (hi << 4));
 }
 
+// ---------------------------------------------------------------------------------------------
+// Round 4: selection and exact ordering ON THE DEVICE - a level no longer visits the host (seven synchronisations and a
+// host sort per level before: candidate count, three histograms, compaction count, candidates, results).  Counts live in a
+// DState block of device memory; kernels whose extent is a device-side count run a fixed grid and stride over it.
+//   k_pick_d   one wavefront turns a 2048-bin histogram into the next digit of the key of rank `keep` from the top
+//   k_rank_d   exact order (response descending, then y, then x) by COUNTING: a candidate's position is the number of
+//              candidates before it - n^2 comparisons through LDS tiles, n = the ~keep candidates that survived the
+//              selection (2.4 x 10^4 at level 0 of a 10^8-pixel image: ~0.1 ms), no sort network, no second buffer
+//   k_emit_d   the level's share of key points -> the output arrays at the running total
+// A level whose selection overflows its buffer (massive ties) raises DState::flags and the call is repeated with the
+// host-side route (SID_ORB_HOST_SELECT=1 forces that route: A/B runs and the equality test).
+// ---------------------------------------------------------------------------------------------
+struct DState { unsigned int nc, nsel, n_lvl, total, prefix, above, flags, pad; };
+
+__global__ void k_lvl_begin(DState *S) { S->nc = 0; S->nsel = 0; S->n_lvl = 0; S->prefix = 0; S->above = 0; }
+__global__ void k_lvl_end(DState *S) { S->total += S->n_lvl; }
+
+__global__ void k_harris_d(const uint8_t *img, int cols, Cand *cand, DState *S, unsigned int cap)
+{
+    const unsigned int n = S->nc;
+    if (n > cap) { if (blockIdx.x == 0 && threadIdx.x == 0) S->flags |= 1u; return; }
+    for (unsigned int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const int x = cand[i].x, y = cand[i].y;
+        int a = 0, b = 0, c = 0;
+        for (int dy = -3; dy <= 3; ++dy) {
+            const uint8_t *p = img + (long long)(y + dy) * cols + x;
+#pragma unroll
+            for (int dx = -3; dx <= 3; ++dx) {
+                const int ix = (int)p[dx + 1] - (int)p[dx - 1], iy = (int)p[dx + cols] - (int)p[dx - cols];
+                a += ix * ix; b += iy * iy; c += ix * iy;
+            }
+        }
+        const long long A = a, B = b, C = c;
+        cand[i].resp = 25 * (A * B - C * C) - (A + B) * (A + B);
+    }
+}
+
+__global__ void k_key_hist_d(const Cand *c, const DState *S, unsigned int cap, int pass, unsigned int *hist)
+{
+    __shared__ unsigned int h[2048];
+    const unsigned int n = S->nc <= cap ? S->nc : 0u;
+    if (blockIdx.x * blockDim.x >= n) return;                          // (uniform)
+    const int shift = pass == 0 ? 21 : pass == 1 ? 10 : 0;
+    const uint32_t dmask = pass == 2 ? 1023u : 2047u, pmask = pass == 0 ? 0u : pass == 1 ? 0xffe00000u : 0xfffffc00u;
+    const uint32_t prefix = S->prefix;
+    for (int b = threadIdx.x; b < 2048; b += blockDim.x) h[b] = 0;
+    __syncthreads();
+    for (unsigned int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const uint32_t k = resp_key(c[i].resp);
+        if ((k & pmask) == prefix) atomicAdd(&h[(k >> shift) & dmask], 1u);
+    }
+    __syncthreads();
+    for (int b = threadIdx.x; b < 2048; b += blockDim.x) { const unsigned int v = h[b]; if (v) atomicAdd(&hist[b], v); }
+}
+
+// one wavefront: digit d (from the top) at which the number of candidates with a larger key reaches keep - the host loop
+// `for (d = max; d > 0; --d) { if (above + hist[d] >= keep) break; above += hist[d]; }` of the host-side route; clears the
+// histogram for the next pass
+__global__ void k_pick_d(unsigned int *hist, DState *S, int pass, int want, long long max_out)
+{
+    const int lane = threadIdx.x;
+    const int shift = pass == 0 ? 21 : pass == 1 ? 10 : 0;
+    const unsigned int dmask = pass == 2 ? 1023u : 2047u;
+    const long long room = max_out - (long long)S->total;
+    const unsigned int keep = (unsigned int)(room < (long long)want ? (room > 0 ? room : 0) : (long long)want);
+    unsigned int c[32], tot = 0;
+#pragma unroll
+    for (int j = 0; j < 32; ++j) {
+        const unsigned int idx = 32u * lane + j;
+        c[j] = idx <= dmask ? hist[idx] : 0u;
+        hist[idx] = 0u;
+        if (idx == 0u) c[j] = keep;                                    // (the loop above never tests digit 0: it ends there)
+        tot += c[j];
+    }
+    unsigned int suf = tot;                                            // inclusive suffix sum over the lanes
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const unsigned int o = (unsigned int)__shfl_down((int)suf, d); if (lane + d < 64) suf += o; }
+    const unsigned int above0 = S->above;
+    const unsigned long long ok = __ballot(above0 + suf >= keep);      // true for lane 0 at least
+    const int L = 63 - __builtin_clzll(ok);
+    if (lane == L) {
+        unsigned int a = above0 + (suf - tot);
+        int d = 0;
+        bool found = false;
+#pragma unroll
+        for (int j = 31; j >= 0; --j) {
+            if (!found) { if (a + c[j] >= keep) { d = 32 * lane + j; found = true; } else a += c[j]; }
+        }
+        S->prefix |= (uint32_t)d << shift; S->above = a;
+    }
+}
+
+// a block owns a contiguous piece of the candidate list: it counts its takers, reserves their slots with ONE atomic on the
+// global counter and writes them (a per-wavefront append - k_compact - serialises ~15 000 atomics on that one address: 120 us)
+__global__ void k_compact_d(const Cand *c, DState *S, unsigned int cap, Cand *out, unsigned int sel_cap, unsigned int *rank)
+{
+    __shared__ unsigned int cnt, base, pos;
+    const unsigned int n = S->nc <= cap ? S->nc : 0u;
+    const uint32_t kmin = S->prefix;
+    const unsigned int per = ((n + gridDim.x - 1) / gridDim.x + 255u) & ~255u, i0 = blockIdx.x * per, i1 = i0 + per < n ? i0 + per : n;
+    if (i0 >= i1) return;                                              // (uniform)
+    if (threadIdx.x == 0) { cnt = 0; pos = 0; }
+    __syncthreads();
+    unsigned int mine = 0;
+    for (unsigned int i = i0 + threadIdx.x; i < i1; i += blockDim.x) mine += resp_key(c[i].resp) >= kmin ? 1u : 0u;
+    if (mine) atomicAdd(&cnt, mine);
+    __syncthreads();
+    if (cnt == 0) return;
+    if (threadIdx.x == 0) base = atomicAdd(&S->nsel, cnt);
+    __syncthreads();
+    for (unsigned int i = i0 + threadIdx.x; i < i1; i += blockDim.x) {
+        const Cand v = c[i];
+        if (resp_key(v.resp) >= kmin) {
+            const unsigned int k = base + atomicAdd(&pos, 1u);
+            if (k < sel_cap) { out[k] = v; rank[k] = 0u; }
+        }
+    }
+}
+
+// position of candidate i = number of candidates before it.  The list is read through UNIFORM addresses - scalar loads, the
+// comparison operands sit in scalar registers, no LDS and no barrier - and cut into gridDim.y pieces whose counts are added
+// up in rank[] (zeroed by k_compact_d).  (First version: one thread walked the whole list through LDS tiles - 2 ms at level 0.)
+constexpr int kRankPieces = 32;
+__global__ void k_rank_d(const Cand *__restrict__ sel, DState *S, unsigned int sel_cap, unsigned int *__restrict__ rank)
+{
+    const unsigned int n = S->nsel;
+    if (n > sel_cap) { if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) S->flags |= 2u; return; }
+    if (blockIdx.x * blockDim.x >= n) return;                          // (uniform)
+    const unsigned int per = (n + gridDim.y - 1) / gridDim.y, j0 = blockIdx.y * per, j1 = j0 + per < n ? j0 + per : n;
+    if (j0 >= j1) return;
+    const unsigned int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const Cand me = sel[i < n ? i : n - 1];
+    const uint32_t myyx = ((uint32_t)me.y << 16) | (uint32_t)me.x;
+    unsigned int r = 0;
+    // branch-free, eight records per trip: the scalar loads of a trip are issued together (with `||` / `&&` the compiler emitted a
+    // load, a wait and a branch per record)
+    const uint4 *s4 = reinterpret_cast<const uint4 *>(sel);            // Cand = {x, y, resp lo, resp hi}
+    auto before = [&](const uint4 o) -> unsigned int {
+        const long long resp = (long long)(((unsigned long long)o.w << 32) | (unsigned long long)o.z);
+        const uint32_t q = (o.y << 16) | o.x;
+        return (unsigned int)((resp > me.resp) | ((resp == me.resp) & (q < myyx)));
+    };
+    unsigned int j = j0;
+    for (; j + 8 <= j1; j += 8) {
+        uint4 o[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) o[u] = s4[j + u];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) r += before(o[u]);
+    }
+    for (; j < j1; ++j) r += before(s4[j]);
+    if (i < n && r) atomicAdd(&rank[i], r);
+}
+
+__global__ void k_scatter_d(const Cand *__restrict__ sel, const DState *S, unsigned int sel_cap, const unsigned int *__restrict__ rank, Cand *__restrict__ sorted)
+{
+    const unsigned int n = S->nsel;
+    if (n > sel_cap) return;
+    for (unsigned int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) sorted[rank[i]] = sel[i];
+}
+
+__global__ void k_emit_d(const Cand *sorted, DState *S, int want, long long max_out, int level, double scale,
+                         int32_t *kp_all, float *xy_all, long long *resp_all)
+{
+    const long long room = max_out - (long long)S->total;
+    long long n = (long long)S->nsel;
+    if (S->flags) n = 0;
+    if (n > (long long)want) n = want;
+    if (n > room) n = room > 0 ? room : 0;
+    if (blockIdx.x == 0 && threadIdx.x == 0) S->n_lvl = (unsigned int)n;
+    const unsigned int base = S->total;
+    for (long long i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const Cand c = sorted[i];
+        const long long o = (long long)base + i;
+        kp_all[4 * o] = c.x; kp_all[4 * o + 1] = c.y; kp_all[4 * o + 2] = level; kp_all[4 * o + 3] = 0;
+        xy_all[2 * o] = (float)((double)c.x * scale); xy_all[2 * o + 1] = (float)((double)c.y * scale);
+        resp_all[o] = c.resp;
+    }
+}
+
+// orientation / descriptor of the level's key points at kp_all[total ..]; the direction goes into kp_all[..][3]
+__global__ void k_orient_d(const uint8_t *img, int cols, int32_t *kp_all, const DState *S, int R, const int32_t *dirs)
+{
+    const int n = (int)S->n_lvl;
+    const int lane = threadIdx.x & 63;
+    for (int i = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); i < n; i += gridDim.x * (blockDim.x >> 6)) {
+        int32_t *kp = kp_all + 4 * ((long long)S->total + i);
+        const int x = kp[0], y = kp[1];
+        const int w = 2 * R + 1, np = w * w;
+        int m10 = 0, m01 = 0;
+        for (int q = lane; q < np; q += 64) {
+            const int dy = q / w - R, dx = q - (dy + R) * w - R;
+            if (dx * dx + dy * dy <= R * R) { const int v = img[(long long)(y + dy) * cols + x + dx]; m10 += dx * v; m01 += dy * v; }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { m10 += __shfl_xor(m10, o); m01 += __shfl_xor(m01, o); }
+        if (lane == 0) {
+            int best = 0; long long bv = (long long)m10 * dirs[0] + (long long)m01 * dirs[1];
+            for (int b = 1; b < 32; ++b) { const long long v = (long long)m10 * dirs[2 * b] + (long long)m01 * dirs[2 * b + 1]; if (v > bv) { bv = v; best = b; } }
+            kp[3] = best;
+        }
+    }
+}
+
+__global__ void k_describe_d(const uint8_t *blur, int cols, const int32_t *kp_all, const DState *S, const int8_t *pattern, uint8_t *desc_all)
+{
+    const int n = (int)S->n_lvl;
+    const int lane = threadIdx.x & 63;
+    for (int i = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); i < n; i += gridDim.x * (blockDim.x >> 6)) {
+        const long long o = (long long)S->total + i;
+        const int32_t *kp = kp_all + 4 * o;
+        const int x = kp[0], y = kp[1];
+        const int8_t *pt = pattern + (long long)kp[3] * 1024;
+        const uint8_t *c = blur + (long long)y * cols + x;
+        uint32_t bits = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int8_t *q = pt + 4 * (4 * lane + k);
+            const int a = c[q[1] * cols + q[0]], b = c[q[3] * cols + q[2]];
+            bits |= (a < b ? 1u : 0u) << k;
+        }
+        const uint32_t hi = __shfl_down(bits, 1);
+        if (!(lane & 1)) desc_all[o * 32 + (lane >> 1)] = (uint8_t)(bits | (hi << 4));
+    }
+}
+
 }  // namespace
 
 namespace {
@@ -322,6 +550,77 @@ size_t up256(size_t b) { return (b + 255) / 256 * 256; }
 
 }  // namespace
 
+// Every level on the stream without a visit to the host (kernels above); one synchronisation at the end.  *overflow: a level's
+// selection did not fit its buffer - nothing was written to the outputs, the caller repeats the call with the host-side route.
+struct DevBufs {
+    uint8_t *img0, *lvl, *aux, *desc; Cand *cand, *sel; int8_t *pat; int32_t *dirs, *kp; unsigned int *hist;
+    float *xy; long long *resp; DState *state; unsigned int *rank;
+};
+int detect_on_device(OrbWs *ws, const DevBufs &B, int64_t rows, int64_t cols, const sid_orb_params *P, const std::vector<double> &sc,
+                     const std::vector<int> &lr, const std::vector<int> &lc, const std::vector<int> &want, unsigned int sel_cap,
+                     float *xy, int32_t *meta, int64_t *response, uint8_t *desc, int64_t max_out, int64_t *total_out, bool *overflow)
+{
+    int rc = SID_PM_OK;
+    hipStream_t st = ws->stream;
+    const int L = P->n_levels, edge = P->edge_threshold, R = P->patch_size / 2;
+    *overflow = false; *total_out = 0;
+    HIP_TRY(hipMemsetAsync(B.state, 0, sizeof(DState), st));
+    HIP_TRY(hipMemsetAsync(B.hist, 0, 2048 * sizeof(unsigned int), st));
+    for (int l = 0; l < L; ++l) {
+        const int r = lr[l], c = lc[l];
+        if (r <= 2 * edge || c <= 2 * edge || want[l] <= 0) continue;
+        const dim3 blk(256), grd((unsigned)((c + 255) / 256), (unsigned)r);
+        const uint8_t *lvl = B.img0;
+        if (l > 0) {
+            const unsigned long long sx = ((unsigned long long)cols << 16) / (unsigned long long)c,
+                                     sy = ((unsigned long long)rows << 16) / (unsigned long long)r;
+            hipLaunchKernelGGL(k_resize, grd, blk, 0, st, B.img0, (int)rows, (int)cols, (long long)cols, B.lvl, r, c, sx, sy);
+            lvl = B.lvl;
+        }
+        hipLaunchKernelGGL(k_lvl_begin, dim3(1), dim3(1), 0, st, B.state);
+        hipLaunchKernelGGL(k_fast, grd, blk, 0, st, lvl, r, c, edge, P->fast_threshold, B.aux);
+        const unsigned int cap = (unsigned int)((size_t)r * c / 4 + 16);
+        hipLaunchKernelGGL(k_nms, dim3(grd.x, (unsigned)((r + kNmsRows - 1) / kNmsRows)), blk, 0, st, B.aux, r, c, edge, B.cand, &B.state->nc, cap);
+        // candidates are a few per cent of the pixels; the grids below stride over the device-side count
+        const unsigned int gcand = (unsigned int)std::min<size_t>(((size_t)cap + 255) / 256, 4096);
+        hipLaunchKernelGGL(k_harris_d, dim3(gcand), blk, 0, st, lvl, c, B.cand, B.state, cap);
+        for (int pass = 0; pass < 3; ++pass) {
+            hipLaunchKernelGGL(k_key_hist_d, dim3(std::min(gcand, 1024u)), blk, 0, st, B.cand, B.state, cap, pass, B.hist);
+            hipLaunchKernelGGL(k_pick_d, dim3(1), dim3(64), 0, st, B.hist, B.state, pass, want[l], (long long)max_out);
+        }
+        hipLaunchKernelGGL(k_compact_d, dim3(std::min(gcand, 512u)), blk, 0, st, B.cand, B.state, cap, B.sel, sel_cap, B.rank);
+        // (the ordered list goes where the level's candidates were: at most as many as there were candidates)
+        const unsigned int nsel_bound = std::min(sel_cap, cap);
+        hipLaunchKernelGGL(k_rank_d, dim3((nsel_bound + 255) / 256, kRankPieces), blk, 0, st, B.sel, B.state, nsel_bound, B.rank);
+        hipLaunchKernelGGL(k_scatter_d, dim3(std::min((nsel_bound + 255) / 256, 1024u)), blk, 0, st, B.sel, B.state, nsel_bound, B.rank, B.cand);
+        const unsigned int gkp = (unsigned int)std::min<int64_t>(((int64_t)want[l] + 3) / 4, 65535);
+        hipLaunchKernelGGL(k_emit_d, dim3(std::min<unsigned int>((unsigned int)(want[l] + 255) / 256, 1024u)), blk, 0, st, B.cand, B.state, want[l],
+                           (long long)max_out, l, sc[l], B.kp, B.xy, B.resp);
+        hipLaunchKernelGGL(k_orient_d, dim3(gkp), blk, 0, st, lvl, c, B.kp, B.state, R, B.dirs);
+        hipLaunchKernelGGL(k_blur, grd, blk, 0, st, lvl, r, c, B.aux);                    // the score map is no longer needed
+        hipLaunchKernelGGL(k_describe_d, dim3(gkp), blk, 0, st, B.aux, c, B.kp, B.state, B.pat, B.desc);
+        hipLaunchKernelGGL(k_lvl_end, dim3(1), dim3(1), 0, st, B.state);
+        HIP_TRY(hipGetLastError());
+    }
+    {
+        DState *hs = reinterpret_cast<DState *>(ws->h_small);
+        HIP_TRY(hipMemcpyAsync(hs, B.state, sizeof(DState), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        if (hs->flags) { *overflow = true; return SID_PM_OK; }
+        const int64_t n = (int64_t)hs->total;
+        if (n > 0) {
+            HIP_TRY(hipMemcpyAsync(xy, B.xy, (size_t)n * 2 * sizeof(float), hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipMemcpyAsync(desc, B.desc, (size_t)n * 32, hipMemcpyDeviceToHost, st));
+            if (meta) HIP_TRY(hipMemcpyAsync(meta, B.kp, (size_t)n * 4 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+            if (response) HIP_TRY(hipMemcpyAsync(response, B.resp, (size_t)n * sizeof(long long), hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+        }
+        *total_out = n;
+    }
+done:
+    return rc;
+}
+
 SID_EXPORT const char *sid_orb_last_error(void) { return g_err; }
 
 SID_EXPORT int sid_orb_release(int device)
@@ -364,6 +663,7 @@ SID_EXPORT int sid_orb_detect(int device, const uint8_t *img, int64_t rows, int6
     };
     uint8_t *d_img0 = nullptr, *d_lvl = nullptr, *d_aux = nullptr, *d_desc = nullptr;
     Cand *d_cand = nullptr, *d_sel = nullptr; unsigned int *d_count = nullptr, *d_hist = nullptr;
+    float *d_xy = nullptr; long long *d_resp = nullptr; DState *d_state = nullptr; unsigned int *d_rank = nullptr;
     const unsigned int sel_cap = (unsigned int)std::min<int64_t>((int64_t)4 * (int64_t)P->n_features + 65536, (int64_t)1 << 26);
     int8_t *d_pat = nullptr; int32_t *d_dirs = nullptr, *d_kp = nullptr, *d_dir = nullptr;
     std::vector<Cand> cand;
@@ -388,18 +688,29 @@ SID_EXPORT int sid_orb_detect(int device, const uint8_t *img, int64_t rows, int6
         if (!ws) { rc = fail(SID_PM_ERR_NOMEM, "no detector workspace"); goto done; }
         st = ws->stream;
         HIP_TRY(ws_reserve(ws, 3 * up256(area0) + up256((area0 / 4 + 16) * sizeof(Cand)) + up256((size_t)sel_cap * sizeof(Cand)) + up256(32 * 1024) +
-                               up256(nkp * 4 * sizeof(int32_t)) + up256(nkp * sizeof(int32_t)) + up256(nkp * 32) + 4 * 256 + up256(2048 * sizeof(unsigned int))));
+                               up256(nkp * 4 * sizeof(int32_t)) + up256(nkp * sizeof(int32_t)) + up256(nkp * 32) + 4 * 256 + up256(2048 * sizeof(unsigned int)) +
+                               up256(nkp * 2 * sizeof(float)) + up256(nkp * sizeof(long long)) + 256 + up256((size_t)sel_cap * sizeof(unsigned int))));
         {
             WsCarver cv{ws->blk};
             d_img0 = cv.take<uint8_t>(area0); d_lvl = cv.take<uint8_t>(area0); d_aux = cv.take<uint8_t>(area0);
             d_cand = cv.take<Cand>(area0 / 4 + 16); d_sel = cv.take<Cand>(sel_cap); d_pat = cv.take<int8_t>(32 * 1024);
             d_kp = cv.take<int32_t>(nkp * 4); d_dir = cv.take<int32_t>(nkp); d_desc = cv.take<uint8_t>(nkp * 32);
             d_count = cv.take<unsigned int>(1); d_dirs = cv.take<int32_t>(64); d_hist = cv.take<unsigned int>(2048);
+            d_xy = cv.take<float>(nkp * 2); d_resp = cv.take<long long>(nkp); d_state = cv.take<DState>(1); d_rank = cv.take<unsigned int>(sel_cap);
         }
         HIP_TRY(hipMemcpy2DAsync(d_img0, (size_t)cols, img, (size_t)stride, (size_t)cols, (size_t)rows, hipMemcpyHostToDevice, st));
         HIP_TRY(hipMemcpyAsync(d_pat, pattern, 32 * 1024, hipMemcpyHostToDevice, st));
         HIP_TRY(hipMemcpyAsync(d_dirs, dirs, 64 * sizeof(int32_t), hipMemcpyHostToDevice, st));
         tick("workspace + upload", -1);
+        // the levels on the device from end to end (SID_ORB_HOST_SELECT=1, or the per-stage timing of SID_ORB_VERBOSE: the
+        // host-side selection and sort below; also the route of a call whose selection overflowed)
+        if (!verbose && getenv("SID_ORB_HOST_SELECT") == nullptr) {
+            const DevBufs B{d_img0, d_lvl, d_aux, d_desc, d_cand, d_sel, d_pat, d_dirs, d_kp, d_hist, d_xy, d_resp, d_state, d_rank};
+            bool overflow = false;
+            rc = detect_on_device(ws, B, rows, cols, P, sc, lr, lc, want, sel_cap, xy, meta, response, desc, max_out, &total, &overflow);
+            if (rc != SID_PM_OK || !overflow) { *n_out = rc == SID_PM_OK ? total : 0; goto done; }
+            total = 0;
+        }
         for (int l = 0; l < L && total < max_out; ++l) {
             const int r = lr[l], c = lc[l];
             if (r <= 2 * edge || c <= 2 * edge || want[l] <= 0) continue;

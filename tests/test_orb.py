@@ -85,3 +85,31 @@ def test_detector_calls_from_several_threads_share_nothing():
             assert len(e[0]) > 500
             for a, b in zip(g, e):
                 np.testing.assert_array_equal(a, b)
+
+
+@pytest.mark.gpu
+def test_selection_and_ordering_on_the_device_equal_the_host_route(monkeypatch):
+    """Round 4: the levels run on the device from end to end (radix selection of the level's share by a one-wavefront pick,
+    exact (response, y, x) order by counting) with one synchronisation per image; SID_ORB_HOST_SELECT=1 is the previous route
+    (counts and histograms to the host, std::sort there).  Same key points in the same order, bit for bit - more features than
+    candidates, fewer, a cap by max_out, plateaus of equal responses - and both equal the oracle."""
+    rng = np.random.default_rng(8)
+    big = syn.make_pair(1500, 1300, seed=33)[1]
+    flat = np.full((600, 600), 90, dtype=np.uint8)
+    flat[::40, :] = 200; flat[:, ::40] = 200                           # a lattice: thousands of equal responses
+    noise = rng.integers(0, 256, (500, 700)).astype(np.uint8)
+    for name, img, kw in (('big', big, dict(n_features=30000, n_levels=7)), ('big-few', big, dict(n_features=200, n_levels=3)),
+                          ('lattice', flat, dict(n_features=5000, n_levels=4)), ('noise', noise, dict(n_features=100000, n_levels=5, fast_threshold=10))):
+        monkeypatch.delenv('SID_ORB_HOST_SELECT', raising=False)
+        dev = orb.detect_and_compute(img, full=True, **kw)
+        monkeypatch.setenv('SID_ORB_HOST_SELECT', '1')
+        host = orb.detect_and_compute(img, full=True, **kw)
+        monkeypatch.delenv('SID_ORB_HOST_SELECT')
+        assert len(host[0]) > 50, name
+        for a, b in zip(dev, host):
+            np.testing.assert_array_equal(a, b, err_msg=name)
+    exp_xy, exp_meta, exp_resp, exp_desc = oo.detect_and_compute(flat, orb.rotated_pattern(), orb.direction_table(), n_features=5000, n_levels=4)
+    xy, desc, meta, resp = orb.detect_and_compute(flat, full=True, n_features=5000, n_levels=4)
+    np.testing.assert_array_equal(meta, exp_meta)
+    np.testing.assert_array_equal(resp, exp_resp)
+    np.testing.assert_array_equal(desc, exp_desc)
