@@ -185,10 +185,14 @@ int make_samp(const std::vector<double> &rot, int K, int s, std::vector<uint16_t
 // this differ in nothing.  The row-pair kernel's slot-group layouts (<= 7 angles) have a 128-VGPR build as well, for the
 // borders whose LDS footprint fits four times (SID_PM_NO_OCC4=1: off; A/B runs).
 constexpr int kMaxPerCu = 3;
+constexpr int kW3MaxLds = 40960;   // every window of pitch 104 that fits four times (borders 20 .. 23 at 34 / 35 px; measured per border: tools/r4_w3.sh)
 // four workgroups per CU need the 128-VGPR build of the row-pair kernel (pm_kernel_rp_occ4.hip): the slot-group layouts only.
 // (Round 4 measured it for the full operand table as well - with sum w'^2 in global memory borders 20-26 fit four per CU:
 // border 20 +1.6 %, border 26 +5 % against three per CU with the sums in LDS; not shipped.)  SID_PM_NO_OCC4=1: never (A/B runs)
-int max_per_cu(bool rp, int rpp) { return (rp && rpp > 0 && getenv("SID_PM_NO_OCC4") == nullptr) ? 4 : kMaxPerCu; }
+// Four points per CU with three wavefronts per point (192 threads: 4 x 3 = the 12 wavefronts of 168 VGPRs a CU holds; pitch codes
+// 1104 / 2104: pm_kernel.h rp_pitch_is_w3) - the smallest windows only (SID_PM_W3_MAX_LDS: footprint up to which the class is used; SID_PM_NO_W3=1: never; A/B runs)
+int w3_max_lds() { const char *e = getenv("SID_PM_W3_MAX_LDS"); return getenv("SID_PM_NO_W3") ? 0 : e ? atoi(e) : kW3MaxLds; }
+int max_per_cu(bool rp, int rpp) { return (rp && (w3_max_lds() > 0 || (rpp > 0 && getenv("SID_PM_NO_OCC4") == nullptr))) ? 4 : kMaxPerCu; }
 
 int blocks_per_cu(int lds)
 {
@@ -256,7 +260,7 @@ bool rp_own_hes(int K, uint32_t flags) { return K > sid::kRpGroup || (flags & (S
 // instantiation of the launch's window pitch does: sid::rp_pitch_is_gs)
 int lds_need(bool rp, int rpp, int wh, int ww, int s, int K, uint32_t flags, int band = 4, int pitch = 0, bool gs = true)
 {
-    if (rp) return sid::rp_lds_layout(wh, ww, s, K <= sid::kRpGroup, rp_rows(rpp, band), pitch, sid::rp_tab_pitch(rpp), rp_own_hes(K, flags), gs).total;
+    if (rp) return sid::rp_lds_layout(wh, ww, s, K <= sid::kRpGroup, rp_rows(rpp, band), sid::rp_pitch_bytes(pitch), sid::rp_tab_pitch(rpp), rp_own_hes(K, flags), gs).total;
     return sid::mfma_lds_layout(wh, ww, s, band, use_paired(K) && band == 4).total;
 }
 
@@ -315,7 +319,7 @@ int fill_args(sid_pm_ctx *ctx, sid::PMArgs &A)
 // kernel - whether sum w'^2 per placement lives in global memory (gs).  gs costs ~5 % where it changes nothing and buys
 // -10 .. -17 % where its smaller footprint lifts the shape into the next residency class, so it is chosen exactly there;
 // and wherever only a gs instantiation exists (window pitch above 112, the 8-row-band kernel, the run-time pitch).
-struct ShapeClass { bool gs; int band, cls, lds, nat_pitch; bool big = false; };   // big: cls 0, a launch of its own (one workgroup per CU)
+struct ShapeClass { bool gs; int band, cls, lds, nat_pitch; bool big = false; int w3_pitch = 0; };   // w3_pitch: pitch code of the three-wavefront class (0: not in it)   // big: cls 0, a launch of its own (one workgroup per CU)
 ShapeClass shape_class(bool rp, int rpp, int wh, int ww, int s, int K, uint32_t flags, bool band8_ok, bool force_gs)
 {
     auto eval = [&](bool gs) {
@@ -333,7 +337,21 @@ ShapeClass shape_class(bool rp, int rpp, int wh, int ww, int s, int K, uint32_t 
     };
     if (!rp) return eval(false);
     ShapeClass g = eval(true);
-    g.cls = std::min(g.cls, 3);                                        // (no four-per-CU build with gs: see below)
+    // (no four-per-CU build with gs - except the three-wavefront class of the full table, for the smallest windows)
+    // The three-wavefront class: window pitch 104 (borders 20 .. 23) and a footprint that fits four times - with the sums in LDS
+    // where that fits (slot groups, borders 20 / 21: no gs cost), else in global memory.  (Pitch 112 - borders 24 .. 28 - measured:
+    // full table +-0 / +0.5 / +4 %, three angles +1.5 / +-0 %, seven angles +1 %: not instantiated.)
+    if (K <= sid::kRpGroup && g.band == 4 && g.nat_pitch <= 104 && !force_gs) {
+        const int cp = sid::rp_class_pitch(g.nat_pitch);
+        for (int code : {2000 + cp, 1000 + cp}) {
+            const bool cgs = code < 2000;
+            const int need = lds_need(rp, rpp, wh, ww, s, K, flags, 4, code, cgs);
+            if (need <= std::min(w3_max_lds(), 32 * 1280) && sid::rp_pitch_instantiated(4, rpp, code)) {
+                ShapeClass c = g; c.gs = cgs; c.cls = 4; c.lds = need; c.w3_pitch = code; return c;
+            }
+        }
+    }
+    g.cls = std::min(g.cls, 3);
     if (g.lds > sid::max_lds_bytes() && getenv("SID_PM_NO_BIG") == nullptr) {   // beyond the LDS even so: the tables go to global memory
         const sid::RpLdsLayout B = big_layout(wh, ww, s, K, flags);
         if (B.total <= sid::max_lds_bytes()) return ShapeClass{true, 4, 0, B.total, B.wpitch, true};
@@ -364,7 +382,7 @@ int classify_points(sid_pm_ctx *ctx)
     static const bool no_fixed_pitch = getenv("SID_PM_NO_FIXED_PITCH") != nullptr;         // (run-time pitch everywhere: gs instantiations; A/B runs)
     // Everything the launch needs to know about a point follows from the SHAPE of its search window, and a run has a few
     // dozen shapes (one per border): the LDS layouts are evaluated per shape, the points are only binned.
-    struct Shape { int wh, ww, lds, band, cls, nat_pitch, pitch; double work; std::vector<int32_t> idx; bool gs = false, big = false; };
+    struct Shape { int wh, ww, lds, band, cls, nat_pitch, pitch; double work; std::vector<int32_t> idx; bool gs = false, big = false; int w3p = 0; };
     std::vector<Shape> shapes;
     std::vector<int32_t> slot_of((size_t)1 << 16, -1);                // (wh, ww) -> shape, direct-mapped on a hash of the pair
     auto find_shape = [&](int wh, int ww) -> int {
@@ -394,7 +412,7 @@ int classify_points(sid_pm_ctx *ctx)
             if (sc.lds > sid::max_lds_bytes())
                 return fail(SID_PM_ERR_UNSUPPORTED, "point %lld: search window %dx%d needs %d bytes of LDS (> %d)",
                             (long long)i, wh, ww, sc.lds, sid::max_lds_bytes());
-            sh.lds = sc.lds; sh.band = sc.band; sh.cls = sc.cls; sh.gs = sc.gs; sh.nat_pitch = sc.nat_pitch; sh.big = sc.big;
+            sh.lds = sc.lds; sh.band = sc.band; sh.cls = sc.cls; sh.gs = sc.gs; sh.nat_pitch = sc.nat_pitch; sh.big = sc.big; sh.w3p = sc.w3_pitch;
             sh.work = (double)(wh - s + 1) * (double)(ww - s + 1);
             k = (int)shapes.size();
             shapes.push_back(sh);
@@ -415,6 +433,7 @@ int classify_points(sid_pm_ctx *ctx)
         if (x.cls != y.cls) return x.cls < y.cls;
         if (x.band != y.band) return x.band < y.band;
         if (x.gs != y.gs) return x.gs;                                // (gs first: the larger windows of a class)
+        if (x.w3p != y.w3p) return x.w3p > y.w3p;                     // (three-wavefront class: one launch per window pitch)
         if (x.work != y.work) return x.work > y.work;
         return x.idx[0] < y.idx[0];
     });
@@ -428,11 +447,12 @@ int classify_points(sid_pm_ctx *ctx)
             size_t b = a + 1;
             const Shape &first = shapes[(size_t)ord[a]];
             while (b < ord.size() && shapes[(size_t)ord[b]].cls == first.cls && shapes[(size_t)ord[b]].band == first.band &&
-                   shapes[(size_t)ord[b]].gs == first.gs) ++b;
+                   shapes[(size_t)ord[b]].gs == first.gs && shapes[(size_t)ord[b]].w3p == first.w3p) ++b;
             const bool gs = first.gs;
             int nat = gs ? 136 : 0;
             for (size_t i = a; i < b; ++i) nat = std::max(nat, shapes[(size_t)ord[i]].nat_pitch);
             int pitch = (nat > 0 && !no_fixed_pitch && !first.big) ? sid::rp_class_pitch(nat) : 0;
+            if (first.w3p) pitch = first.w3p;                                  // (the three-wavefront class: its own instantiations)
             if (pitch && !sid::rp_pitch_instantiated(first.band, rpp, pitch)) pitch = 0;
             for (size_t i = a; i < b && pitch; ++i) {
                 const Shape &sh = shapes[(size_t)ord[i]];
@@ -784,7 +804,7 @@ SID_EXPORT int sid_pm_run(sid_pm_ctx *ctx)
         // two-per-CU class, border 28: 256 threads 5.8 ms, 384: 9.1, 512: 7.8, 768: 7.8 - six wavefronts per group
         // land 2/2/1/1 on the SIMDs, a second group of 168-VGPR wavefronts then no longer fits.)
         const int per_cu = std::max(1, std::min(b.band == 8 ? 2 : 8, blocks_per_cu(b.lds)));
-        const int nthreads = b.band == 8 ? 256 : (per_cu == 1 ? 768 : 256);
+        const int nthreads = b.band == 8 ? 256 : (per_cu == 1 ? 768 : (ctx->rp && sid::rp_pitch_is_w3(b.pitch)) ? 192 : 256);
         const int e = ctx->rp
                           ? sid::launch_pm_rp(A, lds_launch, nthreads, b.band, b.big ? 0 : ctx->rp_paired, b.pitch, b.occ, ctx->stream, b.big)
                           : sid::launch_pm_mfma(A, lds_launch, nthreads, b.band, use_paired(ctx->n_angles), ctx->stream);
@@ -1089,9 +1109,9 @@ static int estimate_points(const double *border, int64_t n, int img_size, int n_
     // tools/border_cost.py on the shipped library, one set per kernel family - full table / two / four slot groups - within
     // 2.3 / 4.3 / 7 % of the measured staircase (profiles/r04_border_cost.json)
     struct Fit { double sweep, winner, pos, fixed, two, one, gs, four; };
-    static const Fit kFit[3] = {{3.4646e-3, 2.2848e-2, 7.6082e-3, 29.955, 1.1228, 1.2800, 1.06500, 0.93000},
-                                {3.9853e-3, 1.7996e-2, 7.6297e-3, 25.686, 1.2348, 1.3287, 0.99236, 0.95706},
-                                {2.5923e-3, 1.8513e-2, 6.4734e-3, 24.173, 1.2518, 1.3574, 1.00890, 0.98625}};
+    static const Fit kFit[3] = {{3.4646e-3, 2.2848e-2, 7.6082e-3, 29.955, 1.1228, 1.2800, 1.06500, 0.88700},
+                                {3.9853e-3, 1.7996e-2, 7.6297e-3, 25.686, 1.2348, 1.3287, 0.99236, 0.91000},
+                                {2.5923e-3, 1.8513e-2, 6.4734e-3, 24.173, 1.2518, 1.3574, 1.00890, 0.86000}};   // (last column: the three-wavefront class, refitted to tools/r4_w3.sh / r4_w3p.sh)
     const Fit &F = kFit[rpp];
     constexpr double kBigFactor = 1.25;   // every per-placement table through L2 / HBM (measured at borders 70 .. 100: tools/border_cost.py)
     const double kSweep = F.sweep, kWinner = F.winner, kPos = F.pos, kFixed = F.fixed, kTwoPerCu = F.two, kOnePerCu = F.one, kFourPerCu = F.four;
@@ -1116,7 +1136,7 @@ static int estimate_points(const double *border, int64_t n, int img_size, int n_
             sweep = groups * (sc.big ? 1.0 : rpp == 2 ? 0.33 : rpp == 1 ? 0.55 : 1.0) * units * (rows * per_row_tile + 2.0);
             winner = wunits * 76.0;
             cls_factor = ((per_cu >= 4 && max_per_cu(rp, rpp) == 4) ? kFourPerCu : per_cu >= 3 ? 1.0 : per_cu == 2 ? kTwoPerCu : kOnePerCu) * (sc.gs ? F.gs : 1.0) * (sc.big ? kBigFactor : 1.0);
-            cls = std::max(1, std::min(per_cu, max_per_cu(rp, rpp))) + (sc.gs ? 16 : 0) + (sc.big ? 32 : 0);   // (+ 16: the launches that keep sum w'^2 in global memory are launches of their own)
+            cls = std::max(1, std::min(per_cu, max_per_cu(rp, rpp))) + (sc.gs ? 16 : 0) + (sc.big ? 32 : 0) + (sc.w3_pitch > 1104 ? 64 : 0);   // (+ 64: the second launch of the three-wavefront class)   // (+ 16: the launches that keep sum w'^2 in global memory are launches of their own)
         } else {
             const sid::MfmaLdsLayout L = sid::mfma_lds_layout(wn, wn, s, 4, use_paired(K));
             const int per_cu = blocks_per_cu(L.total), ntx = (r + 15) / 16;

@@ -183,7 +183,11 @@ __host__ __device__ constexpr int rp_tab_shift(int paired) { return paired == 2 
 // own_hes (gs only): the Hessian magnitudes get LDS of their own behind the winner's NCC matrix (the general ph_hessian -
 // hes_smth / mcc_norm, several groups of angles - keeps its histograms in the winner's operand block); otherwise they lie
 // over the window and the winner's operands, both dead by then (the NCC matrix moves up where those are too short).
-__host__ __device__ constexpr bool rp_pitch_is_gs(int pitch) { return pitch == 0 || pitch >= 136; }
+// Pitch CODES from 1000 up name the instantiations of the three-wavefront class (round 4: 192 threads per point, four points
+// per CU with the 168-VGPR build): window pitch = code % 1000; 1000 + pitch keeps the sums in global memory, 2000 + pitch in LDS.
+__host__ __device__ constexpr int rp_pitch_bytes(int pitch) { return pitch % 1000; }
+__host__ __device__ constexpr bool rp_pitch_is_w3(int pitch) { return pitch >= 1000; }
+__host__ __device__ constexpr bool rp_pitch_is_gs(int pitch) { return pitch == 0 || rp_pitch_bytes(pitch) >= 136 || (pitch >= 1000 && pitch < 2000); }
 // big (gs only; search borders 69 .. ~100 at s = 34, whose per-placement tables no longer fit the 160 KB): the row sums of
 // rp_sums, the NCC matrix of the winning angle and the Hessian magnitudes live in the point's block of GLOBAL memory as well
 // - [sum w'^2 | row sums, later the NCC matrix | Hessian magnitudes], 256-byte aligned; ccm_off / hes_off are byte offsets

@@ -456,13 +456,13 @@ __device__ __forceinline__ void take_better(Score &sc, float rv, int key)
 // region is free already) is fetched in the same round trip: its loads are issued before the window's.
 // PRIO >= 0: the wave priority of the phases up to the sweep, set here - inside a non-inlined phase - rather than in the kernel
 // body (pm_kernel_rp.inc: SID_SETPRIO_TS)
-template <bool PATCH, int PRIO = -1>
+template <bool PATCH, int PRIO = -1, int KWIN = 10, int KPAT = 4>
 __device__ __noinline__ void ph_window_t(const uint8_t *img2, long long rows2, long long cols2, long long stride2,
                                          const uint8_t *img1, long long rows1, long long cols1, long long stride1)
 {
     if (PRIO >= 0) __builtin_amdgcn_s_setprio(PRIO);
     SID_PHASE_LOCALS;
-    constexpr int kPat = 4;                                            // patch dwords per thread and trip (ph_patch)
+    constexpr int kPat = KPAT;                                         // patch dwords per thread and trip (ph_patch)
     u32 plo[kPat] = {}, phi[kPat] = {}, psh[kPat] = {};
     const int pdw = G.ppitch >> 2, pndw = G.pdim * pdw;
     if (PATCH) {
@@ -502,7 +502,7 @@ __device__ __noinline__ void ph_window_t(const uint8_t *img2, long long rows2, l
     const u32 last_off = last_ll > 0x7ffffff0ll ? 0x7ffffff0u : (u32)last_ll;  // offset of the last legal dword
     // kWin dwords per thread and round trip: the common small windows (border <= 23 at 256 threads) load in
     // one trip, i.e. one HBM/L2 latency per point
-    constexpr int kWin = 10;
+    constexpr int kWin = KWIN;
     for (int base = 0; base < ndw; base += kWin * kBlockM) {
         u32 lo[kWin], hi[kWin], shv[kWin];
         int rowv[kWin], dqv[kWin];
@@ -2060,12 +2060,12 @@ int launch_pm_mfma(const PMArgs &args, int lds_bytes, int nthreads, int band, bo
 template <int S>
 static void (*rp_kernel_for(int band, int paired, int pitch))(const PMArgs)
 {
-    if (paired == 2) return pitch == 104 ? pm_kernel_rp<S, 4, 2, 104> : pitch == 112 ? pm_kernel_rp<S, 4, 2, 112> : pitch == 136 ? pm_kernel_rp<S, 4, 2, 136>
+    if (paired == 2) return pitch == 2104 ? pm_kernel_rp<S, 4, 2, 2104> : pitch == 1104 ? pm_kernel_rp<S, 4, 2, 1104> : pitch == 104 ? pm_kernel_rp<S, 4, 2, 104> : pitch == 112 ? pm_kernel_rp<S, 4, 2, 112> : pitch == 136 ? pm_kernel_rp<S, 4, 2, 136>
                           : pitch == 168 ? pm_kernel_rp<S, 4, 2, 168> : pitch == 0 ? pm_kernel_rp<S, 4, 2, 0> : nullptr;
-    if (paired == 1) return pitch == 104 ? pm_kernel_rp<S, 4, 1, 104> : pitch == 112 ? pm_kernel_rp<S, 4, 1, 112> : pitch == 136 ? pm_kernel_rp<S, 4, 1, 136>
+    if (paired == 1) return pitch == 2104 ? pm_kernel_rp<S, 4, 1, 2104> : pitch == 1104 ? pm_kernel_rp<S, 4, 1, 1104> : pitch == 104 ? pm_kernel_rp<S, 4, 1, 104> : pitch == 112 ? pm_kernel_rp<S, 4, 1, 112> : pitch == 136 ? pm_kernel_rp<S, 4, 1, 136>
                           : pitch == 168 ? pm_kernel_rp<S, 4, 1, 168> : pitch == 0 ? pm_kernel_rp<S, 4, 1, 0> : nullptr;
     if (band == 8) return pitch == 136 ? pm_kernel_rp<S, 8, 0, 136> : pitch == 168 ? pm_kernel_rp<S, 8, 0, 168> : pitch == 0 ? pm_kernel_rp<S, 8, 0, 0> : nullptr;
-    return pitch == 104 ? pm_kernel_rp<S, 4, 0, 104> : pitch == 112 ? pm_kernel_rp<S, 4, 0, 112> : pitch == 136 ? pm_kernel_rp<S, 4, 0, 136>
+    return pitch == 104 ? pm_kernel_rp<S, 4, 0, 104> : pitch == 112 ? pm_kernel_rp<S, 4, 0, 112> : pitch == 136 ? pm_kernel_rp<S, 4, 0, 136> : pitch == 1104 ? pm_kernel_rp<S, 4, 0, 1104>
          : pitch == 168 ? pm_kernel_rp<S, 4, 0, 168> : pitch == 0 ? pm_kernel_rp<S, 4, 0, 0> : nullptr;
 }
 
@@ -2092,7 +2092,7 @@ int launch_pm_rp(const PMArgs &args, int lds_bytes, int nthreads, int band, int 
     if (!kern) return (int)hipErrorInvalidValue;
     const hipError_t e = allow_max_lds(kern);
     if (e != hipSuccess) return (int)e;
-    if (lds_bytes > max_lds_bytes() || nthreads < 256 || nthreads > 768 || (nthreads & 63)) return (int)hipErrorInvalidValue;
+    if (lds_bytes > max_lds_bytes() || nthreads < 192 || nthreads > 768 || (nthreads & 63)) return (int)hipErrorInvalidValue;
     hipLaunchKernelGGL(kern, dim3(args.n_launch), dim3(nthreads), lds_bytes, st, args);
     return (int)hipGetLastError();
 }

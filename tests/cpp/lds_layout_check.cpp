@@ -107,6 +107,14 @@ int main()
         const RpLdsLayout a = rp_lds_layout(75, 75, 34, true, 4, 112, 512, false, false), b = rp_lds_layout(77, 77, 34, true, 4, 112, 512, false, false);
         CHECK(a.si_off != 0 && a.total <= 42 * 1280 && b.si_off == 0, "kept sums at border 20 only (%d, %d)", a.total, b.total);
     }
+    // the three-wavefront class of the full table (pitch code 1104): borders 20 .. 23 with the sums in global memory fit FOUR times
+    for (int b = 20; b <= 24; ++b) {
+        const int w = 35 + 2 * b;
+        const RpLdsLayout L = rp_lds_layout(w, w, 34, true, 4, rp_pitch_bytes(1104), 512, false, true);
+        if (b <= 23) CHECK(L.total <= 32 * 1280 && L.wpitch == 104 && L.queue_cap >= kRpQueueMin, "border %d: %d bytes, four per CU expected", b, L.total);
+        else CHECK(L.wpitch > 104, "border 24 keeps a window pitch of 104?");
+    }
+    static_assert(rp_pitch_is_gs(1104) && rp_pitch_is_w3(1104) && !rp_pitch_is_w3(168) && rp_pitch_bytes(1104) == 104 && rp_pitch_bytes(136) == 136, "pitch codes");
     printf("%d violations\n", bad);
     return bad > 100 ? 100 : bad;
 }

@@ -57,29 +57,35 @@ def test_small_pair_matches_oracle(pm_ctx, c_oracle, s, alpha0, angles):
 
 @pytest.mark.parametrize('s,angles', [(34, ANGLES7), (34, [-3, 0, 3]), (35, [-3, 0, 3])])
 def test_four_per_cu_build_equals_the_three_per_cu_build_and_the_oracle(pm_ctx, c_oracle, monkeypatch, s, angles):
-    """Slot-group layouts at borders 20 and 21 fit four workgroups per CU and run the 128-VGPR build of the row-pair kernel
-    (pm_kernel_rp_occ4.hip); borders 22 .. 30 exercise the short operand table in the other launch classes.  Both builds
-    against the oracle, and bit-identical to each other (SID_PM_NO_OCC4 is read at every set_points)."""
+    """Slot-group layouts: borders 20 .. 23 run the three-wavefront class (four points per CU with the 168-VGPR build; round 4);
+    without it (SID_PM_NO_W3) borders 20 and 21 run the 128-VGPR build of round 3 (pm_kernel_rp_occ4.hip), without that
+    (SID_PM_NO_OCC4) three per CU; borders 22 .. 30 exercise the short operand table in the other launch classes.  All three
+    against the oracle, and bit-identical to each other (the switches are read at every set_points)."""
     img1, img2 = syn.make_pair(900, 900, seed=11)
     g = syn.make_grid(900, 900, 14, margin=120)
     n = len(g['c1'])
-    border = np.array([20, 21, 20, 22, 26, 21, 30, 20][:8] * (n // 8 + 1), dtype=np.float64)[:n]
+    border = np.array([20, 21, 20, 22, 26, 21, 30, 23][:8] * (n // 8 + 1), dtype=np.float64)[:n]
     rot = rot_for(angles, 0.0, s)
     exp, exp_ij = c_oracle.pm_batch(img1, img2, g['c1'], g['r1'], g['c2fg'], g['r2fg'], border, s, 0.0, angles, rot=rot,
                                     nthreads=8)
     pm_ctx.upload_pair(img1, img2)
     res = []
-    for no_occ4 in (False, True):
-        if no_occ4:
-            monkeypatch.setenv('SID_PM_NO_OCC4', '1')
+    for envs in ((), ('SID_PM_NO_W3',), ('SID_PM_NO_W3', 'SID_PM_NO_OCC4')):
+        for k in ('SID_PM_NO_W3', 'SID_PM_NO_OCC4'):
+            monkeypatch.delenv(k, raising=False)
+        for k in envs:
+            monkeypatch.setenv(k, '1')
         pm_ctx.set_points(g['c1'], g['r1'], g['c2fg'], g['r2fg'], border, s, 0.0, angles, rot=rot)
         pm_ctx.run()
         got, got_ij = pm_ctx.fetch()
         assert_parity(got, got_ij, exp, exp_ij)
         res.append((got.copy(), got_ij.copy(), pm_ctx.work_info()['launches']))
-    np.testing.assert_array_equal(res[0][0], res[1][0])
-    np.testing.assert_array_equal(res[0][1], res[1][1])
-    assert res[0][2] > res[1][2]                     # borders 20 and 21 were a launch of their own
+    for k in ('SID_PM_NO_W3', 'SID_PM_NO_OCC4'):
+        monkeypatch.delenv(k, raising=False)
+    for r in res[1:]:
+        np.testing.assert_array_equal(res[0][0], r[0])
+        np.testing.assert_array_equal(res[0][1], r[1])
+    assert res[1][2] > res[2][2] and res[0][2] > res[2][2]   # borders 20 and 21 (20 .. 23) were launches of their own
 
 
 def test_sampling_table_flagged_entries_and_fractional_centres(pm_ctx, c_oracle):
@@ -336,3 +342,44 @@ def test_borders_69_to_111_keep_their_tables_in_global_memory(pm_ctx, c_oracle, 
     with pytest.raises(_capi.SidPmError) as e:
         pm_ctx.set_points(c1[:1], r1[:1], c2[:1], r2[:1], [112.0], s, 0.0, angles, rot=rot)
     assert e.value.code == -4
+
+
+@pytest.mark.parametrize('s,angles', [(34, ANGLES15), (35, ANGLES15), (35, [-3, 0, 3]), (34, ANGLES7)])
+def test_three_wavefronts_per_point_class_equals_four_and_the_oracle(pm_ctx, c_oracle, monkeypatch, s, angles):
+    """Round 4: the smallest windows (borders 20 .. 23, window pitch 104) run FOUR points per CU with three wavefronts each
+    (192 threads; pm_kernel_rp<S, 4, *, 1104> with the sums in global memory, <.., 2104> with the sums in LDS where a slot-group
+    layout still fits four times); SID_PM_NO_W3=1 is round 3's classes of 256 threads.  Both equal the oracle, bit for bit each other - also with the on-the-fly sampler (fractional centres) and at the
+    image edge, where the patch cannot ride with the window."""
+    size = 900
+    img1, img2 = syn.make_pair(size, size, seed=41)
+    rng = np.random.default_rng(6)
+    borders = np.repeat(np.arange(20, 25), 24).astype(np.float64)
+    n = len(borders)
+    c1 = np.rint(rng.uniform(60, size - 60, n)); r1 = np.rint(rng.uniform(60, size - 60, n))
+    c1[::7] += 0.37; r1[::5] -= 0.41                                   # fractional template centres: the general sampler
+    c1[:4] = [30.0, size - 31.0, 400.0, 400.0]; r1[:4] = [400.0, 400.0, 30.0, size - 31.0]   # template patch cut by the image edge
+    dc, dr = syn.true_displacement(c1, r1)
+    c2 = np.clip(c1 + np.rint(dc) + rng.integers(-2, 3, n), 70, size - 70); r2 = np.clip(r1 + np.rint(dr) + rng.integers(-2, 3, n), 70, size - 70)
+    rot = rot_for(angles, 0.0, s)
+    exp, exp_ij = c_oracle.pm_batch(img1, img2, c1, r1, c2, r2, borders, s, 0.0, angles, rot=rot, nthreads=8)
+    assert np.isfinite(exp[:, 0]).sum() > n * 0.8
+    pm_ctx.upload_pair(img1, img2)
+    res = []
+    for env in (None, 'SID_PM_NO_W3'):
+        monkeypatch.delenv('SID_PM_NO_W3', raising=False)
+        if env:
+            monkeypatch.setenv(env, '1')
+        pm_ctx.set_points(c1, r1, c2, r2, borders, s, 0.0, angles, rot=rot)
+        per_cu = _capi.estimate_residency(borders[::24], s, len(angles))
+        pm_ctx.run()
+        got, got_ij = pm_ctx.fetch()
+        assert_parity(got, got_ij, exp, exp_ij)
+        res.append((got, got_ij, per_cu))
+    monkeypatch.delenv('SID_PM_NO_W3', raising=False)
+    np.testing.assert_array_equal(res[0][1], res[1][1])
+    np.testing.assert_array_equal(res[0][0][:, :4], res[1][0][:, :4])
+    # the launch classes the host predicts: four per CU up to border 23 (without the class: the full table three per CU)
+    cls = [int(v) & 15 for v in res[0][2]]
+    assert cls[:3] == [4, 4, 4] and cls[4] == 3 and cls[3] in (3, 4)    # (border 23 at 35 px: one granule too many)
+    if len(angles) > 7:
+        assert [int(v) & 15 for v in res[1][2]] == [3, 3, 3, 3, 3]

@@ -39,5 +39,14 @@ run 4000 200 --angles 1 --border 42
 SID_PM_ALWAYS_GS=1 run 4000 300 --angles 7 --border 20
 SID_PM_ALWAYS_GS=1 run 4000 300 --angles 3
 SID_PM_NO_GS=1 run 4000 300 --angles 7
+# round 4 (late): three wavefronts per point and four points per CU (full table, borders 20 .. 23), the per-XCD pool of
+# global-memory blocks, search borders beyond the LDS (tables in global memory)
+run 4000 500 --angles 7 --border 20
+run 4000 400 --angles 7 --border 23
+run 4000 300 --angles 7 --border 21 --img-size 35
+run 10000 100 --angles 7 --border 20
+run 3000 40 --angles 7 --border 80
+SID_PM_NO_W3=1 run 4000 200 --angles 7 --border 20
+SID_PM_NO_GS_POOL=1 run 4000 200 --angles 7
 echo "library md5 $(md5sum $R/sea_ice_drift_amd/libsid_pm.so | cut -d' ' -f1)" >> $OUT
 cat $OUT
