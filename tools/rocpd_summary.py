@@ -16,7 +16,7 @@ def main(path, kernel_filter='pm_kernel'):
     for name, calls, total, avg, pct in db.execute('select name,total_calls,total_duration*1000,average*1000,'
                                                    'percentage from top_kernels'):
         print('%-70s %8d %14.0f %12.0f %8.3f' % (name[:70], calls, total, avg, pct))
-    rows = list(db.execute("select dispatch_id, grid_x, workgroup_x, lds_size, vgpr_count, sgpr_count, "
+    rows = list(db.execute("select dispatch_id, grid_x * max(grid_y, 1) * max(grid_z, 1), workgroup_x, lds_size, vgpr_count, sgpr_count, "
                            "scratch_size, duration from kernels where name like ? order by dispatch_id",
                            ('%' + kernel_filter + '%',)))
     if rows:
