@@ -93,6 +93,7 @@ struct sid_pm_ctx {
     uint16_t *d_samp = nullptr;         // sampling table of the kernel (make_samp)
     bool rp = false;                    // the resident points run the row-pair kernel (decided at set_points: use_rp) ...
     int rp_paired = 0;                  // ... with slot groups: 0 none, 1 two groups (<= 7 angles), 2 four groups (<= 3 angles)
+    bool gs_keep_si = true;             // the blocks of global memory are sized for sum w' as well (classify_points; SID_PM_NO_GSI=1: not)
     bool have_samp = false;             // SID_PM_NO_SAMP_TABLE=1 keeps the on-the-fly sampling (tests of the general sampler)
     int samp_nflag = 0;
     // host copies of what the classification needs: the launch classes depend on the shape of image 2, so a
@@ -270,6 +271,10 @@ sid::RpLdsLayout big_layout(int wh, int ww, int s, int K, uint32_t flags)
     return sid::rp_lds_layout(wh, ww, s, K <= sid::kRpGroup, 4, 0, 512, rp_own_hes(K, flags), true, true);
 }
 
+// full-table row-pair launches with the sums in global memory also keep sum w' there (the winner then multiplies no all-ones
+// operand); decided when the blocks are sized (classify_points) and remembered for the launches (SID_PM_NO_GSI=1: off - A/B runs)
+bool gs_keep_si(const sid_pm_ctx *ctx) { return ctx->rp && ctx->rp_paired == 0 && ctx->gs_keep_si; }
+
 int check_sweep(int img_size, const double *angles, int n_angles, uint32_t flags)
 {
     if (!angles || n_angles < 1)
@@ -308,6 +313,7 @@ int fill_args(sid_pm_ctx *ctx, sid::PMArgs &A)
     A.refused = ctx->h_refused;
     A.gsii = ctx->gsii.p; A.gsii_off = ctx->d_goff.p; A.rec = ctx->d_rec.p;
     A.gs_pool = ctx->gs_pool.p; A.gs_pool_stride = 0;
+    A.gs_keep_si = gs_keep_si(ctx) ? 1u : 0u;
     if (getenv("SID_PM_DEBUG_CHECK")) {
         if (!ctx->dbg_err.p && ctx->dbg_err.reserve(320) == SID_PM_OK) (void)hipMemset(ctx->dbg_err.p, 0, 320 * sizeof(int32_t));
         A.dbg_err = ctx->dbg_err.p;
@@ -393,6 +399,7 @@ int classify_points(sid_pm_ctx *ctx)
             if (shapes[(size_t)k].wh == wh && shapes[(size_t)k].ww == ww) return k;
         }
     };
+    ctx->gs_keep_si = getenv("SID_PM_NO_GSI") == nullptr;
     const uint32_t flags = ctx->flags;
     const int lds_min = lds_need(rp, rpp, s + 1, s + 1, s, K, flags, 4, 0, false);
     {   // shape 0: points whose window does not lie inside image 2 (they write NaN at once; minimal footprint)
@@ -419,7 +426,8 @@ int classify_points(sid_pm_ctx *ctx)
         }
         Shape &sh = shapes[(size_t)k];
         sh.idx.push_back((int32_t)i);
-        gran_of[(size_t)i] = sh.big ? (uint32_t)(big_layout(wh, ww, s, K, flags).big_bytes / 256) : ((uint32_t)((wh - s + 1) * (ww - s + 1)) * 4u + 255u) / 256u;
+        // (full table: sum w' per placement, kept by the sweep for the winner, lies behind sum w'^2 - twice the block)
+        gran_of[(size_t)i] = sh.big ? (uint32_t)(big_layout(wh, ww, s, K, flags).big_bytes / 256) : (((uint32_t)((wh - s + 1) * (ww - s + 1)) * 4u + 255u) / 256u) * (gs_keep_si(ctx) ? 2u : 1u);
         macs += (double)K * sh.work * s * s;
         // window + bounding box of the rotated template + 5 inputs + outputs
         bytes += (double)wh * ww + 51.0 * 51.0 + 40.0 + 52.0;
@@ -508,7 +516,7 @@ int classify_points(sid_pm_ctx *ctx)
             for (size_t i = a; i < b; ++i) {
                 const Shape &sh = shapes[(size_t)ord[i]];
                 if (sh.wh > 0) bk.gs_stride = std::max<uint32_t>(bk.gs_stride, sh.big ? (uint32_t)(big_layout(sh.wh, sh.ww, s, K, flags).big_bytes / 4)
-                                                                                      : (uint32_t)(((sh.wh - s + 1) * (sh.ww - s + 1) * 4 + 255) / 256 * 64));
+                                                                                      : (uint32_t)(((sh.wh - s + 1) * (sh.ww - s + 1) * 4 + 255) / 256 * 64) * (gs_keep_si(ctx) ? 2u : 1u));
             }
         constexpr int64_t kXcd = 8;
         const int64_t L = (int64_t)src->size(), m = (L + kXcd - 1) / kXcd;

@@ -52,7 +52,8 @@ struct PMArgs {
     // (the eight L2s are not coherent with each other inside a kernel).  gs_pool_stride = 0: no pool - the exclusive block of
     // the launch position (gsii_off), which is also what a workgroup uses whose registers read unexpectedly.
     uint32_t *gs_pool;                              // [8 XCDs][kGsPoolSlots][gs_pool_stride]
-    uint32_t gs_pool_stride;                        // u32 entries per slot in this launch (the largest block of its points, 256-byte granules)
+    uint32_t gs_pool_stride;
+    uint32_t gs_keep_si;                            // blocks of global memory hold 2 x round_up(placements, 64) entries: sum w'^2, then sum w' kept by the sweep for the winner                        // u32 entries per slot in this launch (the largest block of its points, 256-byte granules)
     // diagnostics (debug_point only; null in production launches)
     uint8_t *dbg_templates; float *dbg_ccm; float *dbg_hes; int32_t *dbg_shape; int64_t dbg_cap;
     long long *dbg_cycles;                          // [32] shader-clock stamps at phase boundaries

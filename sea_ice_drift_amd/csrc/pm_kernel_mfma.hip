@@ -106,6 +106,7 @@ struct Geo {
     int queue_cap;                   // row-pair kernel: entries of the candidate queue (RpLdsLayout::queue_cap)
     int hes_off, ccm_off;            // Hessian magnitudes and NCC matrix of the winning angle (f32 per placement)
     int si_off;                      // row-pair kernel: sum w' per placement kept from the sweep for the winner (0: none)
+    int gsi;                         // ... the same in the point's block of global memory, behind sum w'^2: offset in u32 entries (0: none)
     int hist_off;                    // 5 KB behind the NCC matrix of the winning angle for ph_hessian_fast (0: none - the general ph_hessian runs)
     long long r0, c0;                // window origin on image 2
     double c1, r1, nd;

@@ -289,8 +289,9 @@ def test_every_launch_class_incl_global_sums_borders_20_to_68(pm_ctx, c_oracle, 
     assert np.isfinite(exp[:, 0]).sum() > n * 0.9
     pm_ctx.upload_pair(img1, img2)
     results = []
-    for env in (None, 'SID_PM_ALWAYS_GS', 'SID_PM_NO_GS'):
-        for k in ('SID_PM_ALWAYS_GS', 'SID_PM_NO_GS'):
+    for env in (None, 'SID_PM_ALWAYS_GS', 'SID_PM_NO_GS', 'SID_PM_NO_GSI'):
+        # (SID_PM_NO_GSI: sum w' per placement is not kept in the global-memory blocks - the winner multiplies the all-ones operand)
+        for k in ('SID_PM_ALWAYS_GS', 'SID_PM_NO_GS', 'SID_PM_NO_GSI'):
             monkeypatch.delenv(k, raising=False)
         if env:
             monkeypatch.setenv(env, '1')
@@ -302,7 +303,7 @@ def test_every_launch_class_incl_global_sums_borders_20_to_68(pm_ctx, c_oracle, 
     for got, got_ij in results[1:]:
         np.testing.assert_array_equal(got_ij, results[0][1])
         np.testing.assert_array_equal(got[:, :4], results[0][0][:, :4])
-    for k in ('SID_PM_ALWAYS_GS', 'SID_PM_NO_GS'):
+    for k in ('SID_PM_ALWAYS_GS', 'SID_PM_NO_GS', 'SID_PM_NO_GSI'):
         monkeypatch.delenv(k, raising=False)
 
 
