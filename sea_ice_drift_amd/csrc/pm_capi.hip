@@ -190,8 +190,8 @@ constexpr int kW3MaxLds = 40960;   // every window of pitch 104 that fits four t
 // four workgroups per CU need the 128-VGPR build of the row-pair kernel (pm_kernel_rp_occ4.hip): the slot-group layouts only.
 // (Round 4 measured it for the full operand table as well - with sum w'^2 in global memory borders 20-26 fit four per CU:
 // border 20 +1.6 %, border 26 +5 % against three per CU with the sums in LDS; not shipped.)  SID_PM_NO_OCC4=1: never (A/B runs)
-// Four points per CU with three wavefronts per point (192 threads: 4 x 3 = the 12 wavefronts of 168 VGPRs a CU holds; pitch codes
-// 1104 / 2104: pm_kernel.h rp_pitch_is_w3) - the smallest windows only (SID_PM_W3_MAX_LDS: footprint up to which the class is used; SID_PM_NO_W3=1: never; A/B runs)
+// Four points per CU with three wavefronts per point (192 threads: 4 x 3 = the 12 wavefronts of 168 VGPRs a CU holds; pitch code
+// 1104: pm_kernel.h rp_pitch_is_w3) - the smallest windows only (SID_PM_W3_MAX_LDS: footprint up to which the class is used; SID_PM_NO_W3=1: never; A/B runs)
 int w3_max_lds() { const char *e = getenv("SID_PM_W3_MAX_LDS"); return getenv("SID_PM_NO_W3") ? 0 : e ? atoi(e) : kW3MaxLds; }
 int max_per_cu(bool rp, int rpp) { return (rp && (w3_max_lds() > 0 || (rpp > 0 && getenv("SID_PM_NO_OCC4") == nullptr))) ? 4 : kMaxPerCu; }
 
@@ -273,7 +273,7 @@ sid::RpLdsLayout big_layout(int wh, int ww, int s, int K, uint32_t flags)
 
 // full-table row-pair launches with the sums in global memory also keep sum w' there (the winner then multiplies no all-ones
 // operand); decided when the blocks are sized (classify_points) and remembered for the launches (SID_PM_NO_GSI=1: off - A/B runs)
-bool gs_keep_si(const sid_pm_ctx *ctx) { return ctx->rp && ctx->rp_paired == 0 && ctx->gs_keep_si; }
+bool gs_keep_si(const sid_pm_ctx *ctx) { return ctx->rp && ctx->gs_keep_si; }
 
 int check_sweep(int img_size, const double *angles, int n_angles, uint32_t flags)
 {
@@ -344,17 +344,14 @@ ShapeClass shape_class(bool rp, int rpp, int wh, int ww, int s, int K, uint32_t 
     if (!rp) return eval(false);
     ShapeClass g = eval(true);
     // (no four-per-CU build with gs - except the three-wavefront class of the full table, for the smallest windows)
-    // The three-wavefront class: window pitch 104 (borders 20 .. 23) and a footprint that fits four times - with the sums in LDS
-    // where that fits (slot groups, borders 20 / 21: no gs cost), else in global memory.  (Pitch 112 - borders 24 .. 28 - measured:
-    // full table +-0 / +0.5 / +4 %, three angles +1.5 / +-0 %, seven angles +1 %: not instantiated.)
+    // The three-wavefront class: window pitch 104 (borders 20 .. 23), sums in global memory, a footprint that fits four times.
+    // (Pitch 112 - borders 24 .. 28 - measured: full table +-0 / +0.5 / +4 %, three angles +1.5 / +-0 %, seven angles +1 %: not
+    // instantiated.  Sums in LDS - pitch code 2104, slot groups at borders 20 / 21 - won until the blocks of global memory held
+    // sum w' as well; since then the gs form is 1.5 % ahead there too and the code 2104 is no longer instantiated.)
     if (K <= sid::kRpGroup && g.band == 4 && g.nat_pitch <= 104 && !force_gs) {
-        const int cp = sid::rp_class_pitch(g.nat_pitch);
-        for (int code : {2000 + cp, 1000 + cp}) {
-            const bool cgs = code < 2000;
-            const int need = lds_need(rp, rpp, wh, ww, s, K, flags, 4, code, cgs);
-            if (need <= std::min(w3_max_lds(), 32 * 1280) && sid::rp_pitch_instantiated(4, rpp, code)) {
-                ShapeClass c = g; c.gs = cgs; c.cls = 4; c.lds = need; c.w3_pitch = code; return c;
-            }
+        const int code = 1000 + sid::rp_class_pitch(g.nat_pitch), need = lds_need(rp, rpp, wh, ww, s, K, flags, 4, code, true);
+        if (need <= std::min(w3_max_lds(), 32 * 1280) && sid::rp_pitch_instantiated(4, rpp, code)) {
+            ShapeClass c = g; c.gs = true; c.cls = 4; c.lds = need; c.w3_pitch = code; return c;
         }
     }
     g.cls = std::min(g.cls, 3);

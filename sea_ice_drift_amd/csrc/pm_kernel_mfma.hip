@@ -2061,9 +2061,9 @@ int launch_pm_mfma(const PMArgs &args, int lds_bytes, int nthreads, int band, bo
 template <int S>
 static void (*rp_kernel_for(int band, int paired, int pitch))(const PMArgs)
 {
-    if (paired == 2) return pitch == 2104 ? pm_kernel_rp<S, 4, 2, 2104> : pitch == 1104 ? pm_kernel_rp<S, 4, 2, 1104> : pitch == 104 ? pm_kernel_rp<S, 4, 2, 104> : pitch == 112 ? pm_kernel_rp<S, 4, 2, 112> : pitch == 136 ? pm_kernel_rp<S, 4, 2, 136>
+    if (paired == 2) return pitch == 1104 ? pm_kernel_rp<S, 4, 2, 1104> : pitch == 104 ? pm_kernel_rp<S, 4, 2, 104> : pitch == 112 ? pm_kernel_rp<S, 4, 2, 112> : pitch == 136 ? pm_kernel_rp<S, 4, 2, 136>
                           : pitch == 168 ? pm_kernel_rp<S, 4, 2, 168> : pitch == 0 ? pm_kernel_rp<S, 4, 2, 0> : nullptr;
-    if (paired == 1) return pitch == 2104 ? pm_kernel_rp<S, 4, 1, 2104> : pitch == 1104 ? pm_kernel_rp<S, 4, 1, 1104> : pitch == 104 ? pm_kernel_rp<S, 4, 1, 104> : pitch == 112 ? pm_kernel_rp<S, 4, 1, 112> : pitch == 136 ? pm_kernel_rp<S, 4, 1, 136>
+    if (paired == 1) return pitch == 1104 ? pm_kernel_rp<S, 4, 1, 1104> : pitch == 104 ? pm_kernel_rp<S, 4, 1, 104> : pitch == 112 ? pm_kernel_rp<S, 4, 1, 112> : pitch == 136 ? pm_kernel_rp<S, 4, 1, 136>
                           : pitch == 168 ? pm_kernel_rp<S, 4, 1, 168> : pitch == 0 ? pm_kernel_rp<S, 4, 1, 0> : nullptr;
     if (band == 8) return pitch == 136 ? pm_kernel_rp<S, 8, 0, 136> : pitch == 168 ? pm_kernel_rp<S, 8, 0, 168> : pitch == 0 ? pm_kernel_rp<S, 8, 0, 0> : nullptr;
     return pitch == 104 ? pm_kernel_rp<S, 4, 0, 104> : pitch == 112 ? pm_kernel_rp<S, 4, 0, 112> : pitch == 136 ? pm_kernel_rp<S, 4, 0, 136> : pitch == 1104 ? pm_kernel_rp<S, 4, 0, 1104>

@@ -348,8 +348,7 @@ def test_borders_69_to_111_keep_their_tables_in_global_memory(pm_ctx, c_oracle, 
 @pytest.mark.parametrize('s,angles', [(34, ANGLES15), (35, ANGLES15), (35, [-3, 0, 3]), (34, ANGLES7)])
 def test_three_wavefronts_per_point_class_equals_four_and_the_oracle(pm_ctx, c_oracle, monkeypatch, s, angles):
     """Round 4: the smallest windows (borders 20 .. 23, window pitch 104) run FOUR points per CU with three wavefronts each
-    (192 threads; pm_kernel_rp<S, 4, *, 1104> with the sums in global memory, <.., 2104> with the sums in LDS where a slot-group
-    layout still fits four times); SID_PM_NO_W3=1 is round 3's classes of 256 threads.  Both equal the oracle, bit for bit each other - also with the on-the-fly sampler (fractional centres) and at the
+    (192 threads, sums in global memory: pm_kernel_rp<S, 4, *, 1104>); SID_PM_NO_W3=1 is round 3's classes of 256 threads.  Both equal the oracle, bit for bit each other - also with the on-the-fly sampler (fractional centres) and at the
     image edge, where the patch cannot ride with the window."""
     size = 900
     img1, img2 = syn.make_pair(size, size, seed=41)
