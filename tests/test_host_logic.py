@@ -202,3 +202,31 @@ def test_flat_simplices_send_the_first_guess_to_scipy():
     rng = np.random.default_rng(5)
     assert not lib._has_degenerate_simplex(Delaunay(rng.uniform(0, 3000, (4000, 2))))
     assert not lib._has_degenerate_simplex(Delaunay(np.stack(np.meshgrid(np.arange(40.0), np.arange(40.0)), -1).reshape(-1, 2)))
+
+
+def test_launch_classes_and_costs_the_host_predicts():
+    """Host arithmetic of the C ABI (no device): the launch class of a border (sid_pm_estimate_residency: workgroups per CU in the
+    low four bits, + 16 sums in global memory, + 32 the launch of the borders beyond the LDS) and its estimated cost
+    (sid_pm_estimate_cost) follow the residency classes DESIGN.md section 6.3 describes - the three-wavefront class (four per CU,
+    sums in global memory) up to border 23, three per CU with the sums in LDS, then in global memory, two per CU, one per CU,
+    tables in global memory from border 69 - for the three kernel families."""
+    from sea_ice_drift_amd import _capi
+    borders = np.arange(20, 112, dtype=np.float64)
+
+    def runs(s, k):
+        out, prev = [], None
+        for b, c in zip(borders, _capi.estimate_residency(borders, s, k)):
+            if c != prev:
+                out.append((int(b), int(c)))
+                prev = c
+        return out
+    assert runs(34, 15) == [(20, 4 + 16), (24, 3), (28, 3 + 16), (37, 2 + 16), (48, 1 + 16), (69, 1 + 16 + 32)]
+    assert runs(35, 15) == [(20, 4 + 16), (23, 3), (26, 3 + 16), (38, 2 + 16), (48, 1 + 16), (70, 1 + 16 + 32)]
+    for k in (3, 7):                                                                # slot groups: the same class at the small borders
+        assert runs(34, k) == [(20, 4 + 16), (24, 3), (29, 3 + 16), (37, 2 + 16), (48, 1 + 16), (69, 1 + 16 + 32)]
+    for s in (34, 35):
+        cost = _capi.estimate_cost(borders, s, 15)
+        assert (np.diff(cost) > -1e-9).all(), cost                                  # a larger border never costs less
+        assert 60.0 < cost[0] < 80.0 and 300.0 < cost[30] < 420.0                   # ns per point at borders 20 and 50 (profiles/r04_border_cost.json)
+    with pytest.raises(_capi.SidPmError):
+        _capi.estimate_cost(borders, 65, 15)                                        # template sides beyond 64: unsupported, not estimated
