@@ -360,6 +360,9 @@ ShapeClass shape_class(bool rp, int rpp, int wh, int ww, int s, int K, uint32_t 
         if (B.total <= sid::max_lds_bytes()) return ShapeClass{true, 4, 0, B.total, B.wpitch, true};
     }
     if (force_gs || getenv("SID_PM_ALWAYS_GS") != nullptr) return g;
+    // slot groups: since their gs launches keep sum w' for the winner as well, the gs form is ahead at every border (3 / 7 angles,
+    // mixed: -0.9 %; borders 25 / 26: -0.8 %; tools/r4_env_ab.sh) - unless the round-3 classes were asked for (SID_PM_NO_W3)
+    if (rpp > 0 && w3_max_lds() > 0 && getenv("SID_PM_NO_GS") == nullptr && getenv("SID_PM_NO_GSI") == nullptr) return g;
     const ShapeClass l = eval(false);
     if (l.band == 8 || l.nat_pitch > 112 || l.lds > sid::max_lds_bytes()) return g;   // (no instantiation without gs)
     // a class the gs footprint reaches only pays where a kernel build exists for it: the four-per-CU build (128 VGPRs) is

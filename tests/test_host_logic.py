@@ -222,8 +222,8 @@ def test_launch_classes_and_costs_the_host_predicts():
         return out
     assert runs(34, 15) == [(20, 4 + 16), (24, 3), (28, 3 + 16), (37, 2 + 16), (48, 1 + 16), (69, 1 + 16 + 32)]
     assert runs(35, 15) == [(20, 4 + 16), (23, 3), (26, 3 + 16), (38, 2 + 16), (48, 1 + 16), (70, 1 + 16 + 32)]
-    for k in (3, 7):                                                                # slot groups: the same class at the small borders
-        assert runs(34, k) == [(20, 4 + 16), (24, 3), (29, 3 + 16), (37, 2 + 16), (48, 1 + 16), (69, 1 + 16 + 32)]
+    for k in (3, 7):                                                                # slot groups: sums in global memory at every border
+        assert runs(34, k) == [(20, 4 + 16), (24, 3 + 16), (37, 2 + 16), (48, 1 + 16), (69, 1 + 16 + 32)]
     for s in (34, 35):
         cost = _capi.estimate_cost(borders, s, 15)
         assert (np.diff(cost) > -1e-9).all(), cost                                  # a larger border never costs less
