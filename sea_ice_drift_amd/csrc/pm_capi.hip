@@ -542,13 +542,16 @@ int classify_points(sid_pm_ctx *ctx)
         if (int rc = ctx->gsii.reserve((size_t)std::max<uint64_t>(gsii_granules, 1) * 64)) return rc;
         if (int rc = ctx->d_goff.reserve((size_t)std::max<int64_t>(n, 1))) return rc;
         if (int rc = ctx->d_rec.reserve((size_t)std::max<int64_t>(n, 1))) return rc;
-        // pool of blocks indexed by where a workgroup runs (SID_PM_NO_GS_POOL=1: exclusive blocks only - A/B runs): 8 XCDs x
+        // Pool of blocks indexed by where a workgroup runs - WITHDRAWN as a default at the end of round 4: it was 0.9 % faster (the
+        // blocks stay in L2) but about one run in 25 000 came back with a burst of 30 .. 200 wrong results (7 events in 180 000 runs of
+        // one configuration against 0 in 140 000 with exclusive blocks) - a workgroup's hardware slot is not the
+        // invariant it was taken for.  SID_PM_GS_POOL=1 still builds it (experiments only): 8 XCDs x
         // kGsPoolSlots slots of the largest block of any gs launch
         uint32_t stride_max = 0;
         for (const Bucket &bk : ctx->buckets) stride_max = std::max(stride_max, bk.gs_stride);
-        if (stride_max && getenv("SID_PM_NO_GS_POOL") == nullptr) {
+        if (stride_max && getenv("SID_PM_GS_POOL") != nullptr) {
             if (int rc = ctx->gs_pool.reserve((size_t)8 * sid::kGsPoolSlots * stride_max)) return rc;
-        } else if (getenv("SID_PM_NO_GS_POOL") != nullptr) { ctx->gs_pool.release(); }
+        } else { ctx->gs_pool.release(); }
     }
     std::vector<sid::PointRec> recs;
     if (rp) {

@@ -47,6 +47,8 @@ run 4000 300 --angles 7 --border 21 --img-size 35
 run 10000 100 --angles 7 --border 20
 run 3000 40 --angles 7 --border 80
 SID_PM_NO_W3=1 run 4000 200 --angles 7 --border 20
-SID_PM_NO_GS_POOL=1 run 4000 200 --angles 7
+# (the per-XCD pool of blocks, SID_PM_GS_POOL=1, is not in the campaign: it is the one known source of differing results - DESIGN.md 6b)
+run 4000 20000 --angles 7 --img-size 35 --border 44
+run 10000 2000 --angles 1
 echo "library md5 $(md5sum $R/sea_ice_drift_amd/libsid_pm.so | cut -d' ' -f1)" >> $OUT
 cat $OUT

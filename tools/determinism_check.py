@@ -34,6 +34,14 @@ with _capi.PMContext(0) as ctx:
         same = (ij == ref[1]).all(1) & ((out == ref[0]) | (np.isnan(out) & np.isnan(ref[0]))).all(1)
         bad = np.nonzero(~same)[0]
         nbad += len(bad)
-        if len(bad): print('run %d: %d differing points' % (it, len(bad)), [(int(b), ij[b].tolist(), ref[1][b].tolist(), out[b, 3], ref[0][b, 3]) for b in bad[:4]])
+        if len(bad):
+            cols = [int(((out[bad, c] != ref[0][bad, c]) & ~(np.isnan(out[bad, c]) & np.isnan(ref[0][bad, c]))).sum()) for c in range(5)]
+            print('run %d: %d differing points, indices %d..%d (%s), differing columns c2/r2/a/r/h: %s, ij rows differing: %d, borders %s'
+                  % (it, len(bad), bad[0], bad[-1], 'consecutive' if bad[-1] - bad[0] + 1 == len(bad) else 'scattered', cols,
+                     int((ij[bad] != ref[1][bad]).any(1).sum()), sorted(set(g['border'][bad].tolist()))[:6]))
+            print('   first:', [(int(b), ij[b].tolist(), ref[1][b].tolist(), out[b].tolist(), ref[0][b].tolist()) for b in bad[:2]])
+            # is the difference still there when the same buffers are fetched again / the step is repeated?
+            out2, ij2 = ctx.fetch()
+            print('   refetch of the same step: %d of them still differ' % int((~((ij2[bad] == ref[1][bad]).all(1) & ((out2[bad] == ref[0][bad]) | (np.isnan(out2[bad]) & np.isnan(ref[0][bad]))).all(1))).sum()))
     print('%d runs of %d points (size %d, s=%d, K=%d, border %s%s): %d differing point results'
           % (runs, len(g['c1']), size, s, len(angles), args.border, ', on-the-fly sampler' if args.no_table else '', nbad))
