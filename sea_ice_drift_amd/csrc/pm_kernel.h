@@ -44,7 +44,9 @@ struct PMArgs {
     uint32_t *gsii;
     const uint32_t *gsii_off;
     const PointRec *rec;                            // [n_launch] row-pair kernel: one record per launch position (above)
-    // Pool of sum w'^2 blocks indexed by WHERE the workgroup runs (round 4): slot = (XCD, CU of the XCD, which of the CU's
+    // EXPERIMENTAL (SID_PM_GS_POOL=1; withdrawn as the default at the end of round 4: with it one run in ~25 000 returned a burst of
+    // wrong results - the premise below does not always hold).  Pool of sum w'^2 blocks indexed by WHERE the
+    // workgroup runs: slot = (XCD, CU of the XCD, which of the CU's
     // LDS allocations) - read from the hardware registers XCC_ID, HW_ID and LDS_ALLOC, no atomics - so that the 768 blocks in
     // flight are always the same 768 and stay in their XCD's L2, instead of 175 MB of write-once blocks travelling to HBM and
     // back every step.  Two co-resident workgroups never share a slot (they cannot share an LDS allocation of one CU:
