@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define SID_PM_ABI_VERSION 2
+#define SID_PM_ABI_VERSION 3
 
 /* return codes */
 #define SID_PM_OK               0
@@ -56,6 +56,9 @@ extern "C" {
 #define SID_PM_HES_NORM 1u          /* hes_norm=True  (default in the reference)               */
 #define SID_PM_HES_SMTH 2u          /* hes_smth=True  (gaussian_filter sigma=1 before Hessian) */
 #define SID_PM_MCC_NORM 4u          /* mcc_norm=True                                           */
+#define SID_PM_ROT_ORDER1 8u        /* rot_order=1 (pmlib.py:89,112-113): templates sampled bilinearly with scipy's arithmetic
+                                     * (float64 taps, uint8 output rounding); default rot_order=0 = nearest neighbour.
+                                     * Orders 2..5 (whole-image spline prefilter) are not implemented.              */
 
 typedef struct sid_pm_ctx sid_pm_ctx;
 
@@ -163,14 +166,23 @@ int sid_pm_work_info(sid_pm_ctx *ctx, double info[6]);
 
 /* Estimated cost (nanoseconds on one MI355X) of grid points with the given search borders, derived from what the kernel
  * executes for each - matrix instructions of the sweep and of the winner's matrix, placements, residency class of the LDS
- * footprint - for cutting points into shards of equal cost over several GPUs.  Pure host arithmetic (no device needed).
- * Replaces the role of `threads`-sized chunks of the reference's Pool.map (pmlib.py:442-444).                          */
-int sid_pm_estimate_cost(const double *border, int64_t n, int img_size, int n_angles, double *cost_ns);
-/* Launch class of a point of that border: low four bits = workgroups per CU (1 .. 4) of its launch - a launch has 256 x that
- * many points in flight, which prices the tail of a short launch when the points are cut into shards -, + 16 when the point
- * runs in the launches that keep the per-placement sum of squares in global memory (round 4), + 32 for the launch of the search
- * borders beyond 68 px, whose other per-placement tables live there as well.  Points of equal value share a launch.  Host arithmetic as well.                                                                                     */
-int sid_pm_estimate_residency(const double *border, int64_t n, int img_size, int n_angles, int32_t *per_cu);
+ * footprint - for cutting points into shards of equal cost over several GPUs.  `flags` = the flags the run will use (they
+ * decide the LDS layout of the Hessian and with it the class borders).  Pure host arithmetic (no device needed).
+ * Replaces the role of `threads`-sized chunks of the reference's Pool.map (pmlib.py:442-444).
+ * ABI 3: the `flags` argument is new (ABI 2 classified every run as flags = 0).                                        */
+int sid_pm_estimate_cost(const double *border, int64_t n, int img_size, int n_angles, uint32_t flags, double *cost_ns);
+/* Launch class of a point of that border.  Points of equal value share a launch.  Host arithmetic as well.
+ *   value & SID_PM_CLASS_PER_CU  workgroups per CU (1 .. 4) of its launch - a launch has 256 x that many points in flight,
+ *                                which prices the tail of a short launch when the points are cut into shards;
+ *   SID_PM_CLASS_GS              the launch keeps its per-placement sums in global memory (a launch of its own);
+ *   SID_PM_CLASS_BIG             search borders beyond 68 px: every per-placement table in global memory;
+ *   SID_PM_CLASS_W3B             reserved (second launch of the three-wavefront class; not produced by this build).
+ * ABI 1 returned the workgroups per CU alone; consumers must mask with SID_PM_CLASS_PER_CU.                             */
+#define SID_PM_CLASS_PER_CU 15
+#define SID_PM_CLASS_GS     16
+#define SID_PM_CLASS_BIG    32
+#define SID_PM_CLASS_W3B    64
+int sid_pm_estimate_residency(const double *border, int64_t n, int img_size, int n_angles, uint32_t flags, int32_t *launch_class);
 
 /* ---- diagnostics used by the parity tests ---- */
 

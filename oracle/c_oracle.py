@@ -32,6 +32,8 @@ def lib():
         L.sid_oracle_get_template.restype = C.c_int
         L.sid_oracle_get_template.argtypes = [_u8p, C.c_int64, C.c_int64, C.c_int64, C.c_double,
                                               C.c_double, _f64p, C.c_int, _u8p]
+        L.sid_oracle_get_template1.restype = C.c_int
+        L.sid_oracle_get_template1.argtypes = L.sid_oracle_get_template.argtypes
         L.sid_oracle_match_template.restype = C.c_int
         L.sid_oracle_match_template.argtypes = [_u8p, C.c_int, C.c_int, C.c_int64, _u8p, C.c_int, _f32p]
         L.sid_oracle_hessian.restype = C.c_int
@@ -57,11 +59,11 @@ def _f64(a):
     return a, a.ctypes.data_as(_f64p)
 
 
-def get_template(img, c, r, rot, s):
+def get_template(img, c, r, rot, s, rot_order=0):
     img, pi = _u8(img)
     rot, pr = _f64(rot)
     out = np.empty((s, s), dtype=np.uint8)
-    lib().sid_oracle_get_template(pi, img.shape[0], img.shape[1], img.strides[0], float(c), float(r),
+    (lib().sid_oracle_get_template1 if rot_order == 1 else lib().sid_oracle_get_template)(pi, img.shape[0], img.shape[1], img.strides[0], float(c), float(r),
                                   pr, int(s), out.ctypes.data_as(_u8p))
     return out
 

@@ -7,6 +7,7 @@
  *
  * Restates /root/reference/sea_ice_drift/pmlib.py (v0.7.1):
  *   sid_oracle_get_template    pmlib.py:89-115   (scipy affine_transform, order 0)
+ *   sid_oracle_get_template1   pmlib.py:89-115   (the same with rot_order=1)
  *   sid_oracle_match_template  pmlib.py:156      (cv2.matchTemplate TM_CCOEFF_NORMED;
  *                                                 OpenCV un-vendored and absent:
  *                                                 PARITY UNPINNED at this call, see
@@ -30,6 +31,7 @@
 #define SID_FLAG_HES_NORM 1u
 #define SID_FLAG_HES_SMTH 2u
 #define SID_FLAG_MCC_NORM 4u
+#define SID_FLAG_ROT_ORDER1 8u   /* rot_order=1 (pmlib.py:89,112-113): bilinear template sampling */
 
 /* ------------------------------------------------------------------ a1 */
 /* rot = {cos a, sin a, tcT0, tcT1} with tcT = [tc,tc].dot([[cos,-sin],[sin,cos]])
@@ -54,6 +56,50 @@ int sid_oracle_get_template(const uint8_t *img, int64_t rows, int64_t cols, int6
             if (rr >= 0.0 && rr <= (double)(rows - 1) && cc >= 0.0 && cc <= (double)(cols - 1)) {
                 int64_t ri = (int64_t)floor(rr + 0.5), ci = (int64_t)floor(cc + 0.5);
                 v = img[ri * stride + ci];
+            }
+            out[i * s + j] = v;
+            if (v < vmin) vmin = v;
+        }
+    }
+    return vmin;
+}
+
+/* The same with rot_order=1: scipy NI_GeometricTransform at spline order 1, mode='constant', cval=0, uint8 output
+ * (oracle/pm_oracle.py get_template_order1 has the derivation; fixture G1b pins both against the reference's own call). */
+int sid_oracle_get_template1(const uint8_t *img, int64_t rows, int64_t cols, int64_t stride,
+                             double c, double r, const double *rot, int s, uint8_t *out)
+{
+    const double cosa = rot[0], sina = rot[1];
+    const double off0 = r - rot[2], off1 = c - rot[3];
+    const double msin = -sina;
+    int vmin = 255;
+    for (int i = 0; i < s; ++i) {
+        for (int j = 0; j < s; ++j) {
+            double rr = 0.0 + (double)i * cosa;
+            rr = rr + (double)j * sina;
+            rr = rr + off0;
+            double cc = 0.0 + (double)i * msin;
+            cc = cc + (double)j * cosa;
+            cc = cc + off1;
+            uint8_t v = 0;
+            if (rr >= 0.0 && rr <= (double)(rows - 1) && cc >= 0.0 && cc <= (double)(cols - 1)) {
+                const double fr = floor(rr), fc = floor(cc);
+                const double yr = rr - fr, yc = cc - fc;
+                const double w0r = 1.0 - yr, w1r = yr, w0c = 1.0 - yc, w1c = yc;
+                const int64_t r0 = (int64_t)fr, c0 = (int64_t)fc;
+                int64_t r1 = r0 + 1, c1 = c0 + 1;                /* the tap behind the last sample is mirrored (its weight is 0) */
+                if (r1 >= rows) r1 = 2 * rows - 2 - r1;
+                if (c1 >= cols) c1 = 2 * cols - 2 - c1;
+                if (r1 < 0) r1 = 0;
+                if (c1 < 0) c1 = 0;
+                double t = 0.0;
+                t = t + ((double)img[r0 * stride + c0] * w0r) * w0c;
+                t = t + ((double)img[r0 * stride + c1] * w0r) * w1c;
+                t = t + ((double)img[r1 * stride + c0] * w1r) * w0c;
+                t = t + ((double)img[r1 * stride + c1] * w1r) * w1c;
+                t = t > 0.0 ? t + 0.5 : 0.0;                      /* CASE_INTERP_OUT_UINT of ni_interpolation.c */
+                t = t > 255.0 ? 255.0 : t;
+                v = (uint8_t)t;
             }
             out[i * s + j] = v;
             if (v < vmin) vmin = v;
@@ -358,7 +404,7 @@ static void use_mcc_ws(sid_ws *w, const uint8_t *img1, int64_t rows1, int64_t co
     float top1 = -INFINITY, top2 = -INFINITY;                   /* two largest values over all angles and placements */
     int best_k = -1, best_idx = -1;
     for (int k = 0; k < n_angles; ++k) {
-        if (sid_oracle_get_template(img1, rows1, cols1, stride1, c1, r1, rot + 4 * k, s, w->tmpl) == 0)
+        if (((flags & SID_FLAG_ROT_ORDER1) ? sid_oracle_get_template1 : sid_oracle_get_template)(img1, rows1, cols1, stride1, c1, r1, rot + 4 * k, s, w->tmpl) == 0)
             return;                                             /* pmlib.py:152-154 -> NaN */
         match_template_core(win, wh, ww, stride2, w->tmpl, s, w->res, w->sit, w->si,
                             w->si + (size_t)rh * rw, k > 0);

@@ -13,6 +13,7 @@ here                  reference              what
 ====================  =====================  ===================================
 rotation_terms        pmlib.py:105-110       tc, cos/sin matrix, tc.dot(transform)
 get_template          pmlib.py:89-115        rotated nearest-neighbour template
+get_template_order1   pmlib.py:89-115        the same with rot_order=1 (bilinear)
 match_template        pmlib.py:156 (cv2)     TM_CCOEFF_NORMED, see below
 get_hessian           pmlib.py:36-59         float32 2nd-derivative magnitude
 rotate_and_match      pmlib.py:117-174       angle sweep, peak pick, Hessian
@@ -61,6 +62,7 @@ import numpy as np
 FLAG_HES_NORM = 1
 FLAG_HES_SMTH = 2
 FLAG_MCC_NORM = 4
+FLAG_ROT_ORDER1 = 8          # rot_order=1 (pmlib.py:89): templates sampled bilinearly
 
 
 # --------------------------------------------------------------------------- a1
@@ -100,6 +102,48 @@ def get_template(img, c, r, a, s):
     ci = np.clip(ci, 0, cols - 1)
     out = np.where(inside, img[ri, ci], 0).astype(np.uint8)
     return out
+
+
+def get_template_order1(img, c, r, a, s):
+    """The same template with ``rot_order=1`` (pmlib.py:89,112-113): scipy's NI_GeometricTransform at spline order 1
+    with mode='constant', cval=0, output=uint8.  Same float64 coordinates as order 0; a coordinate < 0 or > dim-1 yields
+    cval = 0 for the whole sample (no blending with the border - that would be mode='grid-constant'); otherwise
+    start = floor(coordinate), weights (1 - y, y) with y = coordinate - floor(coordinate), the tap behind the last sample
+    mirrored (its weight is then exactly 0), and
+
+        t = 0.0;  t += (v[r0,c0]*w0r)*w0c;  t += (v[r0,c1]*w0r)*w1c;  t += (v[r1,c0]*w1r)*w0c;  t += (v[r1,c1]*w1r)*w1c
+
+    in float64, in that order; uint8 output:  t > 0 ? t + 0.5 : 0, clamped to 255, truncated.  Pinned against scipy
+    through the reference's own get_template: fixture G1b (tests/golden/g1b_templates_order1.npz).
+    """
+    cosa, sina, tct0, tct1 = rotation_terms(a, s)
+    off0 = np.float64(r) - tct0
+    off1 = np.float64(c) - tct1
+    ii = np.arange(s, dtype=np.float64)[:, None]
+    jj = np.arange(s, dtype=np.float64)[None, :]
+    rr = ((0.0 + ii * cosa) + jj * sina) + off0
+    cc = ((0.0 + ii * (-sina)) + jj * cosa) + off1
+    rows, cols = img.shape
+    inside = (rr >= 0) & (rr <= rows - 1) & (cc >= 0) & (cc <= cols - 1)
+    fr, fc = np.floor(rr), np.floor(cc)
+    yr, yc = rr - fr, cc - fc
+    r0 = np.clip(fr.astype(np.int64), 0, rows - 1)
+    c0 = np.clip(fc.astype(np.int64), 0, cols - 1)
+
+    def mirrored(i, n):                           # scipy's edge mapping of a tap index beyond the last sample
+        i = np.where(i >= n, 2 * n - 2 - i, i)
+        return np.clip(i, 0, n - 1)
+    r1, c1 = mirrored(r0 + 1, rows), mirrored(c0 + 1, cols)
+    v = img.astype(np.float64)
+    w0r, w1r, w0c, w1c = 1.0 - yr, yr, 1.0 - yc, yc
+    t = 0.0
+    t = t + (v[r0, c0] * w0r) * w0c
+    t = t + (v[r0, c1] * w0r) * w1c
+    t = t + (v[r1, c0] * w1r) * w0c
+    t = t + (v[r1, c1] * w1r) * w1c
+    t = np.where(t > 0, t + 0.5, 0.0)
+    t = np.minimum(t, 255.0)
+    return np.where(inside, t, 0.0).astype(np.uint8)
 
 
 # --------------------------------------------------------------------------- a3
@@ -211,14 +255,14 @@ def get_hessian(ccm, hes_norm=True, hes_smth=False):
 
 # ----------------------------------------------------------------------- a2,a4,a6
 def rotate_and_match(img1, c1, r1, img_size, image2, alpha0, angles=(-3, 0, 3),
-                     mcc_norm=False, hes_norm=True, hes_smth=False, full=False):
-    """pmlib.py:117-174.  Returns (dc, dr, best_a, best_r, best_h) and, with
+                     mcc_norm=False, hes_norm=True, hes_smth=False, full=False, rot_order=0):
+    """pmlib.py:117-174 (rot_order: 0 or 1, forwarded to get_template as pmlib.py:151 does).  Returns (dc, dr, best_a, best_r, best_h) and, with
     full=True, also (best_ij, best_angle_index, best_result, best_template)."""
     nan = np.nan
     best_r = -np.inf
     best = None
     for k, angle in enumerate(angles):
-        template = get_template(img1, c1, r1, angle - alpha0, img_size)
+        template = (get_template_order1 if rot_order == 1 else get_template)(img1, c1, r1, angle - alpha0, img_size)
         if template.min() == 0:                                   # pmlib.py:152-154
             if full:
                 return (nan, nan, nan, nan, nan), ((-1, -1), -1, None, None)
@@ -273,7 +317,8 @@ def pm_batch(img1, img2, c1, r1, c2fg, r2fg, border, img_size, alpha0, angles,
     out = np.full((n, 5), np.nan)
     ij = np.full((n, 3), -1, dtype=np.int32)
     kw = dict(angles=list(angles), hes_norm=bool(flags & FLAG_HES_NORM),
-              hes_smth=bool(flags & FLAG_HES_SMTH), mcc_norm=bool(flags & FLAG_MCC_NORM))
+              hes_smth=bool(flags & FLAG_HES_SMTH), mcc_norm=bool(flags & FLAG_MCC_NORM),
+              rot_order=1 if (flags & FLAG_ROT_ORDER1) else 0)
     for i in range(n):
         res, (bij, bk, _, _) = use_mcc(c1[i], r1[i], c2fg[i], r2fg[i], border[i], img1, img2,
                                        img_size, alpha0, full=True, **kw)

@@ -14,8 +14,9 @@ LIB_PATH = os.environ.get('SID_PM_LIB') or os.path.join(_HERE, 'libsid_pm.so')  
 HES_NORM = 1
 HES_SMTH = 2
 MCC_NORM = 4
+ROT_ORDER1 = 8          # rot_order=1: bilinear template sampling (include/sid_pm.h)
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 # every symbol include/sid_pm.h declares
 SYMBOLS = (
@@ -102,8 +103,8 @@ def lib():
     L.sid_pm_debug_ncc_selftest.argtypes = [C.c_void_p, C.c_uint64, C.c_int64, C.c_int, C.POINTER(C.c_uint64)]
     if hasattr(L, 'sid_pm_unpermute'):
         L.sid_pm_unpermute.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
-    L.sid_pm_estimate_cost.argtypes = [_f64p, C.c_int64, C.c_int, C.c_int, _f64p]
-    L.sid_pm_estimate_residency.argtypes = [_f64p, C.c_int64, C.c_int, C.c_int, _i32p]
+    L.sid_pm_estimate_cost.argtypes = [_f64p, C.c_int64, C.c_int, C.c_int, C.c_uint32, _f64p]
+    L.sid_pm_estimate_residency.argtypes = [_f64p, C.c_int64, C.c_int, C.c_int, C.c_uint32, _i32p]
     L.sid_pm_debug_hypot_selftest.argtypes = [C.c_void_p, C.c_uint64, C.c_int64, C.POINTER(C.c_uint64)]
     L.sid_ft_knn2.argtypes = [C.c_int, _u8p, C.c_int64, _u8p, C.c_int64, _i32p, _i32p]
     L.sid_ft_knn2_device.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -173,8 +174,13 @@ def _p(a, t):
 
 def release_workspaces(device=-1):
     """Hand the cached device memory of the detector, the matcher and the first-guess evaluation back (``sid_orb_release``,
-    ``sid_ft_release``, ``sid_fg_release``; -1: every device).  No call on that device may be in flight."""
-    L = lib()
+    ``sid_ft_release``, ``sid_fg_release``; -1: every device).  No call on that device may be in flight.
+    A process that never loaded the library has nothing cached: this returns without loading it (it is registered with
+    atexit through pmlib.release_contexts, and loading means importing torch and initialising the GPU - not at interpreter
+    shutdown, and not in a process that only used the host code)."""
+    if _lib is None:
+        return
+    L = _lib
     for name in ('sid_orb_release', 'sid_ft_release', 'sid_fg_release'):
         if hasattr(L, name):
             getattr(L, name)(int(device))
@@ -185,25 +191,33 @@ def unpermute(stack_ptr, world, m, perm_ptr, n, out_ptr, ij_ptr, stream):
     _check(lib().sid_pm_unpermute(stack_ptr, int(world), int(m), perm_ptr, int(n), out_ptr, ij_ptr, stream))
 
 
-def estimate_cost(border, img_size=34, n_angles=15):
-    """Estimated nanoseconds per grid point (include/sid_pm.h sid_pm_estimate_cost): host arithmetic of the library."""
+def estimate_cost(border, img_size=34, n_angles=15, flags=HES_NORM):
+    """Estimated nanoseconds per grid point (include/sid_pm.h sid_pm_estimate_cost): host arithmetic of the library.
+    ``flags``: the flags of the run (they decide the Hessian's LDS layout, hence the class borders)."""
     b = _f64(border).ravel()
     out = np.empty(b.size, dtype=np.float64)
-    _check(lib().sid_pm_estimate_cost(_p(b, _f64p), b.size, int(img_size), int(n_angles), _p(out, _f64p)))
+    _check(lib().sid_pm_estimate_cost(_p(b, _f64p), b.size, int(img_size), int(n_angles), int(flags), _p(out, _f64p)))
     return out
 
 
-def estimate_residency(border, img_size=34, n_angles=15):
+CLASS_PER_CU, CLASS_GS, CLASS_BIG = 15, 16, 32          # include/sid_pm.h SID_PM_CLASS_*
+
+
+def estimate_residency(border, img_size=34, n_angles=15, flags=HES_NORM):
     """Launch class of each grid point (include/sid_pm.h sid_pm_estimate_residency): workgroups per CU (1 .. 4) in the low four
-    bits, + 16 for the launches that keep sum w'^2 in global memory; points of equal value share a launch."""
+    bits (``& CLASS_PER_CU``), ``CLASS_GS`` for the launches that keep their per-placement sums in global memory, ``CLASS_BIG``
+    for borders beyond 68 px; points of equal value share a launch."""
     b = _f64(border).ravel()
     out = np.empty(b.size, dtype=np.int32)
-    _check(lib().sid_pm_estimate_residency(_p(b, _f64p), b.size, int(img_size), int(n_angles), _p(out, _i32p)))
+    _check(lib().sid_pm_estimate_residency(_p(b, _f64p), b.size, int(img_size), int(n_angles), int(flags), _p(out, _i32p)))
     return out
 
 
-def flags_from_kwargs(hes_norm=True, hes_smth=False, mcc_norm=False):
-    return (HES_NORM if hes_norm else 0) | (HES_SMTH if hes_smth else 0) | (MCC_NORM if mcc_norm else 0)
+def flags_from_kwargs(hes_norm=True, hes_smth=False, mcc_norm=False, rot_order=0):
+    if rot_order not in (0, 1):
+        raise NotImplementedError('rot_order=%r' % (rot_order,))
+    return ((HES_NORM if hes_norm else 0) | (HES_SMTH if hes_smth else 0) | (MCC_NORM if mcc_norm else 0) |
+            (ROT_ORDER1 if rot_order == 1 else 0))
 
 
 def pm_batch(img1, img2, c1, r1, c2fg, r2fg, border, img_size, alpha0, angles, rot=None, flags=HES_NORM):

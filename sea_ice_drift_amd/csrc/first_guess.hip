@@ -294,6 +294,65 @@ __global__ __launch_bounds__(256) void k_nearest(const double *seeds, int64_t ns
     if (i < nq) dist[i] = sqrt(best);
 }
 
+// ---- the same distances through the grid of buckets (round 5) ----
+// The seeds are binned into the kGrid x kGrid cells of their bounding box (count, prefix sums, fill: k_grid_scan serves both
+// grids); a query looks at the cells in rings of growing Chebyshev radius around its own (clamped) cell and stops when no
+// cell further out can hold a closer seed: every seed of a cell outside the block of rings 0 .. r lies beyond one of the block's
+// sides that still has grid behind it, i.e. at least `lb` = the smallest distance from the query to such a side away (a side
+// the grid ends at has nothing behind it).  The bound is taken with a margin that covers the rounding of cell_of, so the
+// minimum is over a superset of the seeds that could attain it, and every candidate distance is the SAME expression the
+// brute-force kernel evaluates (dx dx + dy dy, no contraction): the result is bit-identical (test_nearest_keypoint_distance_is_exact,
+// fixture G4), at ~25 cells x ~1 seed per query instead of all 20 000.
+template <int PASS>
+__global__ void k_seed_bin(const double *seeds, int64_t ns, GridGeo g, int32_t *count, const int32_t *start, int32_t *ids)
+{
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= ns) return;
+    const int cell = cell_of(seeds[2 * k + 1], g.y0, g.iy) * kGrid + cell_of(seeds[2 * k], g.x0, g.ix);
+    const int32_t pos = atomicAdd(&count[cell], 1);
+    if (PASS == 1) ids[start[cell] + pos] = (int32_t)k;
+}
+__global__ __launch_bounds__(256) void k_nearest_grid(const double *seeds, const int32_t *start, const int32_t *ids, GridGeo g, double wx, double wy,
+                                                       double margin, const double *q, int64_t nq, double *dist)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nq) return;
+    const double x = q[2 * i], y = q[2 * i + 1];
+    const int cx = cell_of(x, g.x0, g.ix), cy = cell_of(y, g.y0, g.iy);
+    double best = INFINITY;
+    for (int r = 0; r < kGrid; ++r) {
+        const int xa = cx - r, xb = cx + r, ya = cy - r, yb = cy + r;
+        // ring r: the cells of the block [xa, xb] x [ya, yb] that are not in ring r - 1 (clipped to the grid)
+        auto visit = [&](int cell) {
+            for (int32_t e = start[cell]; e < start[cell + 1]; ++e) {
+                const int32_t k = ids[e];
+                const double dx = x - seeds[2 * k], dy = y - seeds[2 * k + 1];
+                const double d2 = dx * dx + dy * dy;
+                best = d2 < best ? d2 : best;
+            }
+        };
+        const int x_lo = xa < 0 ? 0 : xa, x_hi = xb > kGrid - 1 ? kGrid - 1 : xb;
+        for (int yy = (ya < 0 ? 0 : ya); yy <= (yb > kGrid - 1 ? kGrid - 1 : yb); ++yy) {
+            if (yy == ya || yy == yb) {
+                for (int xx = x_lo; xx <= x_hi; ++xx) visit(yy * kGrid + xx);
+            } else {
+                if (xa >= 0) visit(yy * kGrid + xa);
+                if (xb <= kGrid - 1) visit(yy * kGrid + xb);           // (r >= 1 here: xb != xa)
+            }
+        }
+        // nothing closer outside the block?  sides the grid ends at have nothing behind them
+        double lb = INFINITY;
+        if (xa > 0) lb = fmin(lb, x - (g.x0 + (double)xa * wx));
+        if (xb < kGrid - 1) lb = fmin(lb, (g.x0 + (double)(xb + 1) * wx) - x);
+        if (ya > 0) lb = fmin(lb, y - (g.y0 + (double)ya * wy));
+        if (yb < kGrid - 1) lb = fmin(lb, (g.y0 + (double)(yb + 1) * wy) - y);
+        if (lb == INFINITY) break;                                     // the block covers the grid
+        lb -= margin;
+        if (lb > 0.0 && best <= lb * lb) break;
+    }
+    dist[i] = sqrt(best);
+}
+
 #define HIP_TRY(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { rc = fail(SID_PM_ERR_HIP, "%s: %s", #x, hipGetErrorString(e_)); goto done; } } while (0)
 
 // Device scratch of the two entry points: one grow-only block per device, carved per call (no hipMalloc / hipFree per
@@ -444,14 +503,42 @@ SID_EXPORT int sid_fg_nearest_dist(int device, const double *seeds, int64_t n_se
     auto up = [](size_t b) { return (b + 255) / 256 * 256; };
     unsigned char *blk = nullptr;
     double *d_s = nullptr, *d_q = nullptr, *d_d = nullptr;
-    if ((rc = pool_reserve(device, up(sizeof(double) * 2 * n_seeds) + up(sizeof(double) * 2 * n_q) + up(sizeof(double) * n_q), &blk))) { (void)hipSetDevice(prev); return rc; }
+    int32_t *d_cnt = nullptr, *d_start = nullptr, *d_ids = nullptr;
+    if ((rc = pool_reserve(device, up(sizeof(double) * 2 * n_seeds) + up(sizeof(double) * 2 * n_q) + up(sizeof(double) * n_q) +
+                                   up(sizeof(int32_t) * (kGrid * kGrid + 1)) * 2 + up(sizeof(int32_t) * n_seeds), &blk))) { (void)hipSetDevice(prev); return rc; }
     {
         Carver cv(blk);
         d_s = cv.take<double>(2 * n_seeds); d_q = cv.take<double>(2 * n_q); d_d = cv.take<double>(n_q);
+        d_cnt = cv.take<int32_t>(kGrid * kGrid + 1); d_start = cv.take<int32_t>(kGrid * kGrid + 1); d_ids = cv.take<int32_t>(n_seeds);
     }
     HIP_TRY(hipMemcpyAsync(d_s, seeds, sizeof(double) * 2 * n_seeds, hipMemcpyHostToDevice, 0));
     HIP_TRY(hipMemcpyAsync(d_q, q, sizeof(double) * 2 * n_q, hipMemcpyHostToDevice, 0));
-    hipLaunchKernelGGL(k_nearest, dim3((unsigned)((n_q + 255) / 256)), dim3(256), 0, 0, d_s, n_seeds, d_q, n_q, d_d);
+    {
+        // bounding box of the seeds (host: they are host arrays); the buckets pay from a few hundred seeds on, and need finite
+        // coordinates and a box with an area (SID_FG_NO_GRID=1: brute force always; A/B runs and the parity test of both)
+        double x_lo = INFINITY, x_hi = -INFINITY, y_lo = INFINITY, y_hi = -INFINITY;
+        bool finite = true;
+        for (int64_t k = 0; k < n_seeds; ++k) {
+            const double sx = seeds[2 * k], sy = seeds[2 * k + 1];
+            finite = finite && isfinite(sx) && isfinite(sy);
+            x_lo = fmin(x_lo, sx); x_hi = fmax(x_hi, sx); y_lo = fmin(y_lo, sy); y_hi = fmax(y_hi, sy);
+        }
+        const double w = x_hi - x_lo, h = y_hi - y_lo;
+        if (getenv("SID_FG_NO_GRID") == nullptr && n_seeds >= 256 && finite && w > 0.0 && h > 0.0 && isfinite(w) && isfinite(h)) {
+            const GridGeo geo{x_lo, y_lo, (double)kGrid / w, (double)kGrid / h};
+            // rounding of (v - v0) * inv in cell_of moves a seed by at most a few ulp of the box across a cell border
+            const double margin = 1e-9 * (w + h) + 1e-12 * (fabs(x_lo) + fabs(x_hi) + fabs(y_lo) + fabs(y_hi));
+            const unsigned nb = (unsigned)((n_seeds + 255) / 256);
+            HIP_TRY(hipMemsetAsync(d_cnt, 0, sizeof(int32_t) * (kGrid * kGrid + 1), 0));
+            hipLaunchKernelGGL(k_seed_bin<0>, dim3(nb), dim3(256), 0, 0, d_s, n_seeds, geo, d_cnt, (const int32_t *)nullptr, (int32_t *)nullptr);
+            hipLaunchKernelGGL(k_grid_scan, dim3(1), dim3(1024), 0, 0, d_cnt, d_start);
+            hipLaunchKernelGGL(k_seed_bin<1>, dim3(nb), dim3(256), 0, 0, d_s, n_seeds, geo, d_cnt, d_start, d_ids);
+            hipLaunchKernelGGL(k_nearest_grid, dim3((unsigned)((n_q + 255) / 256)), dim3(256), 0, 0, d_s, d_start, d_ids, geo, w / kGrid, h / kGrid, margin,
+                               d_q, n_q, d_d);
+        } else {
+            hipLaunchKernelGGL(k_nearest, dim3((unsigned)((n_q + 255) / 256)), dim3(256), 0, 0, d_s, n_seeds, d_q, n_q, d_d);
+        }
+    }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpy(dist, d_d, sizeof(double) * n_q, hipMemcpyDeviceToHost));
 done:

@@ -94,6 +94,7 @@ struct sid_pm_ctx {
     bool rp = false;                    // the resident points run the row-pair kernel (decided at set_points: use_rp) ...
     int rp_paired = 0;                  // ... with slot groups: 0 none, 1 two groups (<= 7 angles), 2 four groups (<= 3 angles)
     bool gs_keep_si = true;             // the blocks of global memory are sized for sum w' as well (classify_points; SID_PM_NO_GSI=1: not)
+    bool gs_keep_acc = false;           // ... or for the sweep's accumulators (PMArgs::gs_keep_acc; classify_points: keep_acc_policy)
     bool have_samp = false;             // SID_PM_NO_SAMP_TABLE=1 keeps the on-the-fly sampling (tests of the general sampler)
     int samp_nflag = 0;
     // host copies of what the classification needs: the launch classes depend on the shape of image 2, so a
@@ -106,7 +107,6 @@ struct sid_pm_ctx {
     DevBuf<uint32_t> gsii;              // row-pair kernel: sum w'^2 per placement of every resident point (PMArgs::gsii) ...
     DevBuf<uint32_t> d_goff;            // ... and the offset of every launch position's block in it (units of 64 entries)
     DevBuf<sid::PointRec> d_rec;        // row-pair kernel: one record per launch position (index, block offset, the five inputs)
-    DevBuf<uint32_t> gs_pool;           // pool of sum w'^2 blocks indexed by where a workgroup runs (PMArgs::gs_pool)
     int32_t *h_refused = nullptr;       // pinned, device-visible: valid points a launch could not hold (PMArgs::refused)
     double *user_out = nullptr;         // caller-owned result arrays (bind_results)
     int32_t *user_ij = nullptr;
@@ -275,6 +275,24 @@ sid::RpLdsLayout big_layout(int wh, int ww, int s, int K, uint32_t flags)
 // operand); decided when the blocks are sized (classify_points) and remembered for the launches (SID_PM_NO_GSI=1: off - A/B runs)
 bool gs_keep_si(const sid_pm_ctx *ctx) { return ctx->rp && ctx->gs_keep_si; }
 
+// Kept accumulators (PMArgs::gs_keep_acc, round 5): the gs launches of a run with ONE group of angles store the sweep's exact
+// S_IT' of every slot and placement in the point's block of global memory, and the winner's NCC matrix is a normalisation of
+// stored sums.  Default: the slot-group layouts (at most 7 angles - 16 / 32 bytes per placement; the reference's default is 3
+// angles); SID_PM_KEEP_ACC=1: also the full table (64 bytes per placement), =0: never (A/B runs and the tests of both routes).
+bool keep_acc_policy(bool rp, int rpp, int K)
+{
+    if (!rp || K > sid::kRpGroup) return false;
+    if (rpp == 0 && !sid::kKeepAccFull) return false;                  // (the full-table kernels carry the code in measurement builds only)
+    const char *e = getenv("SID_PM_KEEP_ACC");
+    return e ? atoi(e) > 0 : rpp > 0;
+}
+// u32 entries of the block of a point of that shape in a gs launch
+uint32_t block_entries(const sid_pm_ctx *ctx, int wh, int ww, int band)
+{
+    const int s = ctx->img_size;
+    return sid::rp_block_entries(wh - s + 1, ww - s + 1, rp_rows(ctx->rp_paired, band), 16 >> ctx->rp_paired, gs_keep_si(ctx), ctx->gs_keep_acc);
+}
+
 int check_sweep(int img_size, const double *angles, int n_angles, uint32_t flags)
 {
     if (!angles || n_angles < 1)
@@ -283,7 +301,7 @@ int check_sweep(int img_size, const double *angles, int n_angles, uint32_t flags
     if (n_angles > sid::kMaxAngles) return fail(SID_PM_ERR_UNSUPPORTED, "more than %d angles", sid::kMaxAngles);
     if (!sid::mfma_img_size_supported(img_size))
         return fail(SID_PM_ERR_UNSUPPORTED, "img_size=%d: the kernel supports 2..64", img_size);
-    if (flags & ~(SID_PM_HES_NORM | SID_PM_HES_SMTH | SID_PM_MCC_NORM)) return fail(SID_PM_ERR_ARG, "unknown flag bits");
+    if (flags & ~(SID_PM_HES_NORM | SID_PM_HES_SMTH | SID_PM_MCC_NORM | SID_PM_ROT_ORDER1)) return fail(SID_PM_ERR_ARG, "unknown flag bits");
     return SID_PM_OK;
 }
 
@@ -312,8 +330,8 @@ int fill_args(sid_pm_ctx *ctx, sid::PMArgs &A)
     A.out_ij = ctx->user_out ? ctx->user_ij : ctx->out_ij.p;
     A.refused = ctx->h_refused;
     A.gsii = ctx->gsii.p; A.gsii_off = ctx->d_goff.p; A.rec = ctx->d_rec.p;
-    A.gs_pool = ctx->gs_pool.p; A.gs_pool_stride = 0;
     A.gs_keep_si = gs_keep_si(ctx) ? 1u : 0u;
+    A.gs_keep_acc = ctx->gs_keep_acc ? 1u : 0u;
     if (getenv("SID_PM_DEBUG_CHECK")) {
         if (!ctx->dbg_err.p && ctx->dbg_err.reserve(320) == SID_PM_OK) (void)hipMemset(ctx->dbg_err.p, 0, 320 * sizeof(int32_t));
         A.dbg_err = ctx->dbg_err.p;
@@ -400,6 +418,7 @@ int classify_points(sid_pm_ctx *ctx)
         }
     };
     ctx->gs_keep_si = getenv("SID_PM_NO_GSI") == nullptr;
+    ctx->gs_keep_acc = keep_acc_policy(rp, rpp, K);
     const uint32_t flags = ctx->flags;
     const int lds_min = lds_need(rp, rpp, s + 1, s + 1, s, K, flags, 4, 0, false);
     {   // shape 0: points whose window does not lie inside image 2 (they write NaN at once; minimal footprint)
@@ -408,7 +427,7 @@ int classify_points(sid_pm_ctx *ctx)
     }
     double macs = 0, bytes = 0, valid = 0;
     int lds_max = lds_min;
-    std::vector<uint32_t> gran_of((size_t)n, 0u);                     // 256-byte granules of every point's block of global memory (row-pair kernel; 0: NaN point)
+    std::vector<int32_t> shape_of((size_t)n, 0);                      // shape of every point (0: its window does not lie inside image 2)
     for (int64_t i = 0; i < n; ++i) {
         int wh = 0, ww = 0;
         if (!window_dims(c2fg[i], r2fg[i], border[i], s, rows2, cols2, wh, ww)) { shapes[0].idx.push_back((int32_t)i); continue; }
@@ -426,8 +445,7 @@ int classify_points(sid_pm_ctx *ctx)
         }
         Shape &sh = shapes[(size_t)k];
         sh.idx.push_back((int32_t)i);
-        // (full table: sum w' per placement, kept by the sweep for the winner, lies behind sum w'^2 - twice the block)
-        gran_of[(size_t)i] = sh.big ? (uint32_t)(big_layout(wh, ww, s, K, flags).big_bytes / 256) : (((uint32_t)((wh - s + 1) * (ww - s + 1)) * 4u + 255u) / 256u) * (gs_keep_si(ctx) ? 2u : 1u);
+        shape_of[(size_t)i] = (int32_t)k;
         macs += (double)K * sh.work * s * s;
         // window + bounding box of the rotated template + 5 inputs + outputs
         bytes += (double)wh * ww + 51.0 * 51.0 + 40.0 + 52.0;
@@ -516,7 +534,7 @@ int classify_points(sid_pm_ctx *ctx)
             for (size_t i = a; i < b; ++i) {
                 const Shape &sh = shapes[(size_t)ord[i]];
                 if (sh.wh > 0) bk.gs_stride = std::max<uint32_t>(bk.gs_stride, sh.big ? (uint32_t)(big_layout(sh.wh, sh.ww, s, K, flags).big_bytes / 4)
-                                                                                      : (uint32_t)(((sh.wh - s + 1) * (sh.ww - s + 1) * 4 + 255) / 256 * 64) * (gs_keep_si(ctx) ? 2u : 1u));
+                                                                                      : block_entries(ctx, sh.wh, sh.ww, sh.band));
             }
         constexpr int64_t kXcd = 8;
         const int64_t L = (int64_t)src->size(), m = (L + kXcd - 1) / kXcd;
@@ -529,29 +547,36 @@ int classify_points(sid_pm_ctx *ctx)
         } else order.insert(order.end(), src->begin(), src->end());
         a = b;
     }
-    // row-pair kernel: every launch position gets a block of global memory for its sum w'^2 values (256-byte granules)
+    // row-pair kernel: every launch position of a launch that keeps per-placement tables in global memory (gs and big launches)
+    // gets a block of its own there, in 256-byte granules: sum w'^2, then sum w' or the sweep's accumulators (block_entries);
+    // big layouts: every table of the point.  Points whose launch keeps its sums in LDS get none.  Scratch per run =
+    // the sum over those points: 14 KB per point at border 20 with sum w', 48 KB with the accumulators of four slot groups,
+    // 0.6 MB at border 111 (sid_pm.h).
     std::vector<uint32_t> goff;
     uint64_t gsii_granules = 0;
     if (rp) {
+        std::vector<uint32_t> gran_shape(shapes.size(), 0u);
+        for (size_t k = 1; k < shapes.size(); ++k) {
+            const Shape &sh = shapes[k];
+            if (sh.big) gran_shape[k] = (uint32_t)(big_layout(sh.wh, sh.ww, s, K, flags).big_bytes / 256);
+            else if (sh.gs) gran_shape[k] = block_entries(ctx, sh.wh, sh.ww, sh.band) / 64u;
+        }
         goff.resize((size_t)n);
         for (int64_t p = 0; p < n; ++p) {
             goff[(size_t)p] = (uint32_t)gsii_granules;
-            gsii_granules += gran_of[(size_t)order[(size_t)p]];
+            gsii_granules += gran_shape[(size_t)shape_of[(size_t)order[(size_t)p]]];
         }
-        if (gsii_granules >= 0xffffffffull) return fail(SID_PM_ERR_UNSUPPORTED, "sum-of-squares scratch beyond 1 TB");
+        if (gsii_granules >= 0xffffffffull) return fail(SID_PM_ERR_UNSUPPORTED, "per-placement tables in global memory beyond 1 TB");
+        {   // fail with the numbers before hipMalloc does
+            size_t free_b = 0, total_b = 0;
+            if (gsii_granules * 256ull > ctx->gsii.cap * sizeof(uint32_t) && hipMemGetInfo(&free_b, &total_b) == hipSuccess &&
+                gsii_granules * 256ull > (uint64_t)free_b + ctx->gsii.cap * sizeof(uint32_t))
+                return fail(SID_PM_ERR_NOMEM, "per-placement tables of %lld points need %.1f GB of device memory, %.1f GB are free (smaller batches, or borders below 69 px)",
+                            (long long)n, (double)gsii_granules * 256e-9, (double)free_b * 1e-9);
+        }
         if (int rc = ctx->gsii.reserve((size_t)std::max<uint64_t>(gsii_granules, 1) * 64)) return rc;
         if (int rc = ctx->d_goff.reserve((size_t)std::max<int64_t>(n, 1))) return rc;
         if (int rc = ctx->d_rec.reserve((size_t)std::max<int64_t>(n, 1))) return rc;
-        // Pool of blocks indexed by where a workgroup runs - WITHDRAWN as a default at the end of round 4: it was 0.9 % faster (the
-        // blocks stay in L2) but about one run in 25 000 came back with a burst of 30 .. 200 wrong results (7 events in 180 000 runs of
-        // one configuration against 0 in 140 000 with exclusive blocks) - a workgroup's hardware slot is not the
-        // invariant it was taken for.  SID_PM_GS_POOL=1 still builds it (experiments only): 8 XCDs x
-        // kGsPoolSlots slots of the largest block of any gs launch
-        uint32_t stride_max = 0;
-        for (const Bucket &bk : ctx->buckets) stride_max = std::max(stride_max, bk.gs_stride);
-        if (stride_max && getenv("SID_PM_GS_POOL") != nullptr) {
-            if (int rc = ctx->gs_pool.reserve((size_t)8 * sid::kGsPoolSlots * stride_max)) return rc;
-        } else { ctx->gs_pool.release(); }
     }
     std::vector<sid::PointRec> recs;
     if (rp) {
@@ -655,7 +680,7 @@ SID_EXPORT void sid_pm_destroy(sid_pm_ctx *ctx)
     }
     for (auto &pair : ctx->own) for (auto &b : pair) b.release();
     ctx->arena.release();
-    ctx->out.release(); ctx->out_ij.release(); ctx->dbg_err.release(); ctx->gsii.release(); ctx->d_goff.release(); ctx->d_rec.release(); ctx->gs_pool.release();
+    ctx->out.release(); ctx->out_ij.release(); ctx->dbg_err.release(); ctx->gsii.release(); ctx->d_goff.release(); ctx->d_rec.release();
     if (ctx->h_refused) (void)hipHostFree(ctx->h_refused);
     delete ctx;
 }
@@ -742,7 +767,8 @@ SID_EXPORT int sid_pm_set_points(sid_pm_ctx *ctx, const double *c1, const double
     make_rot(angles, K, alpha0, s, rot, rotv);
     std::vector<uint16_t> sampv;
     int nflag = 0;
-    if (!getenv("SID_PM_NO_SAMP_TABLE")) nflag = make_samp(rotv, K, s, sampv);
+    // (rot_order = 1: no offset table - every template sample is interpolated in float64 by the general sampler)
+    if (!getenv("SID_PM_NO_SAMP_TABLE") && !(flags & SID_PM_ROT_ORDER1)) nflag = make_samp(rotv, K, s, sampv);
 
     // one arena, one upload: [5n doubles | K angles | 4K rotation terms | order (int32 n) | sampling table]
     auto up = [](size_t v) { return (v + 255) / 256 * 256; };
@@ -806,7 +832,6 @@ SID_EXPORT int sid_pm_run(sid_pm_ctx *ctx)
         A.order = ctx->d_order + b.offset;
         A.gsii_off = ctx->d_goff.p ? ctx->d_goff.p + b.offset : nullptr;
         A.rec = ctx->d_rec.p ? ctx->d_rec.p + b.offset : nullptr;
-        A.gs_pool_stride = ctx->gs_pool.p ? b.gs_stride : 0u;
         A.n_launch = b.count;
         const int lds_launch = std::min(b.lds, sid::max_lds_bytes());
         A.lds_bytes = lds_launch;
@@ -980,7 +1005,8 @@ SID_EXPORT int sid_pm_debug_point(sid_pm_ctx *ctx, double c1, double r1, double 
     DevBuf<uint16_t> dsamp;
     std::vector<uint16_t> sampv;
     int nflag = 0;
-    if (!getenv("SID_PM_NO_SAMP_TABLE")) nflag = make_samp(rotv, K, s, sampv);
+    // (rot_order = 1: no offset table - every template sample is interpolated in float64 by the general sampler)
+    if (!getenv("SID_PM_NO_SAMP_TABLE") && !(flags & SID_PM_ROT_ORDER1)) nflag = make_samp(rotv, K, s, sampv);
     DevBuf<float> dccm, dhes;
     DevBuf<long long> dcyc;
     DevBuf<uint32_t> dgs;                                              // row-pair kernel: this point's sum w'^2 block + its offset (0)
@@ -993,7 +1019,7 @@ SID_EXPORT int sid_pm_debug_point(sid_pm_ctx *ctx, double c1, double r1, double 
         (rc = dout.reserve(5)) || (rc = dord.reserve(1)) || (rc = dij.reserve(3)) || (rc = dshape.reserve(2)) ||
         (rc = dt.reserve(tcount)) || (rc = dccm.reserve((size_t)std::max<int64_t>(cap, 1))) ||
         (rc = dhes.reserve((size_t)std::max<int64_t>(cap, 1))) || (rc = dcyc.reserve(32)) ||
-        (rc = dsamp.reserve(sampv.size() + 4)) || (rc = dgs.reserve(64 + (size_t)(wh > s ? (wh - s + 1) * (ww - s + 1) : 1))) || (rc = drec.reserve(1))) { cleanup(); return rc; }
+        (rc = dsamp.reserve(sampv.size() + 4)) || (rc = dgs.reserve(64 + (size_t)(wh > s ? sid::rp_block_entries(wh - s + 1, ww - s + 1, rp_rows(rpp, 4), 16 >> rpp, false, keep_acc_policy(rp, rpp, K)) : 64))) || (rc = drec.reserve(1))) { cleanup(); return rc; }
     const double v5[5] = {c1, r1, c2fg, r2fg, border};
     const int32_t zero = 0, shape0[2] = {0, 0};
     hipError_t e = hipSuccess;
@@ -1028,6 +1054,7 @@ SID_EXPORT int sid_pm_debug_point(sid_pm_ctx *ctx, double c1, double r1, double 
         A.samp = sampv.empty() ? nullptr : dsamp.p; A.samp_nflag = nflag;
         A.lds_bytes = lds;
         A.gsii = dgs.p + 64; A.gsii_off = dgs.p; A.rec = drec.p;
+        A.gs_keep_acc = keep_acc_policy(rp, rpp, K) ? 1u : 0u;
         step((hipError_t)(rp ? sid::launch_pm_rp(A, lds, 256, 4, rpp, 0, 3, ctx->stream)
                                        : sid::launch_pm_mfma(A, lds, 256, 4, use_paired(K), ctx->stream)));
         step(hipStreamSynchronize(ctx->stream));
@@ -1107,7 +1134,7 @@ SID_EXPORT int sid_pm_debug_hypot_selftest(sid_pm_ctx *ctx, uint64_t seed, int64
 // winner's NCC matrix, the placements themselves - times a factor for the residency class of its LDS footprint (fewer
 // co-resident workgroups hide less latency).  The six constants were fitted to tools/border_cost.py (template side 34, 15
 // angles, borders 20..50: within 4 % everywhere); what matters to the sharding are the ratios between points.
-static int estimate_points(const double *border, int64_t n, int img_size, int n_angles, double *cost_ns, int32_t *per_cu_out)
+static int estimate_points(const double *border, int64_t n, int img_size, int n_angles, uint32_t flags, double *cost_ns, int32_t *per_cu_out)
 {
     if (n < 0 || (n > 0 && (!border || (!cost_ns && !per_cu_out)))) return fail(SID_PM_ERR_ARG, "bad argument");
     const int s = img_size, K = n_angles;
@@ -1136,8 +1163,8 @@ static int estimate_points(const double *border, int64_t n, int img_size, int n_
         int cls = kMaxPerCu;
         if (rp) {
             static const bool no_band8 = getenv("SID_PM_NO_BAND8") != nullptr;
-            const ShapeClass sc = shape_class(rp, rpp, wn, wn, s, K, 0, sid::mfma_band8_supported(s) && !no_band8 && !rpp, false);
-            const sid::RpLdsLayout L4 = sid::rp_lds_layout(wn, wn, s, K <= sid::kRpGroup, rp_rows(rpp, 4), 0, sid::rp_tab_pitch(rpp), rp_own_hes(K, 0), sc.gs);
+            const ShapeClass sc = shape_class(rp, rpp, wn, wn, s, K, flags, sid::mfma_band8_supported(s) && !no_band8 && !rpp, false);   // (the flags decide the Hessian's LDS: rp_own_hes)
+            const sid::RpLdsLayout L4 = sid::rp_lds_layout(wn, wn, s, K <= sid::kRpGroup, rp_rows(rpp, 4), 0, sid::rp_tab_pitch(rpp), rp_own_hes(K, flags), sc.gs);
             const int per_cu = std::max(1, sc.cls), band = sc.band;            // (big layouts - class 0 - run one workgroup per CU, full table)
             const int rows = sc.big ? 4 : rp_rows(rpp, band), nb = (r + rows - 1) / rows, tiles = 2 * L4.npair + L4.nsingle;
             const double per_row_tile = (double)((s + 1) / 2 + s / 2 + 1) / 2.0 + (double)(((s - 32 + 1) / 2) * 2);
@@ -1162,17 +1189,17 @@ static int estimate_points(const double *border, int64_t n, int img_size, int n_
     return SID_PM_OK;
 }
 
-SID_EXPORT int sid_pm_estimate_cost(const double *border, int64_t n, int img_size, int n_angles, double *cost_ns)
+SID_EXPORT int sid_pm_estimate_cost(const double *border, int64_t n, int img_size, int n_angles, uint32_t flags, double *cost_ns)
 {
     if (n > 0 && !cost_ns) return fail(SID_PM_ERR_ARG, "bad argument");
-    return estimate_points(border, n, img_size, n_angles, cost_ns, nullptr);
+    return estimate_points(border, n, img_size, n_angles, flags, cost_ns, nullptr);
 }
 
-// Launch class of a point of that border: workgroups per CU (its LDS residency class: 1 .. 3, 4 for the slot-group layouts) in
-// the low four bits - a launch runs 256 x that many points at a time, which is what the tail of a SHORT launch costs (dist.py) -
-// plus 16 when the point runs in the launches that keep sum w'^2 in global memory (points of equal value share a launch).
-SID_EXPORT int sid_pm_estimate_residency(const double *border, int64_t n, int img_size, int n_angles, int32_t *per_cu)
+// Launch class of a point of that border (include/sid_pm.h): workgroups per CU in the low four bits - a launch runs 256 x that
+// many points at a time, which is what the tail of a SHORT launch costs (dist.py) - plus the SID_PM_CLASS_* bits that tell the
+// launches of equal residency apart (points of equal value share a launch).
+SID_EXPORT int sid_pm_estimate_residency(const double *border, int64_t n, int img_size, int n_angles, uint32_t flags, int32_t *per_cu)
 {
     if (n > 0 && !per_cu) return fail(SID_PM_ERR_ARG, "bad argument");
-    return estimate_points(border, n, img_size, n_angles, nullptr, per_cu);
+    return estimate_points(border, n, img_size, n_angles, flags, nullptr, per_cu);
 }

@@ -44,18 +44,13 @@ struct PMArgs {
     uint32_t *gsii;
     const uint32_t *gsii_off;
     const PointRec *rec;                            // [n_launch] row-pair kernel: one record per launch position (above)
-    // EXPERIMENTAL (SID_PM_GS_POOL=1; withdrawn as the default at the end of round 4: with it one run in ~25 000 returned a burst of
-    // wrong results - the premise below does not always hold).  Pool of sum w'^2 blocks indexed by WHERE the
-    // workgroup runs: slot = (XCD, CU of the XCD, which of the CU's
-    // LDS allocations) - read from the hardware registers XCC_ID, HW_ID and LDS_ALLOC, no atomics - so that the 768 blocks in
-    // flight are always the same 768 and stay in their XCD's L2, instead of 175 MB of write-once blocks travelling to HBM and
-    // back every step.  Two co-resident workgroups never share a slot (they cannot share an LDS allocation of one CU:
-    // tools/ubench/resident_slot.hip, 0 collisions in 8 x 10^4 workgroups), and a slot is only ever touched through ONE XCD's L2
-    // (the eight L2s are not coherent with each other inside a kernel).  gs_pool_stride = 0: no pool - the exclusive block of
-    // the launch position (gsii_off), which is also what a workgroup uses whose registers read unexpectedly.
-    uint32_t *gs_pool;                              // [8 XCDs][kGsPoolSlots][gs_pool_stride]
-    uint32_t gs_pool_stride;
-    uint32_t gs_keep_si;                            // blocks of global memory hold 2 x round_up(placements, 64) entries: sum w'^2, then sum w' kept by the sweep for the winner                        // u32 entries per slot in this launch (the largest block of its points, 256-byte granules)
+    uint32_t gs_keep_si;                            // blocks of global memory hold 2 x round_up(placements, 64) entries: sum w'^2, then sum w' kept by the sweep for the winner
+    // round 5: the launch keeps the sweep's ACCUMULATORS - the exact integer S_IT' of every slot at every placement, sum w' in the
+    // ones slot - in the point's block of global memory, behind sum w'^2: [round_up(placements, 64) u32 | rows_pad x cols_pad
+    // placements x (slots of one group) i32] (rp_acc_dims).  The NCC matrix of the winning angle is then a normalisation of
+    // stored sums (rp_winner_kept): no second pass over the window, no operand staging, no matrix instructions.  16 B per
+    // placement with four slot groups (the reference's default: 3 angles), 32 B with two (<= 7 angles), 64 B with the full table.
+    uint32_t gs_keep_acc;
     // diagnostics (debug_point only; null in production launches)
     uint8_t *dbg_templates; float *dbg_ccm; float *dbg_hes; int32_t *dbg_shape; int64_t dbg_cap;
     long long *dbg_cycles;                          // [32] shader-clock stamps at phase boundaries
@@ -68,7 +63,6 @@ __host__ __device__ inline int round_up(int v, int m) { return (v + m - 1) / m *
 constexpr int kMiscMfmaBytes = 2688;
 constexpr int kTrowPad = 36;         // zero rows around a winner operand block: 16 above, 20 below (the step loop runs in fours)
 constexpr int kQueueCap = 192;       // arg-max candidates waiting for exact evaluation (16 B each)
-constexpr int kGsPoolSlots = 128;    // slots per XCD in the pool of sum w'^2 blocks: 32 CUs x 4 LDS allocations
 constexpr int kRpQueueWithSi = 128;  // ... and the sums kept for the winner (RpLdsLayout::si_off) leave it at least this
 constexpr int kRpQueueMin = 64;      // row-pair kernel: the queue shrinks to this where it decides the residency class (overflow is evaluated in place)
 
@@ -310,6 +304,24 @@ __host__ __device__ inline RpLdsLayout rp_lds_layout(int wh, int ww, int s, bool
     return L;
 }
 
+// kept accumulators (PMArgs::gs_keep_acc): the table is padded to whole work items, so that the sweep stores without predicates -
+// cols_pad = the placement columns its tiles cover, rows_pad = bands x output rows per item
+__host__ __device__ inline void rp_acc_dims(int rh, int rw, int rows_per_item, int &cols_pad, int &rows_pad)
+{
+    const int rem = rw % 32;
+    cols_pad = 32 * (rw / 32 + (rem > 16 ? 1 : 0)) + ((rem > 0 && rem <= 16) ? 16 : 0);
+    rows_pad = (rh + rows_per_item - 1) / rows_per_item * rows_per_item;
+}
+// u32 entries of a point's block of global memory: sum w'^2 (+ sum w' when kept on its own), + the accumulator table
+__host__ __device__ inline uint32_t rp_block_entries(int rh, int rw, int rows_per_item, int slots_per_group, bool keep_si, bool keep_acc)
+{
+    const uint32_t npos64 = (uint32_t)round_up(rh * rw, 64);
+    if (!keep_acc) return npos64 * (keep_si ? 2u : 1u);
+    int cp, rp;
+    rp_acc_dims(rh, rw, rows_per_item, cp, rp);
+    return npos64 + (uint32_t)round_up(cp * rp * slots_per_group, 64);
+}
+
 // window pitches the row-pair kernel is instantiated for (besides the run-time pitch): the smallest one that holds
 // `natural`, or 0 (run-time pitch) beyond the largest
 __host__ __device__ inline int rp_class_pitch(int natural)
@@ -318,6 +330,12 @@ __host__ __device__ inline int rp_class_pitch(int natural)
 }
 // paired: 0 = one group of 16 slots, 1 = two groups (at most 7 angles), 2 = four groups (at most 3 angles)
 // occ: wavefronts per SIMD the build allows - 3, or 4 (128 VGPRs; slot groups with pitch 104 only: four workgroups per CU)
+// kept accumulators are compiled into the slot-group kernels (paired != 0); into all with -DSID_KEEP_ACC_FULL (pm_kernel_rp.inc)
+#ifdef SID_KEEP_ACC_FULL
+constexpr bool kKeepAccFull = true;
+#else
+constexpr bool kKeepAccFull = false;
+#endif
 int launch_pm_rp(const PMArgs &args, int lds_bytes, int nthreads, int band, int paired, int pitch, int occ, void *stream, bool big = false);
 bool rp_pitch_instantiated(int band, int paired, int pitch, int occ = 3);
 

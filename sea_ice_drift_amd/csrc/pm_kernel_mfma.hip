@@ -108,6 +108,8 @@ struct Geo {
     int si_off;                      // row-pair kernel: sum w' per placement kept from the sweep for the winner (0: none)
     int gsi;                         // ... the same in the point's block of global memory, behind sum w'^2: offset in u32 entries (0: none)
     int hist_off;                    // 5 KB behind the NCC matrix of the winning angle for ph_hessian_fast (0: none - the general ph_hessian runs)
+    int gsa, gsa_rw;                 // kept accumulators (PMArgs::gs_keep_acc): offset of the table in the point's block (u32 entries; 0: none) and its row pitch in placements
+    int lin;                         // rot_order = 1 (SID_PM_ROT_ORDER1, pmlib.py:89): templates sampled bilinearly, every sample through sample_exact
     long long r0, c0;                // window origin on image 2
     double c1, r1, nd;
     unsigned long long big;          // row-pair kernel, big layouts (rp_lds_layout): the point's block of global memory
@@ -679,7 +681,7 @@ __device__ __noinline__ void ph_patch(const uint8_t *img1, long long rows1, long
 // whenever the rounding or the image-bounds decision could depend on the last bits (|doubt| < kGuard,
 // float error < 2.5e-5) the sample is flagged and redone afterwards with scipy's double arithmetic.
 struct SampleGeom {
-    const uint8_t *patch; int ppitch, pr0, pc0, s, ngrp, ig, j; bool act, inside;
+    const uint8_t *patch; int ppitch, pr0, pc0, s, ngrp, ig, j; bool act, inside, lin;
     float lo_r, hi_r, lo_c, hi_c;
     double c1, r1, rmax1, cmax1;
 };
@@ -698,6 +700,7 @@ __device__ __forceinline__ SampleGeom sample_geom(const Geo &G, int s, long long
     g.lo_r = (float)(-G.pr0); g.hi_r = (float)(rows1 - 1 - G.pr0);
     g.lo_c = (float)(-G.pc0); g.hi_c = (float)(cols1 - 1 - G.pc0);
     g.c1 = G.c1; g.r1 = G.r1; g.rmax1 = (double)(rows1 - 1); g.cmax1 = (double)(cols1 - 1);
+    g.lin = G.lin != 0;
     return g;
 }
 
@@ -714,6 +717,24 @@ __device__ __forceinline__ int sample_exact(const SampleGeom &g, const double *r
     cc = cc + off1;
     int v = 0;
     if (rr >= 0.0 && rr <= g.rmax1 && cc >= 0.0 && cc <= g.cmax1) {
+        if (g.lin) {
+            // rot_order = 1: scipy's spline order 1 (NI_GeometricTransform, mode 'constant', cval 0, uint8 output) - weights
+            // (1 - y, y), the four taps accumulated in float64 in the order (0,0) (0,1) (1,0) (1,1) as ((v w_row) w_col), then
+            // t > 0 ? t + 0.5 : 0, clamped to 255, truncated.  A tap behind the last image row / column carries the weight 0
+            // (the coordinate is then integral) and reads a finite patch byte.  Oracle: get_template_order1, fixture G1b.
+            const double fr = floor(rr), fc = floor(cc);
+            const double yr = rr - fr, yc = cc - fc;
+            const double w0r = 1.0 - yr, w0c = 1.0 - yc;
+            const uint8_t *p = g.patch + ((int)fr - g.pr0) * g.ppitch + ((int)fc - g.pc0);
+            double t = 0.0;
+            t = t + ((double)p[0] * w0r) * w0c;
+            t = t + ((double)p[1] * w0r) * yc;
+            t = t + ((double)p[g.ppitch] * yr) * w0c;
+            t = t + ((double)p[g.ppitch + 1] * yr) * yc;
+            t = t > 0.0 ? t + 0.5 : 0.0;
+            t = t > 255.0 ? 255.0 : t;
+            return (int)t;
+        }
         const int ri = (int)floor(rr + 0.5) - g.pr0, ci = (int)floor(cc + 0.5) - g.pc0;
         v = g.patch[ri * g.ppitch + ci];
     }
@@ -747,6 +768,7 @@ __device__ __forceinline__ u32 sample_fast5(const SampleGeom &g, const double *r
         const float flr = floorf(tr), flc = floorf(tc_);
         // doubtful when the coordinate is within kGuard of a rounding boundary
         bool sure = fabsf((tr - flr) - 0.5f) < 0.5f - kGuard && fabsf((tc_ - flc) - 0.5f) < 0.5f - kGuard;
+        sure = sure && !g.lin;                                         // (bilinear sampling: every sample takes the float64 route)
         bool in_f = true;
         if (!INSIDE) {
             const float rrf = tr - 0.5f, ccf = tc_ - 0.5f;
@@ -1815,7 +1837,7 @@ __global__ __launch_bounds__(BAND == 8 ? 512 : kMaxBlockM, BAND == 8 ? 2 : kOccM
         G->win_magic = 0xffffffffu / (u32)(L.wpitch >> 2) + 1u; G->patch_magic = 0xffffffffu / (u32)(L.ppitch >> 2) + 1u;
         G->rw_magic = 0xffffffffu / (u32)rw + 1u;
         G->r0 = r0; G->c0 = c0; G->c1 = c1; G->r1 = r1; G->nd = (double)(s * s);
-        G->hist_off = 0;
+        G->hist_off = 0; G->lin = (int)((A.flags >> 3) & 1u);
         m->zero_flag = 0; m->gmax_key = 0x007fffffu /* f2key(-inf) */; m->qcount = 0;
         for (int k = 0; k < 5; ++k) m->gw[k] = A.gauss_w[k];
     }

@@ -16,14 +16,14 @@ import os
 import numpy as np
 
 
-def point_cost(border, img_size=34, n_angles=15):
+def point_cost(border, img_size=34, n_angles=15, flags=1):
     """Estimated cost of a grid point (nanoseconds on one MI355X; only the ratios matter here).  Computed by the library
     (include/sid_pm.h ``sid_pm_estimate_cost``, host arithmetic) from what the kernel executes for a point of that search
     border - matrix instructions of the sweep and of the winner's NCC matrix, placements - and from the residency class of
     its LDS footprint, for the template side and angle count of the run; it reproduces the staircase that
     tools/border_cost.py measures (placement tiles per output row, work items per wavefront, workgroups per CU) within 4 %."""
     from . import _capi
-    return _capi.estimate_cost(np.asarray(border, dtype=np.float64), img_size, n_angles)
+    return _capi.estimate_cost(np.asarray(border, dtype=np.float64), img_size, n_angles, flags)
 
 
 # tail of a launch in run times of one of its workgroups, by residency class (workgroups per CU): with 256 x class points in
@@ -48,7 +48,7 @@ def _shard_times(cost, cls, cuts):
     return t
 
 
-def shard_indices_by_cost(border, world_size, rank, img_size=34, n_angles=15):
+def shard_indices_by_cost(border, world_size, rank, img_size=34, n_angles=15, flags=1):
     """Indices owned by `rank` when the points, ordered by border (largest first, stable), are cut into `world_size`
     contiguous runs of equal estimated TIME.  A rank then holds one or two neighbouring border classes instead of an
     eighth of every class, i.e. one or two launches that are eight times longer: at 5 000 points per rank the tails of
@@ -65,8 +65,8 @@ def shard_indices_by_cost(border, world_size, rank, img_size=34, n_angles=15):
     n = order.size
     if n == 0 or world_size <= 1:
         return np.sort(order) if rank == 0 else np.zeros(0, dtype=order.dtype)
-    cost = point_cost(border[order], img_size, n_angles)
-    cls = _capi.estimate_residency(border[order], img_size, n_angles)
+    cost = point_cost(border[order], img_size, n_angles, flags)          # (flags of the run: sid_pm.h SID_PM_HES_NORM = 1 ...)
+    cls = _capi.estimate_residency(border[order], img_size, n_angles, flags)
     cum = np.concatenate([[0.0], np.cumsum(cost)])
     share = np.full(world_size, cum[-1] / world_size)               # cost each shard is to hold
 

@@ -12,8 +12,9 @@ The structure is  prelude (host, NumPy)  ->  dispatch (GPU)  ->  postlude (host,
 * the dispatch replaces the ``multiprocessing.Pool.map`` of pmlib.py:436-448 with the HIP
   kernel behind the C ABI (``_capi``).  ``threads`` is accepted for signature compatibility
   and ignored.  There is no CPU fallback: without the HIP library / a gfx950 device this
-  raises.  Options the kernel does not implement (``rot_order != 0``, a
-  user ``template_matcher``, ``img_size`` outside 2..64) raise ``NotImplementedError``;
+  raises.  Options the kernel does not implement (``rot_order`` above 1, an ``mtype`` other
+  than TM_CCOEFF_NORMED, a user ``template_matcher``, ``img_size`` outside 2..64) raise
+  ``NotImplementedError``;
 * ``pm_postlude``  turns the (N,5) result block into the seven output grids as
                    pmlib.py:451-497 does.
 """
@@ -30,6 +31,7 @@ from sea_ice_drift_amd import _capi
 from sea_ice_drift_amd.lib import NSR, _fill_gpi, interpolation_near, interpolation_poly
 
 DEFAULT_SRS = '+proj=latlong +datum=WGS84 +ellps=WGS84 +no_defs'
+TM_CCOEFF_NORMED = 5                  # cv2.TM_CCOEFF_NORMED, the reference's default mtype (pmlib.py:119)
 
 
 # ------------------------------------------------------------------ small pieces
@@ -192,12 +194,22 @@ def _sweep_options(kwargs):
     if kwargs.get('template_matcher') is not None:
         raise NotImplementedError('template_matcher= is a CPU plug point of the reference (pmlib.py:120); '
                                   'the device kernel implements TM_CCOEFF_NORMED only')
-    if kwargs.get('rot_order', 0) != 0:
-        raise NotImplementedError('rot_order=%r: the device samples templates nearest-neighbour (order 0) only'
-                                  % (kwargs['rot_order'],))
+    # mtype (pmlib.py:119,156) is handed to the matcher; the device matcher IS cv2.TM_CCOEFF_NORMED (= 5 in every OpenCV
+    # release: imgproc.hpp TemplateMatchModes).  Anything else would be answered with the wrong correlation: refuse it.
+    mtype = kwargs.get('mtype', None)
+    if mtype is not None and (isinstance(mtype, bool) or mtype != TM_CCOEFF_NORMED):
+        raise NotImplementedError('mtype=%r: the device matcher implements cv2.TM_CCOEFF_NORMED (%d) only (pmlib.py:119,156)'
+                                  % (mtype, TM_CCOEFF_NORMED))
+    # rot_order (pmlib.py:89,112-113): scipy's spline order of the template rotation.  0 (nearest, the default) and 1
+    # (bilinear, scipy's double arithmetic and uint8 rounding) run on the device; orders 2..5 filter the WHOLE image 1 with
+    # scipy's recursive B-spline prefilter before sampling - a different algorithm over 10^8 pixels, not implemented.
+    rot_order = kwargs.get('rot_order', 0)
+    if isinstance(rot_order, bool) or rot_order not in (0, 1):
+        raise NotImplementedError('rot_order=%r: templates are sampled nearest-neighbour (0) or bilinear (1); orders 2..5 need '
+                                  "scipy's whole-image spline prefilter" % (rot_order,))
     angles = list(kwargs.get('angles', [-3, 0, 3]))
     flags = _capi.flags_from_kwargs(hes_norm=kwargs.get('hes_norm', True), hes_smth=kwargs.get('hes_smth', False),
-                                    mcc_norm=kwargs.get('mcc_norm', False))
+                                    mcc_norm=kwargs.get('mcc_norm', False), rot_order=int(rot_order))
     return angles, flags
 
 
@@ -239,10 +251,7 @@ def release_contexts(timeout=5.0):
                 ctx.close()
             finally:
                 lock.release()
-    try:
-        _capi.release_workspaces(-1)
-    except Exception:                                                 # noqa: BLE001 - at exit the library may be gone already
-        pass
+    _capi.release_workspaces(-1)                                      # (a no-op unless this process loaded the library)
 
 
 atexit.register(release_contexts)

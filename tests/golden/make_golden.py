@@ -6,10 +6,12 @@ stub-import recipe).  The fixtures hold numbers only - inputs (or the seeds that
 them, with a sha256) and the outputs the reference's functions returned:
 
   g1_templates.npz   pmlib.get_template              (pmlib.py:89-115)
+  g1b_templates_order1.npz  pmlib.get_template(rot_order=1)  (pmlib.py:89-115, scipy order 1)
   g2_hessian.npz     pmlib.get_hessian               (pmlib.py:36-59)
   g3_use_mcc.npz     pmlib.use_mcc / rotate_and_match (pmlib.py:117-212) with
                      template_matcher=<restated TM_CCOEFF_NORMED> injected through the
                      reference's own plug point (cv2 is absent: parity unpinned at that call)
+  g3b_use_mcc_order1.npz  pmlib.use_mcc(rot_order=1) on G3's pair and points
   g4_pattern_matching.npz  pmlib.pattern_matching    (pmlib.py:326-497) end to end on an
                      affine stand-in for Nansat, incl. the kernel-input vectors it built
   g5_fullsize.npz    sha256 of the 10000x10000 benchmark pair + C-oracle results on a 1 %
@@ -77,6 +79,38 @@ def make_g1(pmlib):
     np.savez_compressed(os.path.join(HERE, 'g1_templates.npz'),
                         img_sha=syn.sha256(img), t34=np.array(out[:48], dtype=np.uint8),
                         t35=np.array(out[48:], dtype=np.uint8), edge=edge)
+
+
+def make_g1b(pmlib):
+    """get_template(..., rot_order=1): scipy's bilinear sampling (double arithmetic, uint8 output rounding) over G1's
+    angle / centre set, plus centres whose template reaches the image border (mode='constant', cval=0)."""
+    img = g1_image()
+    out = []
+    for s in (34, 35):
+        for a in G1_ANGLES:
+            for (c, r) in G1_CENTRES:
+                out.append(pmlib.get_template(img, c, r, a, s, rot_order=1).ravel())
+    edges = [(5, 5, 10, 34), (390.5, 17.25, -6, 35), (17, 399, 3, 34), (399, 399, 0, 35), (0, 0, 0, 34)]
+    d = dict(img_sha=syn.sha256(img), t34=np.array(out[:48], dtype=np.uint8), t35=np.array(out[48:], dtype=np.uint8),
+             edge_args=np.array(edges, dtype=np.float64))
+    for k, (c, r, a, s) in enumerate(edges):
+        d['edge%d' % k] = pmlib.get_template(img, c, r, a, s, rot_order=1)
+    np.savez_compressed(os.path.join(HERE, 'g1b_templates_order1.npz'), **d)
+
+
+def make_g3b(pmlib):
+    """use_mcc(..., rot_order=1) on G3's pair and points (the kwarg travels use_mcc -> rotate_and_match -> get_template,
+    pmlib.py:204-208,151), restated matcher injected as in G3."""
+    img1, img2 = g3_pair()
+    c1, r1, c2fg, r2fg, border = g3_points()
+    d = dict(pair_sha=syn.sha256(img1, img2))
+    for s, alpha0 in ((34, 0.0), (35, -3.85)):
+        for k, angles in enumerate(G3_ANGLE_SETS):
+            res = np.array([pmlib.use_mcc(c1[i], r1[i], c2fg[i], r2fg[i], border[i], img1, img2, s, alpha0,
+                                          angles=angles, rot_order=1, template_matcher=po.match_template)
+                            for i in range(len(c1))], dtype=np.float64)
+            d['out_s%d_k%d' % (s, k)] = res
+    np.savez_compressed(os.path.join(HERE, 'g3b_use_mcc_order1.npz'), **d)
 
 
 def g2_inputs():
@@ -312,7 +346,7 @@ def make_g7():
 
 
 def main():
-    which = sys.argv[1:] or ['g1', 'g2', 'g3', 'g4', 'g5', 'g6', 'g7']
+    which = sys.argv[1:] or ['g1', 'g1b', 'g2', 'g3', 'g3b', 'g4', 'g5', 'g6', 'g7']
     if 'g7' in which:
         t = time.time()
         make_g7()
@@ -323,7 +357,7 @@ def main():
         make_g6(reflib)
         print('g6 done in %.1f s' % (time.time() - t))
     c_oracle.build()
-    for name, fn in (('g1', make_g1), ('g2', make_g2), ('g3', make_g3), ('g4', make_g4)):
+    for name, fn in (('g1', make_g1), ('g1b', make_g1b), ('g2', make_g2), ('g3', make_g3), ('g3b', make_g3b), ('g4', make_g4)):
         if name in which:
             t = time.time()
             fn(pmlib)

@@ -100,12 +100,30 @@ def test_bucket_walk_equals_the_brute_force_pass(monkeypatch):
         np.testing.assert_array_equal(got, exp)                           # (NaN positions and bits alike)
 
 
-def test_nearest_keypoint_distance_is_exact():
+def test_nearest_keypoint_distance_is_exact(monkeypatch):
+    """The distance to the nearest key point through the grid of buckets (round 5: rings of cells around the query, a bound
+    that stops the search) against a KD-tree and against the brute-force kernel (SID_FG_NO_GRID=1), bit for bit: uniform
+    seeds, seeds clustered in a corner (most cells empty: long ring walks), queries far outside the seeds' box, queries ON
+    seeds, seeds on one line, a handful of seeds (brute force)."""
     rng = np.random.default_rng(9)
-    seeds = np.floor(rng.uniform(0, 3000, (5000, 2)))
-    q = np.floor(rng.uniform(0, 3000, (30000, 2)))
-    exp, _ = cKDTree(seeds).query(q, k=1)
-    np.testing.assert_array_equal(_capi.fg_nearest_dist(seeds, q), exp)
+    cases = []
+    cases.append((np.floor(rng.uniform(0, 3000, (5000, 2))), np.floor(rng.uniform(0, 3000, (30000, 2)))))
+    cl = np.concatenate([np.floor(rng.normal(400, 60, (4000, 2))), np.floor(rng.uniform(0, 10000, (40, 2)))])
+    cases.append((cl, np.floor(rng.uniform(-500, 10500, (40000, 2)))))
+    s3 = np.floor(rng.uniform(2000, 2600, (20000, 2)))
+    cases.append((s3, np.concatenate([s3[:5000], np.floor(rng.uniform(0, 10000, (20000, 2))), rng.uniform(1900, 2700, (5000, 2))])))
+    cases.append((np.stack([np.arange(1000.0), np.full(1000, 77.0)], axis=1) + np.array([[0.0, 0.0]]), np.floor(rng.uniform(-50, 1050, (5000, 2)))))
+    cases.append((np.floor(rng.uniform(0, 100, (7, 2))), np.floor(rng.uniform(0, 100, (300, 2)))))
+    for seeds, q in cases:
+        got = _capi.fg_nearest_dist(seeds, q)
+        integral = q == np.floor(q)                                   # (pixel coordinates: sqrt of an exact integer, as the EDT's)
+        sel = integral.all(axis=1)
+        exp, _ = cKDTree(seeds).query(q[sel], k=1)
+        np.testing.assert_array_equal(got[sel], exp)
+        monkeypatch.setenv('SID_FG_NO_GRID', '1')
+        brute = _capi.fg_nearest_dist(seeds, q)
+        monkeypatch.delenv('SID_FG_NO_GRID')
+        np.testing.assert_array_equal(got, brute)
 
 
 def test_prelude_on_the_device_equals_the_reference_fixture():

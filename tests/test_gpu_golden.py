@@ -93,8 +93,8 @@ def test_unsupported_sizes_and_flags_are_errors(pm_ctx):
     assert e.value.code == -4
     with pytest.raises(_capi.SidPmError):
         pm_ctx.set_points(*one, 34, 0.0, [])
-    with pytest.raises(_capi.SidPmError) as e:                     # unknown flag bit
-        pm_ctx.set_points(*one, 34, 0.0, [0.0], flags=8)
+    with pytest.raises(_capi.SidPmError) as e:                     # unknown flag bit (8 = SID_PM_ROT_ORDER1 is one now)
+        pm_ctx.set_points(*one, 34, 0.0, [0.0], flags=16)
     assert e.value.code == -1
     with pytest.raises(_capi.SidPmError) as e:                     # border too large for LDS
         pm_ctx.set_points([150.0], [150.0], [150.0], [150.0], [112.0], 34, 0.0, [0.0])

@@ -311,8 +311,7 @@ def test_every_launch_class_incl_global_sums_borders_20_to_68(pm_ctx, c_oracle, 
 def test_borders_69_to_111_keep_their_tables_in_global_memory(pm_ctx, c_oracle, monkeypatch, s, angles, flags):
     """Round 4: beyond border 68 the per-placement tables of a point (sum w'^2, the row sums, the NCC matrix of the winning angle,
     the Hessian magnitudes) no longer fit the 160 KB of LDS next to the window; those points run `pm_kernel_rp<S, 4, 0, 0, true>`,
-    which keeps them in the point's block of global memory (the exclusive block of the launch position; SID_PM_GS_POOL=1: a slot of
-    the experimental per-XCD pool).  Borders up to 111 (reference kwarg max_border; its default is 50), any angle set (slot-group
+    which keeps them in the point's block of global memory.  Borders up to 111 (reference kwarg max_border; its default is 50), any angle set (slot-group
     sets run the full-table kernel there), both Hessian routes, several groups of angles."""
     size = 1700
     img1, img2 = syn.make_pair(size, size, seed=29)
@@ -326,19 +325,10 @@ def test_borders_69_to_111_keep_their_tables_in_global_memory(pm_ctx, c_oracle, 
     exp, exp_ij = c_oracle.pm_batch(img1, img2, c1, r1, c2, r2, borders, s, 0.0, angles, rot=rot, nthreads=8, flags=flags)
     assert np.isfinite(exp[:, 0]).sum() > n * 0.9
     pm_ctx.upload_pair(img1, img2)
-    results = []
-    for env in (None, 'SID_PM_GS_POOL'):
-        monkeypatch.delenv('SID_PM_GS_POOL', raising=False)
-        if env:
-            monkeypatch.setenv(env, '1')
-        pm_ctx.set_points(c1, r1, c2, r2, borders, s, 0.0, angles, rot=rot, flags=flags)
-        pm_ctx.run()
-        got, got_ij = pm_ctx.fetch()
-        assert_parity(got, got_ij, exp, exp_ij, mcc_norm=bool(flags & 4))
-        results.append((got, got_ij))
-    np.testing.assert_array_equal(results[1][1], results[0][1])
-    np.testing.assert_array_equal(results[1][0], results[0][0])
-    monkeypatch.delenv('SID_PM_GS_POOL', raising=False)
+    pm_ctx.set_points(c1, r1, c2, r2, borders, s, 0.0, angles, rot=rot, flags=flags)
+    pm_ctx.run()
+    got, got_ij = pm_ctx.fetch()
+    assert_parity(got, got_ij, exp, exp_ij, mcc_norm=bool(flags & 4))
     # one more border does not fit any more: an error, not a NaN
     with pytest.raises(_capi.SidPmError) as e:
         pm_ctx.set_points(c1[:1], r1[:1], c2[:1], r2[:1], [112.0], s, 0.0, angles, rot=rot)

@@ -39,6 +39,50 @@ def test_g1_templates_numpy_and_c(c_oracle):
     assert g['edge'].min() == 0
 
 
+# ---------------------------------------------------------------- G1b get_template(rot_order=1)
+def test_g1b_templates_order1_numpy_and_c(c_oracle):
+    """scipy's bilinear sampling (pmlib.py:89,112-113 with rot_order=1), restated in NumPy and C, against the reference's
+    own get_template on G1's angle / centre set and on templates cut by the image border."""
+    g = load('g1b_templates_order1.npz')
+    img = mg.g1_image()
+    assert syn.sha256(img) == str(g['img_sha'])
+    differs_from_order0 = 0
+    for s, key in ((34, 't34'), (35, 't35')):
+        k = 0
+        for a in mg.G1_ANGLES:
+            for (c, r) in mg.G1_CENTRES:
+                exp = g[key][k].reshape(s, s)
+                np.testing.assert_array_equal(po.get_template_order1(img, c, r, a, s), exp)
+                np.testing.assert_array_equal(c_oracle.get_template(img, c, r, po.rotation_terms(a, s), s, rot_order=1), exp)
+                differs_from_order0 += int((po.get_template(img, c, r, a, s) != exp).any())
+                k += 1
+    assert differs_from_order0 > 60                                # (integral centres at 0 / 90 degrees sample the grid itself)
+    for k, (c, r, a, s) in enumerate(g['edge_args']):
+        s = int(s)
+        np.testing.assert_array_equal(po.get_template_order1(img, c, r, a, s), g['edge%d' % k])
+        np.testing.assert_array_equal(c_oracle.get_template(img, c, r, po.rotation_terms(a, s), s, rot_order=1), g['edge%d' % k])
+        assert g['edge%d' % k].min() == 0
+
+
+@pytest.mark.parametrize('s,alpha0', [(34, 0.0), (35, -3.85)])
+def test_g3b_use_mcc_order1(c_oracle, s, alpha0):
+    g = load('g3b_use_mcc_order1.npz')
+    g3 = load('g3_use_mcc.npz')
+    img1, img2 = mg.g3_pair()
+    assert syn.sha256(img1, img2) == str(g['pair_sha'])
+    v = [g3[k] for k in ('c1', 'r1', 'c2fg', 'r2fg', 'border')]
+    for k, angles in enumerate(mg.G3_ANGLE_SETS):
+        exp = g['out_s%d_k%d' % (s, k)]
+        got_c, ij = c_oracle.pm_batch(img1, img2, *v, s, alpha0, angles, rot=rot_for(angles, alpha0, s), flags=1 | 8, nthreads=4)
+        np.testing.assert_array_equal(got_c, exp)
+        assert ((ij[:, 2] == -1) == np.isnan(exp[:, 0])).all()
+        if k == 0:
+            got_n, _ = po.pm_batch(img1, img2, *v, s, alpha0, angles, flags=1 | po.FLAG_ROT_ORDER1)
+            np.testing.assert_array_equal(got_n, exp)
+        assert not np.array_equal(exp, g3['out_s%d_k%d_m0' % (s, k)], equal_nan=True)   # (order 1 is not order 0)
+    assert np.isnan(g['out_s%d_k0' % s][:, 0]).any()
+
+
 # ---------------------------------------------------------------- G2 get_hessian
 @pytest.mark.parametrize('n', [42, 72, 101, 102])
 def test_g2_hessian(c_oracle, n):
