@@ -51,7 +51,7 @@ struct Image {
     int64_t rows = 0, cols = 0, stride = 0;
 };
 
-struct Bucket { int offset, count, lds, band, pitch, occ; uint32_t gs_stride = 0; bool big = false; };   // gs_stride: largest sum w'^2 block of the launch's points, in u32 entries (gs launches; 0 otherwise)   // occ: wavefronts per SIMD of the kernel build (3; 4: the four-per-CU class of the slot-group layouts); band: output rows per sweep work item of this launch (4 or 8); pitch: compile-time window pitch of the row-pair kernel (0: run-time)
+struct Bucket { int offset, count, lds, band, pitch, occ; uint32_t gs_stride = 0; bool big = false; bool keep = false; };   // keep: the launch keeps the sweep's accumulators (PMArgs::gs_keep_acc) and takes recycled blocks   // gs_stride: largest sum w'^2 block of the launch's points, in u32 entries (gs launches; 0 otherwise)   // occ: wavefronts per SIMD of the kernel build (3; 4: the four-per-CU class of the slot-group layouts); band: output rows per sweep work item of this launch (4 or 8); pitch: compile-time window pitch of the row-pair kernel (0: run-time)
 
 template <typename T>
 struct DevBuf {
@@ -83,6 +83,10 @@ struct sid_pm_ctx {
     // pair streaming: uploads run on their own stream; slot_ready[s] = upload of slot s complete,
     // slot_done[s] = last kernels reading slot s complete (an upload into s waits for it)
     hipStream_t copy_stream = nullptr;
+    // short runs (a rank's shard of an N-GPU run: two or three launches of a few rounds of workgroups each) put their launches
+    // side by side on these streams, so that one launch's half-empty last round is filled by the next (sid_pm_run)
+    hipStream_t side[3] = {nullptr, nullptr, nullptr};
+    hipEvent_t fork_ev = nullptr, join_ev[3] = {nullptr, nullptr, nullptr};
     hipEvent_t slot_ready[2] = {nullptr, nullptr}, slot_done[2] = {nullptr, nullptr};
     bool ready_rec[2] = {false, false}, done_rec[2] = {false, false};
     // resident points: one device arena (a single upload per set_points) carved into the vectors below
@@ -91,6 +95,7 @@ struct sid_pm_ctx {
     int32_t *d_order = nullptr;
     double *d_angles = nullptr, *d_rot = nullptr;
     uint16_t *d_samp = nullptr;         // sampling table of the kernel (make_samp)
+    uint32_t *d_samp2 = nullptr;        // ... sorted per angle for the row-pair kernel (make_samp2; SID_PM_NO_SAMP2=1: not built)
     bool rp = false;                    // the resident points run the row-pair kernel (decided at set_points: use_rp) ...
     int rp_paired = 0;                  // ... with slot groups: 0 none, 1 two groups (<= 7 angles), 2 four groups (<= 3 angles)
     bool gs_keep_si = true;             // the blocks of global memory are sized for sum w' as well (classify_points; SID_PM_NO_GSI=1: not)
@@ -107,6 +112,8 @@ struct sid_pm_ctx {
     DevBuf<uint32_t> gsii;              // row-pair kernel: sum w'^2 per placement of every resident point (PMArgs::gsii) ...
     DevBuf<uint32_t> d_goff;            // ... and the offset of every launch position's block in it (units of 64 entries)
     DevBuf<sid::PointRec> d_rec;        // row-pair kernel: one record per launch position (index, block offset, the five inputs)
+    DevBuf<uint32_t> ring, pool;        // recycled blocks of the launches that keep accumulators (PMArgs::ring / pool; SID_PM_NO_RECYCLE=1: none)
+    uint32_t pool_stride = 0;           // u32 entries per recycled block: the largest block of any launch that takes them
     int32_t *h_refused = nullptr;       // pinned, device-visible: valid points a launch could not hold (PMArgs::refused)
     double *user_out = nullptr;         // caller-owned result arrays (bind_results)
     int32_t *user_ij = nullptr;
@@ -177,6 +184,33 @@ int make_samp(const std::vector<double> &rot, int K, int s, std::vector<uint16_t
             }
     }
     return nflag;
+}
+
+// The sampling table sorted per angle for the row-pair kernel (PMArgs::samp2): run records first, gather records after.
+// A quad (row i, columns 4 jq .. 4 jq + 3, all inside the 32 main columns) is a RUN when none of its entries is flagged and
+// its four patch offsets are consecutive.
+void make_samp2(const std::vector<uint16_t> &tab, int K, int s, std::vector<uint32_t> &out)
+{
+    const int sp = sid::samp_pitch(s), nq = sp >> 2;
+    out.assign((size_t)K * sid::kSamp2Words, 0u);
+    for (int k = 0; k < K; ++k) {
+        uint32_t *blk = out.data() + (size_t)k * sid::kSamp2Words;
+        uint32_t nrun = 0, ngat = 0;
+        uint16_t *ids = reinterpret_cast<uint16_t *>(blk + sid::kSamp2Id);
+        for (int i = 0; i < s; ++i)
+            for (int jq = 0; jq < nq; ++jq) {
+                const uint16_t *e = tab.data() + ((size_t)k * s + i) * sp + 4 * jq;
+                const bool full = 4 * jq + 3 < s && jq < 8;
+                const bool run = full && !((e[0] | e[1] | e[2] | e[3]) & 0x8000u) && e[1] == e[0] + 1 && e[2] == e[0] + 2 && e[3] == e[0] + 3;
+                if (run) blk[sid::kSamp2Run + nrun++] = (uint32_t)(e[0] & ~3u) | ((uint32_t)(e[0] & 3u) << 15) | ((uint32_t)i << 17) | ((uint32_t)jq << 23);
+                else {
+                    blk[sid::kSamp2Gat + 2 * ngat] = (uint32_t)e[0] | ((uint32_t)e[1] << 16);
+                    blk[sid::kSamp2Gat + 2 * ngat + 1] = (uint32_t)e[2] | ((uint32_t)e[3] << 16);
+                    ids[ngat++] = (uint16_t)(i * nq + jq);
+                }
+            }
+        blk[0] = nrun; blk[1] = ngat;
+    }
 }
 
 // window geometry of one point, the same arithmetic as the kernel (pmlib.py:200-202)
@@ -286,11 +320,20 @@ bool keep_acc_policy(bool rp, int rpp, int K)
     const char *e = getenv("SID_PM_KEEP_ACC");
     return e ? atoi(e) > 0 : rpp > 0;
 }
+// ... per launch: four slot groups (at most 3 angles, 16 B per placement) everywhere; two groups (at most 7 angles, 32 B) only
+// in the four-per-CU class of the smallest windows - at larger borders the stores cost more than the winner's matrix
+// instructions they replace (7 angles, mixed borders: +1.5 % with, -2 % at border 20; SID_PM_KEEP_ACC=1 keeps them everywhere)
+bool keep_acc_launch(const sid_pm_ctx *ctx, bool gs, bool big, int cls)
+{
+    if (!ctx->gs_keep_acc || !gs || big) return false;
+    if (ctx->rp_paired == 1 && cls != 4) { const char *e = getenv("SID_PM_KEEP_ACC"); return e && atoi(e) > 0; }
+    return true;
+}
 // u32 entries of the block of a point of that shape in a gs launch
-uint32_t block_entries(const sid_pm_ctx *ctx, int wh, int ww, int band)
+uint32_t block_entries(const sid_pm_ctx *ctx, int wh, int ww, int band, bool keep)
 {
     const int s = ctx->img_size;
-    return sid::rp_block_entries(wh - s + 1, ww - s + 1, rp_rows(ctx->rp_paired, band), 16 >> ctx->rp_paired, gs_keep_si(ctx), ctx->gs_keep_acc);
+    return sid::rp_block_entries(wh - s + 1, ww - s + 1, rp_rows(ctx->rp_paired, band), 16 >> ctx->rp_paired, gs_keep_si(ctx), keep);
 }
 
 int check_sweep(int img_size, const double *angles, int n_angles, uint32_t flags)
@@ -325,13 +368,13 @@ int fill_args(sid_pm_ctx *ctx, sid::PMArgs &A)
     A.c1 = ctx->d_vec; A.r1 = ctx->d_vec + n; A.c2fg = ctx->d_vec + 2 * n; A.r2fg = ctx->d_vec + 3 * n;
     A.border = ctx->d_vec + 4 * n;
     A.img_size = ctx->img_size; A.n_angles = ctx->n_angles; A.flags = ctx->flags;
-    A.angles = ctx->d_angles; A.rot = ctx->d_rot; A.samp = ctx->have_samp ? ctx->d_samp : nullptr; A.samp_nflag = ctx->samp_nflag;
+    A.angles = ctx->d_angles; A.rot = ctx->d_rot; A.samp = ctx->have_samp ? ctx->d_samp : nullptr; A.samp_nflag = ctx->samp_nflag; A.samp2 = ctx->have_samp ? ctx->d_samp2 : nullptr;
     A.out = ctx->user_out ? ctx->user_out : ctx->out.p;
     A.out_ij = ctx->user_out ? ctx->user_ij : ctx->out_ij.p;
     A.refused = ctx->h_refused;
     A.gsii = ctx->gsii.p; A.gsii_off = ctx->d_goff.p; A.rec = ctx->d_rec.p;
     A.gs_keep_si = gs_keep_si(ctx) ? 1u : 0u;
-    A.gs_keep_acc = ctx->gs_keep_acc ? 1u : 0u;
+    A.gs_keep_acc = 0u; A.ring = nullptr; A.pool = ctx->pool.p; A.pool_stride = ctx->pool_stride;   // (per launch: sid_pm_run)
     if (getenv("SID_PM_DEBUG_CHECK")) {
         if (!ctx->dbg_err.p && ctx->dbg_err.reserve(320) == SID_PM_OK) (void)hipMemset(ctx->dbg_err.p, 0, 320 * sizeof(int32_t));
         A.dbg_err = ctx->dbg_err.p;
@@ -406,7 +449,7 @@ int classify_points(sid_pm_ctx *ctx)
     static const bool no_fixed_pitch = getenv("SID_PM_NO_FIXED_PITCH") != nullptr;         // (run-time pitch everywhere: gs instantiations; A/B runs)
     // Everything the launch needs to know about a point follows from the SHAPE of its search window, and a run has a few
     // dozen shapes (one per border): the LDS layouts are evaluated per shape, the points are only binned.
-    struct Shape { int wh, ww, lds, band, cls, nat_pitch, pitch; double work; std::vector<int32_t> idx; bool gs = false, big = false; int w3p = 0; };
+    struct Shape { int wh, ww, lds, band, cls, nat_pitch, pitch; double work; std::vector<int32_t> idx; bool gs = false, big = false; int w3p = 0; bool keep = false; };
     std::vector<Shape> shapes;
     std::vector<int32_t> slot_of((size_t)1 << 16, -1);                // (wh, ww) -> shape, direct-mapped on a hash of the pair
     auto find_shape = [&](int wh, int ww) -> int {
@@ -495,6 +538,7 @@ int classify_points(sid_pm_ctx *ctx)
             a = b;
         }
     }
+    for (Shape &sh : shapes) sh.keep = rp && sh.wh > 0 && keep_acc_launch(ctx, sh.gs, sh.big, sh.cls);   // (the launch class is final here)
     // XCD-aware launch order.  Workgroup j of a launch runs on XCD j mod 8 and every XCD has its own L2, so
     // within a run of points of equal class and work (= equal border: the order there is the caller's, i.e.
     // spatial for a grid) the run is cut into 8 contiguous chunks and chunk c goes to the XCD of slot
@@ -527,14 +571,14 @@ int classify_points(sid_pm_ctx *ctx)
                                           (rp && first.cls >= 4 && sid::rp_pitch_instantiated(first.band, rpp, first.pitch, 4)) ? 4 : 3});
         ctx->info[5] = (double)first.cls;                             // (class of the bucket being filled)
         Bucket &bk = ctx->buckets.back();
-        bk.big = first.big;
+        bk.big = first.big; bk.keep = first.keep;
         bk.count += (int)src->size();
         bk.lds = std::max(bk.lds, lds_run);
         if (rp && first.gs)                                           // (launches that keep sum w'^2 in global memory: the largest block)
             for (size_t i = a; i < b; ++i) {
                 const Shape &sh = shapes[(size_t)ord[i]];
                 if (sh.wh > 0) bk.gs_stride = std::max<uint32_t>(bk.gs_stride, sh.big ? (uint32_t)(big_layout(sh.wh, sh.ww, s, K, flags).big_bytes / 4)
-                                                                                      : block_entries(ctx, sh.wh, sh.ww, sh.band));
+                                                                                      : block_entries(ctx, sh.wh, sh.ww, sh.band, sh.keep));
             }
         constexpr int64_t kXcd = 8;
         const int64_t L = (int64_t)src->size(), m = (L + kXcd - 1) / kXcd;
@@ -555,11 +599,31 @@ int classify_points(sid_pm_ctx *ctx)
     std::vector<uint32_t> goff;
     uint64_t gsii_granules = 0;
     if (rp) {
+        // Launches that keep accumulators take their blocks from the per-XCD free lists (PMArgs::ring): 8 x kRing blocks of the
+        // largest such block, whatever the number of points (SID_PM_NO_RECYCLE=1: a block per launch position, as the others)
+        const bool recycle = ctx->gs_keep_acc && getenv("SID_PM_NO_RECYCLE") == nullptr;
+        uint32_t stride = 0;
         std::vector<uint32_t> gran_shape(shapes.size(), 0u);
         for (size_t k = 1; k < shapes.size(); ++k) {
             const Shape &sh = shapes[k];
             if (sh.big) gran_shape[k] = (uint32_t)(big_layout(sh.wh, sh.ww, s, K, flags).big_bytes / 256);
-            else if (sh.gs) gran_shape[k] = block_entries(ctx, sh.wh, sh.ww, sh.band) / 64u;
+            else if (sh.gs && sh.keep && recycle) stride = std::max(stride, block_entries(ctx, sh.wh, sh.ww, sh.band, true));
+            else if (sh.gs) gran_shape[k] = block_entries(ctx, sh.wh, sh.ww, sh.band, sh.keep) / 64u;
+        }
+        ctx->pool_stride = stride;
+        if (stride) {
+            if (int rc = ctx->pool.reserve((size_t)8 * sid::kRing * stride)) return rc;
+            if (int rc = ctx->ring.reserve((size_t)8 * sid::kRingWords)) return rc;
+            // every block free (entry i = generation 0, block i), head 0, tail kRing; rewritten at every classification - no
+            // launch of this handle is in flight here - so that an aborted run cannot leave a list short of blocks
+            std::vector<uint32_t> init((size_t)8 * sid::kRingWords, 0u);
+            for (int x = 0; x < 8; ++x) {
+                uint32_t *rx = init.data() + (size_t)x * sid::kRingWords;
+                rx[sid::kRingTail] = (uint32_t)sid::kRing;
+                for (int i = 0; i < sid::kRing; ++i) rx[sid::kRingEnt + i] = (uint32_t)i;
+            }
+            HIP_TRY(hipMemcpyAsync(ctx->ring.p, init.data(), init.size() * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+            HIP_TRY(hipStreamSynchronize(ctx->stream));
         }
         goff.resize((size_t)n);
         for (int64_t p = 0; p < n; ++p) {
@@ -660,6 +724,11 @@ SID_EXPORT int sid_pm_create(int device, sid_pm_ctx **out)
             e = hipEventCreateWithFlags(&ctx->slot_ready[k], hipEventDisableTiming);
             if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->slot_done[k], hipEventDisableTiming);
         }
+        for (int k = 0; k < 3 && e == hipSuccess; ++k) {
+            e = hipStreamCreateWithFlags(&ctx->side[k], hipStreamNonBlocking);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->join_ev[k], hipEventDisableTiming);
+        }
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->fork_ev, hipEventDisableTiming);
         if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void **>(&ctx->h_refused), sizeof(int32_t), hipHostMallocMapped);
         if (e != hipSuccess) { sid_pm_destroy(ctx); return fail(SID_PM_ERR_HIP, "stream/event creation failed: %s", hipGetErrorString(e)); }
         *ctx->h_refused = 0;
@@ -678,9 +747,14 @@ SID_EXPORT void sid_pm_destroy(sid_pm_ctx *ctx)
         if (ctx->slot_ready[k]) (void)hipEventDestroy(ctx->slot_ready[k]);
         if (ctx->slot_done[k]) (void)hipEventDestroy(ctx->slot_done[k]);
     }
+    for (int k = 0; k < 3; ++k) {
+        if (ctx->side[k]) { (void)hipStreamSynchronize(ctx->side[k]); (void)hipStreamDestroy(ctx->side[k]); }
+        if (ctx->join_ev[k]) (void)hipEventDestroy(ctx->join_ev[k]);
+    }
+    if (ctx->fork_ev) (void)hipEventDestroy(ctx->fork_ev);
     for (auto &pair : ctx->own) for (auto &b : pair) b.release();
     ctx->arena.release();
-    ctx->out.release(); ctx->out_ij.release(); ctx->dbg_err.release(); ctx->gsii.release(); ctx->d_goff.release(); ctx->d_rec.release();
+    ctx->out.release(); ctx->out_ij.release(); ctx->dbg_err.release(); ctx->gsii.release(); ctx->d_goff.release(); ctx->d_rec.release(); ctx->ring.release(); ctx->pool.release();
     if (ctx->h_refused) (void)hipHostFree(ctx->h_refused);
     delete ctx;
 }
@@ -769,12 +843,14 @@ SID_EXPORT int sid_pm_set_points(sid_pm_ctx *ctx, const double *c1, const double
     int nflag = 0;
     // (rot_order = 1: no offset table - every template sample is interpolated in float64 by the general sampler)
     if (!getenv("SID_PM_NO_SAMP_TABLE") && !(flags & SID_PM_ROT_ORDER1)) nflag = make_samp(rotv, K, s, sampv);
+    std::vector<uint32_t> samp2v;
+    if (!sampv.empty() && use_rp(s, K) && getenv("SID_PM_NO_SAMP2") == nullptr) make_samp2(sampv, K, s, samp2v);
 
     // one arena, one upload: [5n doubles | K angles | 4K rotation terms | order (int32 n) | sampling table]
     auto up = [](size_t v) { return (v + 255) / 256 * 256; };
     const size_t o_vec = 0, o_ang = up(o_vec + sizeof(double) * 5 * (size_t)n), o_rot = up(o_ang + sizeof(double) * (size_t)K),
                  o_ord = up(o_rot + sizeof(double) * 4 * (size_t)K), o_smp = up(o_ord + sizeof(int32_t) * (size_t)n),
-                 total = up(o_smp + sizeof(uint16_t) * (sampv.size() + 4));
+                 o_smp2 = up(o_smp + sizeof(uint16_t) * (sampv.size() + 4)), total = up(o_smp2 + sizeof(uint32_t) * samp2v.size());
     HIP_TRY(hipStreamSynchronize(ctx->stream));               // nothing may still read the old arena
     if (int rc = ctx->arena.reserve(total)) return rc;
     if (int rc = ctx->out.reserve((size_t)(5 * n))) return rc;
@@ -785,6 +861,7 @@ SID_EXPORT int sid_pm_set_points(sid_pm_ctx *ctx, const double *c1, const double
     memcpy(host.data() + o_ang, angles, sizeof(double) * (size_t)K);
     memcpy(host.data() + o_rot, rotv.data(), sizeof(double) * rotv.size());
     if (!sampv.empty()) memcpy(host.data() + o_smp, sampv.data(), sizeof(uint16_t) * sampv.size());
+    if (!samp2v.empty()) memcpy(host.data() + o_smp2, samp2v.data(), sizeof(uint32_t) * samp2v.size());
     // synchronous: the host vectors are caller-owned and not retained
     HIP_TRY(hipMemcpy(ctx->arena.p, host.data(), total, hipMemcpyHostToDevice));
     ctx->d_vec = reinterpret_cast<double *>(ctx->arena.p + o_vec);
@@ -792,6 +869,7 @@ SID_EXPORT int sid_pm_set_points(sid_pm_ctx *ctx, const double *c1, const double
     ctx->d_rot = reinterpret_cast<double *>(ctx->arena.p + o_rot);
     ctx->d_order = reinterpret_cast<int32_t *>(ctx->arena.p + o_ord);
     ctx->d_samp = reinterpret_cast<uint16_t *>(ctx->arena.p + o_smp);
+    ctx->d_samp2 = samp2v.empty() ? nullptr : reinterpret_cast<uint32_t *>(ctx->arena.p + o_smp2);
     ctx->have_samp = !sampv.empty(); ctx->samp_nflag = nflag;
     ctx->h_c2fg.assign(c2fg, c2fg + n); ctx->h_r2fg.assign(r2fg, r2fg + n); ctx->h_border.assign(border, border + n);
     ctx->h_c1.assign(c1, c1 + n); ctx->h_r1.assign(r1, r1 + n);
@@ -828,11 +906,53 @@ SID_EXPORT int sid_pm_run(sid_pm_ctx *ctx)
     fill_args(ctx, A);
     if (ctx->cur_slot >= 0 && ctx->ready_rec[ctx->cur_slot])
         HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->slot_ready[ctx->cur_slot], 0));
+    // Launches side by side for SHORT runs.  A full grid is dozens of rounds of workgroups per launch and its launches run one
+    // after the other (side by side they measured 1-6 % slower: a CU that took a workgroup of a large-window class is lost to
+    // several small ones, rounds 2-4).  A rank's shard of an 8-GPU run is two or three launches of one to seven rounds each,
+    // and every launch ends with a half-empty round - a quarter of such a run; side by side the next launch's workgroups fill
+    // the CUs the previous one drains.  Rule: all launches of a run together are at most kSideRounds rounds of workgroups
+    // (SID_PM_SIDE_BY_SIDE=0 / 1: never / always; A/B runs).  The launches keep their order (largest footprint first).
+    bool side_by_side = false;
+    if (ctx->buckets.size() > 1) {
+        double rounds = 0;
+        for (const Bucket &b : ctx->buckets) rounds += (double)b.count / (256.0 * std::max(1, std::min(b.band == 8 ? 2 : 4, blocks_per_cu(b.lds))));
+        constexpr double kSideRounds = 16.0;
+        const char *e = getenv("SID_PM_SIDE_BY_SIDE");
+        side_by_side = e ? atoi(e) > 0 : rounds <= kSideRounds;
+    }
+    // (SID_PM_SIDE_FIRST=n, experiments: only the first n launches of a long run side by side - the large-window classes, a
+    // round or two of workgroups each - then the rest in sequence)
+    int n_side = side_by_side ? (int)ctx->buckets.size() : 0;
+    if (!side_by_side) if (const char *e = getenv("SID_PM_SIDE_FIRST")) n_side = std::min((int)ctx->buckets.size(), std::max(0, atoi(e)));
+    if (n_side > 1) HIP_TRY(hipEventRecord(ctx->fork_ev, ctx->stream));
+    int nb = 0;
+    unsigned used = 0;
+    auto join = [&]() -> int {
+        for (int k = 0; k < 3; ++k)                                  // the handle's stream continues when every side launch is done
+            if (used & (1u << k)) {
+                HIP_TRY(hipEventRecord(ctx->join_ev[k], ctx->side[k]));
+                HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->join_ev[k], 0));
+            }
+        used = 0;
+        return SID_PM_OK;
+    };
     for (const Bucket &b : ctx->buckets) {
+        // launch k of a side-by-side run: the handle's stream, then the side streams in turn
+        hipStream_t st = ctx->stream;
+        if (nb == n_side && n_side > 1) { if (int rc = join()) return rc; }
+        if (nb > 0 && nb < n_side) {
+            const int k = (nb - 1) % 3;
+            st = ctx->side[k];
+            if (!(used & (1u << k))) HIP_TRY(hipStreamWaitEvent(st, ctx->fork_ev, 0));
+            used |= 1u << k;
+        }
+        ++nb;
         A.order = ctx->d_order + b.offset;
         A.gsii_off = ctx->d_goff.p ? ctx->d_goff.p + b.offset : nullptr;
         A.rec = ctx->d_rec.p ? ctx->d_rec.p + b.offset : nullptr;
         A.n_launch = b.count;
+        A.gs_keep_acc = b.keep ? 1u : 0u;
+        A.ring = (b.keep && ctx->pool_stride) ? ctx->ring.p : nullptr;
         const int lds_launch = std::min(b.lds, sid::max_lds_bytes());
         A.lds_bytes = lds_launch;
         // 256 threads per point; 768 when the LDS footprint leaves room for one point per CU only, so that
@@ -842,10 +962,11 @@ SID_EXPORT int sid_pm_run(sid_pm_ctx *ctx)
         const int per_cu = std::max(1, std::min(b.band == 8 ? 2 : 8, blocks_per_cu(b.lds)));
         const int nthreads = b.band == 8 ? 256 : (per_cu == 1 ? 768 : (ctx->rp && sid::rp_pitch_is_w3(b.pitch)) ? 192 : 256);
         const int e = ctx->rp
-                          ? sid::launch_pm_rp(A, lds_launch, nthreads, b.band, b.big ? 0 : ctx->rp_paired, b.pitch, b.occ, ctx->stream, b.big)
-                          : sid::launch_pm_mfma(A, lds_launch, nthreads, b.band, use_paired(ctx->n_angles), ctx->stream);
+                          ? sid::launch_pm_rp(A, lds_launch, nthreads, b.band, b.big ? 0 : ctx->rp_paired, b.pitch, b.occ, st, b.big)
+                          : sid::launch_pm_mfma(A, lds_launch, nthreads, b.band, use_paired(ctx->n_angles), st);
         if (e != 0) return fail(SID_PM_ERR_HIP, "kernel launch failed: %s", hipGetErrorString((hipError_t)e));
     }
+    if (int rc = join()) return rc;
     if (ctx->cur_slot >= 0) {
         HIP_TRY(hipEventRecord(ctx->slot_done[ctx->cur_slot], ctx->stream));
         ctx->done_rec[ctx->cur_slot] = true;

@@ -30,6 +30,13 @@ struct PMArgs {
     // null = always sample on the fly
     const uint16_t *samp;
     int32_t samp_nflag;                             // number of flagged entries in samp (0 almost always)
+    // round 5, row-pair kernel: the same table SORTED per angle (make_samp2 in pm_capi.hip; null: not built).  A quad of four
+    // template samples whose patch bytes are CONSECUTIVE - three quarters of them at +-7 degrees: a nearest-neighbour rotation by a
+    // few degrees copies runs of a patch row - is one record {aligned patch offset, byte shift, row, quad} and costs two aligned
+    // dwords + one v_alignbyte instead of four byte gathers; the rest (a run ends inside the quad, the tail quad of a row, flagged
+    // entries) keep their four offsets.  Per angle kSamp2Words u32: [n_run, n_gather, -, -][kSamp2Cap run records]
+    // [kSamp2Cap x uint2 gather offsets][kSamp2Cap x u16 unit numbers i * nq + jq].
+    const uint32_t *samp2;
     double gauss_w[5];                              // hes_smth: normalised sigma-1 Gaussian taps w[0] (|k| = 4) .. w[4] (centre), host-computed
     double *out;                                    // [n_total][5]
     int32_t *out_ij;                                // [n_total][3]
@@ -51,6 +58,17 @@ struct PMArgs {
     // stored sums (rp_winner_kept): no second pass over the window, no operand staging, no matrix instructions.  16 B per
     // placement with four slot groups (the reference's default: 3 angles), 32 B with two (<= 7 angles), 64 B with the full table.
     uint32_t gs_keep_acc;
+    // Recycled blocks (round 5; the safe successor of round 4's hardware-slot pool): the blocks of global memory of a launch
+    // that keeps accumulators come from a FREE LIST per XCD - `ring`: [8 XCDs][kRingWords] u32, a ticket ring of kRing block
+    // numbers (pop: one atomic on `head` + the entry, tagged with its generation; push: one atomic on `tail` + one store) -
+    // instead of one block per launch position.  A block belongs to whoever popped it until that workgroup pushes it back:
+    // ownership is a property of the list, not of where the workgroup happens to run (tools/ubench/slot_life.hip: under a queue
+    // eviction workgroups are saved and restored on OTHER CUs - but on the same XCD, which is all the list relies on: a block
+    // is only ever written and read through ONE XCD's L2).  1024 - 2048 blocks cycle through L2 / the Infinity Cache instead of
+    // 40 000 write-once blocks travelling to HBM.  ring = null: the exclusive block of the launch position (gsii_off).
+    uint32_t *ring;
+    uint32_t *pool;                                 // [8 XCDs][kRing blocks][pool_stride u32]
+    uint32_t pool_stride;
     // diagnostics (debug_point only; null in production launches)
     uint8_t *dbg_templates; float *dbg_ccm; float *dbg_hes; int32_t *dbg_shape; int64_t dbg_cap;
     long long *dbg_cycles;                          // [32] shader-clock stamps at phase boundaries
@@ -63,6 +81,8 @@ __host__ __device__ inline int round_up(int v, int m) { return (v + m - 1) / m *
 constexpr int kMiscMfmaBytes = 2688;
 constexpr int kTrowPad = 36;         // zero rows around a winner operand block: 16 above, 20 below (the step loop runs in fours)
 constexpr int kQueueCap = 192;       // arg-max candidates waiting for exact evaluation (16 B each)
+constexpr int kRingLog = 8, kRing = 1 << kRingLog;        // recycled blocks per XCD (PMArgs::ring): twice what an XCD can hold resident
+constexpr int kRingHead = 0, kRingTail = 32, kRingEnt = 64, kRingWords = kRingEnt + kRing;   // head and tail in cache lines of their own
 constexpr int kRpQueueWithSi = 128;  // ... and the sums kept for the winner (RpLdsLayout::si_off) leave it at least this
 constexpr int kRpQueueMin = 64;      // row-pair kernel: the queue shrinks to this where it decides the residency class (overflow is evaluated in place)
 
@@ -305,7 +325,9 @@ __host__ __device__ inline RpLdsLayout rp_lds_layout(int wh, int ww, int s, bool
 }
 
 // kept accumulators (PMArgs::gs_keep_acc): the table is padded to whole work items, so that the sweep stores without predicates -
-// cols_pad = the placement columns its tiles cover, rows_pad = bands x output rows per item
+// cols_pad = the placement columns its tiles cover, rows_pad = bands x output rows per item.  (Measured, 3 angles: predicated
+// stores +6 % at border 30, stores of the lanes beyond the matrix redirected to one spare entry +2 %; the padding costs 30 %
+// more bytes, which the recycled blocks keep in cache.)
 __host__ __device__ inline void rp_acc_dims(int rh, int rw, int rows_per_item, int &cols_pad, int &rows_pad)
 {
     const int rem = rw % 32;
@@ -340,6 +362,8 @@ int launch_pm_rp(const PMArgs &args, int lds_bytes, int nthreads, int band, int 
 bool rp_pitch_instantiated(int band, int paired, int pitch, int occ = 3);
 
 __host__ __device__ inline int samp_pitch(int s) { return round_up(s, 4); }
+constexpr int kSamp2Cap = 320;                                              // units per angle: 35 rows x 9 quads = 315
+constexpr int kSamp2Run = 4, kSamp2Gat = kSamp2Run + kSamp2Cap, kSamp2Id = kSamp2Gat + 2 * kSamp2Cap, kSamp2Words = kSamp2Id + kSamp2Cap / 2;
 constexpr double kSampGuard = 1e-5;   // table entries whose coordinate is this close to k + 1/2 are flagged
 
 int launch_pm_mfma(const PMArgs &args, int lds_bytes, int nthreads, int band, bool paired, void *stream);

@@ -109,6 +109,7 @@ struct Geo {
     int gsi;                         // ... the same in the point's block of global memory, behind sum w'^2: offset in u32 entries (0: none)
     int hist_off;                    // 5 KB behind the NCC matrix of the winning angle for ph_hessian_fast (0: none - the general ph_hessian runs)
     int gsa, gsa_rw;                 // kept accumulators (PMArgs::gs_keep_acc): offset of the table in the point's block (u32 entries; 0: none) and its row pitch in placements
+    int blk, blk_xcd;                // recycled block of this point and the XCD ring it came from (PMArgs::ring; -1: none)
     int lin;                         // rot_order = 1 (SID_PM_ROT_ORDER1, pmlib.py:89): templates sampled bilinearly, every sample through sample_exact
     long long r0, c0;                // window origin on image 2
     double c1, r1, nd;
@@ -1562,8 +1563,35 @@ __device__ __forceinline__ float hypot_spec(float x, float y)
     const double hh = (double)x * (double)x + (double)y * (double)y;
     return (float)sqrt(hh);
 }
+// Round 5, measured and NOT the default (-DSID_HYPOT_F32): the same value in FLOAT32 arithmetic.  The idea was that the float64
+// form below costs 29 double-rate instructions per magnitude; it does not - plain float64 FMAs issue at the float32 rate on
+// gfx950 - and the 38 float32 instructions of this form measured +-0 (15 and 3 angles) to +3 % (7 angles).  Kept because it is
+// verified (0 differences against the specification on the device and in a NumPy emulation with +-1 ulp v_sqrt / v_rcp).  x^2 + y^2 = s + t exactly up to 2^-46 s (error-free products by FMA, TwoSum); r0 =
+// v_sqrt_f32(s) is within 1 ulp; the residual e = (s - r0^2) + t is known to 2^-24 of itself, so the true root is r0 + z ulp(r0)
+// with z = e / (2 r0 ulp) known to ~1e-6 (|z| <= ~3), and the correctly rounded float32 root is r0 + round(z) ulp - unless z lies
+// within 1e-4 of a half-integer (that includes every case in which the specification's double rounding - to float64, then to
+// float32 - could matter), r0 sits next to a power of two (the ulp changes there), or s is zero / tiny / huge / NaN: those lanes,
+// ~2e-4 of them, take the specification's route.  sid_pm_debug_hypot_selftest compares both forms on 2^27 pairs on the device.
 __device__ __forceinline__ float hypot_fast(float x, float y)
 {
+#ifdef SID_HYPOT_F32
+    const float p = x * x, q = y * y;
+    const float ep = __builtin_fmaf(x, x, -p), eq = __builtin_fmaf(y, y, -q);    // x^2 = p + ep, y^2 = q + eq (exact)
+    const float s = p + q;
+    const float bb = s - p;
+    const float es = (p - (s - bb)) + (q - bb);                                    // TwoSum: p + q = s + es (exact)
+    const float t = (es + ep) + eq;
+    const float r0 = __builtin_amdgcn_sqrtf(s);
+    const float e = __builtin_fmaf(-r0, r0, s) + t;
+    const int ex = __builtin_amdgcn_frexp_expf(r0);                                // r0 = m 2^ex, m in [0.5, 1): ulp(r0) = 2^(ex - 24)
+    const float z = __builtin_amdgcn_ldexpf(e * __builtin_amdgcn_rcpf(r0), 23 - ex);   // e / (2 r0) in ulps
+    const float k = __builtin_rintf(z);
+    const u32 rb = __float_as_uint(r0), mb = rb & 0x7fffffu;
+    const bool slow = !(__builtin_fabsf(z - k) < 0.5f - 1e-4f) || (mb - 8u) > 0x7fffefu || !(s > 0x1p-60f && s < 0x1p60f);
+    float out = __uint_as_float(rb + (u32)(int)k);                                 // k ulps on (same binade: checked)
+    if (slow) out = (float)sqrt((double)x * (double)x + (double)y * (double)y);
+    return out;
+#else
     const double hh = (double)x * (double)x + (double)y * (double)y;
     const double y0 = __builtin_amdgcn_rsq(hh);
     double g = hh * y0, h = 0.5 * y0;
@@ -1577,6 +1605,7 @@ __device__ __forceinline__ float hypot_fast(float x, float y)
     float out = (float)g;
     if (slow) out = (float)sqrt(hh);
     return out;
+#endif
 }
 
 // Bucket of a Hessian magnitude (>= 0) in the fixed histogram of ph_hessian_fast: 16 binades 2^-15 .. 2 with 128 buckets

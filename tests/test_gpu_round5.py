@@ -63,7 +63,7 @@ def test_rot_order1_other_kernels_against_the_oracle(pm_ctx, c_oracle, s, angles
     n = 60
     c1 = rng.uniform(100, 600, n); r1 = rng.uniform(100, 600, n)
     c1[::2] = np.rint(c1[::2]); r1[::2] = np.rint(r1[::2])
-    c1[:3] = [12.0, 690.5, 350.0]; r1[:3] = [350.0, 350.0, 8.25]     # templates that reach beyond image 1
+    c1[:3] = [3.0, 697.5, 350.0]; r1[:3] = [350.0, 350.0, 2.25]      # templates that reach beyond image 1 (at every side tested)
     dc, dr = syn.true_displacement(c1, r1)
     c2 = np.rint(c1 + dc); r2 = np.rint(r1 + dr)
     c2[:3] = 350.0; r2[:3] = 350.0
@@ -139,3 +139,36 @@ def test_kept_accumulators_equal_the_recomputed_winner_and_the_oracle(pm_ctx, c_
     d = pm_ctx.debug_point(c1[0], r1[0], c2[0], r2[0], 24.0, s, 0.0, angles, rot=rot, flags=1)
     full = po.use_mcc(c1[0], r1[0], c2[0], r2[0], 24.0, img1, img2, s, 0.0, full=True, angles=angles)
     np.testing.assert_array_equal(d['ccm'], full[1][2])
+
+
+@pytest.mark.parametrize('s,angles', [(34, list(range(-7, 8))), (35, [-3, 0, 3]), (34, list(range(-3, 4))), (35, [0.5 * k for k in range(-8, 9)]),
+                                      (34, [-45.0, -20.0, 0.0, 33.3, 90.0])])
+def test_sorted_sampling_table_equals_the_plain_one_and_the_oracle(pm_ctx, c_oracle, monkeypatch, s, angles):
+    """Round 5: the row-pair kernel reads the sampling table sorted per angle - quads of four CONSECUTIVE patch bytes as run
+    records (two aligned dwords + v_alignbyte), the rest as gathers (PMArgs::samp2).  Small and large angles (at 45 degrees almost
+    nothing is a run), several groups of angles, both template sides, a scene rotation that makes every angle fractional, points
+    on the zero patch: against the oracle, and bit-identical to the plain table (SID_PM_NO_SAMP2=1)."""
+    img1, img2 = syn.make_pair(900, 900, seed=31)
+    img1 = img1.copy()
+    img1[400:420, 380:430] = 0
+    g = syn.make_grid(900, 900, 13, margin=120)
+    rng = np.random.default_rng(6)
+    border = rng.integers(20, 38, len(g['c1'])).astype(np.float64)
+    res = []
+    for alpha0 in (0.0, -3.85):
+        rot = rot_for(angles, alpha0, s)
+        exp, exp_ij = c_oracle.pm_batch(img1, img2, g['c1'], g['r1'], g['c2fg'], g['r2fg'], border, s, alpha0, angles, rot=rot, nthreads=8)
+        assert np.isnan(exp[:, 0]).any()
+        pm_ctx.upload_pair(img1, img2)
+        for env in (None, 'SID_PM_NO_SAMP2'):
+            monkeypatch.delenv('SID_PM_NO_SAMP2', raising=False)
+            if env:
+                monkeypatch.setenv(env, '1')
+            pm_ctx.set_points(g['c1'], g['r1'], g['c2fg'], g['r2fg'], border, s, alpha0, angles, rot=rot)
+            pm_ctx.run()
+            got, got_ij = pm_ctx.fetch()
+            assert_parity(got, got_ij, exp, exp_ij)
+            res.append((got.copy(), got_ij.copy()))
+        monkeypatch.delenv('SID_PM_NO_SAMP2', raising=False)
+        np.testing.assert_array_equal(res[-1][0], res[-2][0])
+        np.testing.assert_array_equal(res[-1][1], res[-2][1])

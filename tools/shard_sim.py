@@ -27,18 +27,28 @@ out = {}
 with _capi.PMContext(0) as ctx:
     ctx.upload_pair(img1, img2)
     def timed(idx, steps=30):
+        """(run + fetch, run + sync) in ms: the first is what one GPU pays for a shard on its own (kernels + copy of its results
+        to the host); the second is the kernels alone - what a rank of an N-GPU run contributes before the exchange step, where
+        the per-rank copy does not exist (the kernels write the gathered block in place)."""
         ctx.set_points(g['c1'][idx], g['r1'][idx], g['c2fg'][idx], g['r2fg'][idx], g['border'][idx], s, 0.0, angles, rot=rot)
         for _ in range(3):
             ctx.run(); ctx.fetch(want_ij=False)
         t0 = time.perf_counter()
         for _ in range(steps):
             ctx.run(); ctx.fetch(want_ij=False)
-        return (time.perf_counter() - t0) / steps * 1e3
-    full = timed(np.arange(g['c1'].size))
+        t1 = time.perf_counter()
+        for _ in range(steps):
+            ctx.run(); ctx.sync()
+        t2 = time.perf_counter()
+        return (t1 - t0) / steps * 1e3, (t2 - t1) / steps * 1e3
+    full, full_k = timed(np.arange(g['c1'].size))
     for name, fn in schemes.items():
         shards = [fn(r) for r in range(world)]
         assert sorted(np.concatenate(shards).tolist()) == list(range(g['c1'].size))
-        ms = [timed(ix) for ix in shards]
+        both = [timed(ix) for ix in shards]
+        ms, mk = [b[0] for b in both], [b[1] for b in both]
         out[name] = {'points_per_rank': [int(len(ix)) for ix in shards], 'ms_per_rank': [round(x, 3) for x in ms],
-                     'slowest_ms': round(max(ms), 3), 'predicted_speedup_before_gather': round(full / max(ms), 2)}
-print(json.dumps({'world': world, 'full_step_ms_one_gpu': round(full, 3), 'schemes': out}, indent=1))
+                     'slowest_ms': round(max(ms), 3), 'predicted_speedup_before_gather': round(full / max(ms), 2),
+                     'kernels_only_ms_per_rank': [round(x, 3) for x in mk], 'kernels_only_slowest_ms': round(max(mk), 3),
+                     'kernels_only_sum_ms': round(sum(mk), 3)}
+print(json.dumps({'world': world, 'full_step_ms_one_gpu': round(full, 3), 'full_step_kernels_only_ms': round(full_k, 3), 'schemes': out}, indent=1))
