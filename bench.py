@@ -405,7 +405,7 @@ def grid_mode(args, torch, dist, dev, world, rank, local_rank):
             # the sweep runs on v_mfma_i32_16x16x64_i8: the matrix cores are the roofline that bounds it
             'bound': 'mfma', 'achieved': mfma_achieved, 'peak': MFMA_I8_PEAK_TOPS, 'unit': 'TFLOP/s',
             'frac': mfma_achieved / MFMA_I8_PEAK_TOPS, 'traffic': traffic, 'traffic_note': traffic_note,
-            'kernel': ('sid::pm_kernel_rp<%d> (row-pair sweep; one launch per LDS class: 3 / 2 / 1 workgroups per CU)' % s
+            'kernel': ('sid::pm_kernel_rp<%d,...> (row-pair sweep; one launch per residency class: 4 / 3 / 3 / 2 / 1 workgroups per CU)' % s
                        if s in (34, 35) and not os.environ.get('SID_PM_NO_RP') else
                        'sid::pm_kernel_mfma<%d,...> (classic sweep: one instantiation per band height / pairing)' % (s if s in (34, 35) else 0)),
             'launches_per_step': launches, 'kernel_ms_per_step': kern_ms, 'avg_launch_ms': kern_ms / launches,

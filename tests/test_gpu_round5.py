@@ -144,10 +144,10 @@ def test_kept_accumulators_equal_the_recomputed_winner_and_the_oracle(pm_ctx, c_
 @pytest.mark.parametrize('s,angles', [(34, list(range(-7, 8))), (35, [-3, 0, 3]), (34, list(range(-3, 4))), (35, [0.5 * k for k in range(-8, 9)]),
                                       (34, [-45.0, -20.0, 0.0, 33.3, 90.0])])
 def test_sorted_sampling_table_equals_the_plain_one_and_the_oracle(pm_ctx, c_oracle, monkeypatch, s, angles):
-    """Round 5: the row-pair kernel reads the sampling table sorted per angle - quads of four CONSECUTIVE patch bytes as run
-    records (two aligned dwords + v_alignbyte), the rest as gathers (PMArgs::samp2).  Small and large angles (at 45 degrees almost
+    """Round 5 (measured slower, built on request only: SID_PM_SAMP2=1): the sampling table sorted per angle - quads of four
+    CONSECUTIVE patch bytes as run records (two aligned dwords + v_alignbyte), the rest as gathers (PMArgs::samp2).  Small and large angles (at 45 degrees almost
     nothing is a run), several groups of angles, both template sides, a scene rotation that makes every angle fractional, points
-    on the zero patch: against the oracle, and bit-identical to the plain table (SID_PM_NO_SAMP2=1)."""
+    on the zero patch: against the oracle, and bit-identical to the plain table."""
     img1, img2 = syn.make_pair(900, 900, seed=31)
     img1 = img1.copy()
     img1[400:420, 380:430] = 0
@@ -160,8 +160,8 @@ def test_sorted_sampling_table_equals_the_plain_one_and_the_oracle(pm_ctx, c_ora
         exp, exp_ij = c_oracle.pm_batch(img1, img2, g['c1'], g['r1'], g['c2fg'], g['r2fg'], border, s, alpha0, angles, rot=rot, nthreads=8)
         assert np.isnan(exp[:, 0]).any()
         pm_ctx.upload_pair(img1, img2)
-        for env in (None, 'SID_PM_NO_SAMP2'):
-            monkeypatch.delenv('SID_PM_NO_SAMP2', raising=False)
+        for env in (None, 'SID_PM_SAMP2'):
+            monkeypatch.delenv('SID_PM_SAMP2', raising=False)
             if env:
                 monkeypatch.setenv(env, '1')
             pm_ctx.set_points(g['c1'], g['r1'], g['c2fg'], g['r2fg'], border, s, alpha0, angles, rot=rot)
@@ -169,6 +169,6 @@ def test_sorted_sampling_table_equals_the_plain_one_and_the_oracle(pm_ctx, c_ora
             got, got_ij = pm_ctx.fetch()
             assert_parity(got, got_ij, exp, exp_ij)
             res.append((got.copy(), got_ij.copy()))
-        monkeypatch.delenv('SID_PM_NO_SAMP2', raising=False)
+        monkeypatch.delenv('SID_PM_SAMP2', raising=False)
         np.testing.assert_array_equal(res[-1][0], res[-2][0])
         np.testing.assert_array_equal(res[-1][1], res[-2][1])

@@ -83,7 +83,17 @@ def _evictor(stop, counter):
     picked by hardware slot; the free lists of round 5 (PMArgs::ring) must not care."""
     import ctypes, mmap, time
     libc = ctypes.CDLL('libc.so.6', use_errno=True)
-    hip = ctypes.CDLL('libamdhip64.so')
+    # the HIP runtime THIS process already runs on (torch ships its own copy: opening "libamdhip64.so" by name would map a
+    # second runtime into the process)
+    path = None
+    with open('/proc/self/maps') as fh:
+        for line in fh:
+            if 'libamdhip64.so' in line:
+                path = line.split()[-1]
+                break
+    if path is None:
+        return
+    hip = ctypes.CDLL(path)
     size = 8 << 20
     while not stop.is_set():
         buf = mmap.mmap(-1, size)
@@ -103,6 +113,7 @@ def _evictor(stop, counter):
         time.sleep(0.003)
 
 
+@pytest.mark.timeout(600)
 @pytest.mark.parametrize('angles,img_size', [(1, 35), (3, 34)])
 def test_recycled_blocks_survive_queue_evictions(workload, c_oracle, angles, img_size):
     """The launches of at most 7 angles take the blocks of global memory that hold their per-placement sums and accumulators

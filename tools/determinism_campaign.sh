@@ -47,8 +47,18 @@ run 4000 300 --angles 7 --border 21 --img-size 35
 run 10000 100 --angles 7 --border 20
 run 3000 40 --angles 7 --border 80
 SID_PM_NO_W3=1 run 4000 200 --angles 7 --border 20
-# (the per-XCD pool of blocks, SID_PM_GS_POOL=1, is not in the campaign: it is the one known source of differing results - DESIGN.md 6b)
+# (round 4's pool of blocks picked by hardware slot is gone from the library: DESIGN.md section 5.5)
 run 4000 20000 --angles 7 --img-size 35 --border 44
 run 10000 2000 --angles 1
+# round 5: blocks recycled through the per-XCD free lists (launches of at most 3 angles everywhere, of at most 7 in the
+# four-per-CU class), accumulators kept for the winner, the sorted sampling table, exclusive blocks for comparison
+run 4000 20000 --angles 1 --img-size 35
+run 4000 5000 --angles 1 --border 20
+run 4000 5000 --angles 3 --border 20
+run 4000 2000 --angles 3
+run 10000 1000 --angles 1 --img-size 35
+SID_PM_NO_RECYCLE=1 run 4000 1000 --angles 1 --img-size 35
+SID_PM_KEEP_ACC=0 run 4000 1000 --angles 1 --img-size 35
+SID_PM_SAMP2=1 run 4000 300 --angles 7
 echo "library md5 $(md5sum $R/sea_ice_drift_amd/libsid_pm.so | cut -d' ' -f1)" >> $OUT
 cat $OUT
