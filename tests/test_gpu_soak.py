@@ -75,7 +75,7 @@ def test_repeated_runs_are_bit_identical(workload, c_oracle, angles, img_size, b
     np.testing.assert_allclose(ref[sel, 4], exp[:, 4], rtol=1e-5, atol=1e-5)
 
 
-def _evictor(stop, counter):
+def _evictor(stop, counter, lock):
     """Host thread that keeps provoking evictions of this process's GPU queues: pages of a hipHostRegister'ed (user-pointer)
     buffer are invalidated (madvise / mprotect), which the kernel driver answers by quiescing the queues - wavefronts in
     flight are saved by the trap handler and restored later, on OTHER compute units of their XCD (tools/ubench/slot_life.hip:
@@ -100,49 +100,56 @@ def _evictor(stop, counter):
         view = (ctypes.c_char * size).from_buffer(buf)
         addr = ctypes.addressof(view)
         ctypes.memset(addr, 1, size)
-        if hip.hipHostRegister(ctypes.c_void_p(addr), ctypes.c_size_t(size), ctypes.c_uint(0)) == 0:
-            libc.madvise(ctypes.c_void_p(addr), ctypes.c_size_t(size), ctypes.c_int(4))            # MADV_DONTNEED
-            ctypes.memset(addr, 2, size)
-            libc.mprotect(ctypes.c_void_p(addr), ctypes.c_size_t(size), ctypes.c_int(1))          # PROT_READ
-            libc.mprotect(ctypes.c_void_p(addr), ctypes.c_size_t(size), ctypes.c_int(3))          # PROT_READ | PROT_WRITE
-            time.sleep(0.002)
-            hip.hipHostUnregister(ctypes.c_void_p(addr))
-            counter[0] += 1
+        # (register .. unregister under the lock the main thread holds around its copies to the host: kernels overlap the
+        # evictions - the point of the test -, the runtime's own pinning of a pageable copy target does not)
+        with lock:
+            if hip.hipHostRegister(ctypes.c_void_p(addr), ctypes.c_size_t(size), ctypes.c_uint(0)) == 0:
+                libc.madvise(ctypes.c_void_p(addr), ctypes.c_size_t(size), ctypes.c_int(4))        # MADV_DONTNEED
+                ctypes.memset(addr, 2, size)
+                libc.mprotect(ctypes.c_void_p(addr), ctypes.c_size_t(size), ctypes.c_int(1))      # PROT_READ
+                libc.mprotect(ctypes.c_void_p(addr), ctypes.c_size_t(size), ctypes.c_int(3))      # PROT_READ | PROT_WRITE
+                time.sleep(0.002)
+                hip.hipHostUnregister(ctypes.c_void_p(addr))
+                counter[0] += 1
         del view
         buf.close()
         time.sleep(0.003)
 
 
-@pytest.mark.timeout(600)
+@pytest.mark.timeout(240)
 @pytest.mark.parametrize('angles,img_size', [(1, 35), (3, 34)])
 def test_recycled_blocks_survive_queue_evictions(workload, c_oracle, angles, img_size):
     """The launches of at most 7 angles take the blocks of global memory that hold their per-placement sums and accumulators
     from per-XCD free lists (round 5).  300 repetitions of a 6 400-point run while a host thread provokes queue evictions:
     every repetition bit-identical to the first, the first equal to the oracle; and the lists are whole afterwards (the next
     set_points would re-initialise them, so a second handle-less check is the repetitions themselves)."""
-    import threading
+    import faulthandler, threading
+    faulthandler.dump_traceback_later(200, exit=False)                # (a hang shows where every thread stands)
     img1, img2, size = workload
     g = syn.make_grid(size, size, 80, border='mixed')
     ang = list(range(-angles, angles + 1))
     rot = my.rotation_table(ang, 0.0, img_size)
-    stop, counter = threading.Event(), [0]
+    stop, counter, lock = threading.Event(), [0], threading.Lock()
     with _capi.PMContext(0) as ctx:
         ctx.upload_pair(img1, img2)
         ctx.set_points(g['c1'], g['r1'], g['c2fg'], g['r2fg'], g['border'], img_size, 0.0, ang, rot=rot)
         ctx.run()
         ref, ref_ij = ctx.fetch()
-        th = threading.Thread(target=_evictor, args=(stop, counter), daemon=True)
+        th = threading.Thread(target=_evictor, args=(stop, counter, lock), daemon=True)
         th.start()
         bad = 0
         try:
             for _ in range(300):
                 ctx.run()
-                out, ij = ctx.fetch()
+                ctx.sync()                                          # the kernels run - and are evicted - with the lock free
+                with lock:
+                    out, ij = ctx.fetch()
                 same = (ij == ref_ij).all(1) & ((out == ref) | (np.isnan(out) & np.isnan(ref))).all(1)
                 bad += int((~same).sum())
         finally:
             stop.set()
             th.join(timeout=10)
+            faulthandler.cancel_dump_traceback_later()
     assert bad == 0, '%d point results differed between repetitions (%d evictions provoked)' % (bad, counter[0])
     assert counter[0] > 0, 'no queue eviction could be provoked on this box'
     sel = np.arange(0, len(ref), 53)

@@ -39,7 +39,7 @@ done
 python3 $R/bench.py --mode stream --pairs 16 --steps 2 --warmup 1 --check 32 > $OUT/stream_bench.json 2>> $OUT/bench.err
 python3 $R/bench.py --gpus 2 --steps 5 --warmup 1 --no-cpu-baseline > $OUT/dryrun_2ranks_1gpu.json 2>> $OUT/bench.err
 python3 $R/bench.py --gpus 1 --force-collective --steps 20 --warmup 3 --no-cpu-baseline > $OUT/force_collective_rccl_1gpu.json 2>> $OUT/bench.err
-python3 $R/bench.py --mode ftpm --check 400 > $OUT/ftpm_bench.json 2>> $OUT/bench.err
+timeout 300 python3 $R/bench.py --mode ftpm --check 400 > $OUT/ftpm_bench.json 2>> $OUT/bench.err
 rocprofv3 --kernel-trace --stats -d /tmp/kt_$TAG -o kt -- python3 $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-also-defaults --check 0 > /dev/null 2>&1
 python3 $R/tools/rocpd_summary.py $(find /tmp/kt_$TAG -name "*.db" | head -1) > $OUT/kernel_trace_stats.txt
 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU -d /tmp/p1_$TAG -o p1 -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-also-defaults --check 0 > /dev/null 2>&1
@@ -47,5 +47,5 @@ rocprofv3 --pmc SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_A
 rocprofv3 --pmc SQ_VALU_MFMA_COEXEC_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_CYCLES -d /tmp/p3_$TAG -o p3 -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-also-defaults --check 0 > /dev/null 2>&1
 rocprofv3 --pmc SQC_ICACHE_REQ SQC_ICACHE_MISSES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE -d /tmp/p4_$TAG -o p4 -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-also-defaults --check 0 > /dev/null 2>&1
 for p in p1 p2 p3 p4; do python3 $R/tools/rocpd_summary.py $(find /tmp/${p}_$TAG -name "*.db" | head -1) | sed -n '/PMC per dispatch/,$p' >> $OUT/pmc_counters.txt; done
-python3 $R/tools/e2e_bench.py > $OUT/e2e_pattern_matching.json 2>> $OUT/bench.err
+timeout 200 python3 $R/tools/e2e_bench.py > $OUT/e2e_pattern_matching.json 2>> $OUT/bench.err
 ls -la $OUT
