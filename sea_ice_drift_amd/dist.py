@@ -31,6 +31,8 @@ def point_cost(border, img_size=34, n_angles=15, flags=1):
 # up to 1.5x inside one launch, and end less evenly.  Fitted to the shards tools/shard_sim.py measures on the GPU
 # (8 shards of the benchmark grid: 0.5 everywhere left the one-per-CU shard 6.5 % and the mixed one 7.4 % above the others).
 _TAIL_ROUNDS = {1: 1.0, 2: 0.7, 3: 0.5, 4: 0.5}
+_SIDE_TAIL_BLEND = float(os.environ.get('SID_DIST_TAIL_BLEND', '0.7'))   # share of the shorter tails a side-by-side run still pays (fitted: tools/shard_sim.py)
+_SIDE_BY_SIDE_ROUNDS = 16.0        # pm_capi.hip kSideRounds: runs of at most this many rounds of workgroups launch their classes side by side
 
 
 def _shard_times(cost, cls, cuts):
@@ -40,11 +42,19 @@ def _shard_times(cost, cls, cuts):
     t = np.zeros(len(cuts) - 1)
     for r in range(len(cuts) - 1):
         a, b = cuts[r], cuts[r + 1]
+        parts = []
         for c in np.unique(cls[a:b]):                               # one launch per class (residency | 16 x global sums)
             sel = cost[a:b][cls[a:b] == c]
             per_cu = int(c) & 15
             latency = 256.0 * per_cu * sel.mean()
-            t[r] += max(sel.sum() + _TAIL_ROUNDS.get(per_cu, 0.5) * latency, latency)
+            parts.append((sel.sum(), _TAIL_ROUNDS.get(per_cu, 0.5) * latency, latency, sel.size / (256.0 * per_cu)))
+        if len(parts) > 1 and sum(p[3] for p in parts) <= _SIDE_BY_SIDE_ROUNDS:
+            # the launches of a short run go side by side (sid_pm_run, round 5): the next launch fills the CUs the previous one
+            # drains, so the run ends with ONE tail - the longest - instead of one per launch
+            tails = sorted(p[1] for p in parts)
+            t[r] = max(sum(p[0] for p in parts) + tails[-1] + _SIDE_TAIL_BLEND * sum(tails[:-1]), max(p[2] for p in parts))
+        else:
+            t[r] = sum(max(p[0] + p[1], p[2]) for p in parts)
     return t
 
 

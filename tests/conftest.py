@@ -26,3 +26,13 @@ def pm_ctx():
     ctx = _capi.PMContext(0)
     yield ctx
     ctx.close()
+
+
+def pytest_collection_modifyitems(config, items):
+    """The eviction soaks (tests/test_gpu_soak.py) run FIRST: each is a process of its own that provokes evictions of its GPU
+    queues, and on the pool's boxes such an eviction stalls for minutes once another process - this one, after the first GPU
+    test - holds queues and gigabytes of allocations on the same device."""
+    first = [it for it in items if 'survive_queue_evictions' in it.nodeid]
+    if first:
+        rest = [it for it in items if 'survive_queue_evictions' not in it.nodeid]
+        items[:] = first + rest
