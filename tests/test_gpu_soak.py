@@ -76,7 +76,7 @@ def test_repeated_runs_are_bit_identical(workload, c_oracle, angles, img_size, b
 
 
 @pytest.mark.parametrize('angles,img_size', [(1, 35), (3, 34)])
-def test_recycled_blocks_survive_queue_evictions(angles, img_size):
+def test_recycled_blocks_survive_queue_evictions(angles, img_size, c_oracle, tmp_path):
     """The launches of at most 7 angles take the blocks of global memory that hold their per-placement sums and accumulators
     from per-XCD free lists (round 5).  300 repetitions of a 6 400-point run while a host thread provokes evictions of the
     process's GPU queues (tools/eviction_soak.py: wavefronts in flight are saved and restored on OTHER compute units - what broke
@@ -86,7 +86,8 @@ def test_recycled_blocks_survive_queue_evictions(angles, img_size):
     import json, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     try:
-        p = subprocess.run([sys.executable, os.path.join(root, 'tools', 'eviction_soak.py'), str(angles), str(img_size), '300'],
+        dump = str(tmp_path / 'first_run.npz')
+        p = subprocess.run([sys.executable, os.path.join(root, 'tools', 'eviction_soak.py'), str(angles), str(img_size), '300', dump],
                            capture_output=True, text=True, timeout=240, cwd=root)
     except subprocess.TimeoutExpired:
         # (seen when a second process holds the device: the driver's restore after an eviction then takes minutes - with or
@@ -97,4 +98,11 @@ def test_recycled_blocks_survive_queue_evictions(angles, img_size):
     res = json.loads(p.stdout.strip().splitlines()[-1])
     assert res['bad'] == 0, '%d point results differed between repetitions (%d evictions provoked)' % (res['bad'], res['evictions'])
     assert res['evictions'] > 0, 'no queue eviction could be provoked on this box'
-    assert res['parity_ok'] is True, res['parity_ok']
+    d = np.load(dump)
+    img1, img2 = syn.make_pair(int(d['size']), int(d['size']), seed=int(d['seed']))
+    sel = np.arange(0, len(d['ref']), 53)
+    exp, exp_ij = c_oracle.pm_batch(img1, img2, d['c1'][sel], d['r1'][sel], d['c2fg'][sel], d['r2fg'][sel], d['border'][sel], int(d['img_size']),
+                                    0.0, list(d['angles']), rot=d['rot'], nthreads=8)
+    np.testing.assert_array_equal(d['ref_ij'][sel], exp_ij)
+    np.testing.assert_array_equal(d['ref'][sel, :4], exp[:, :4])
+    np.testing.assert_allclose(d['ref'][sel, 4], exp[:, 4], rtol=1e-5, atol=1e-5)
