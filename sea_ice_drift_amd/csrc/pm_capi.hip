@@ -966,7 +966,10 @@ SID_EXPORT int sid_pm_run(sid_pm_ctx *ctx)
         const int e = ctx->rp
                           ? sid::launch_pm_rp(A, lds_launch, nthreads, b.band, b.big ? 0 : ctx->rp_paired, b.pitch, b.occ, st, b.big)
                           : sid::launch_pm_mfma(A, lds_launch, nthreads, b.band, use_paired(ctx->n_angles), st);
-        if (e != 0) return fail(SID_PM_ERR_HIP, "kernel launch failed: %s", hipGetErrorString((hipError_t)e));
+        if (e != 0) {
+            (void)join();                                            // (what the side streams already hold still orders before the handle's stream)
+            return fail(SID_PM_ERR_HIP, "kernel launch failed: %s", hipGetErrorString((hipError_t)e));
+        }
     }
     if (int rc = join()) return rc;
     if (ctx->cur_slot >= 0) {
