@@ -88,12 +88,12 @@ def test_recycled_blocks_survive_queue_evictions(angles, img_size, c_oracle, tmp
     try:
         dump = str(tmp_path / 'first_run.npz')
         p = subprocess.run([sys.executable, os.path.join(root, 'tools', 'eviction_soak.py'), str(angles), str(img_size), '300', dump],
-                           capture_output=True, text=True, timeout=240, cwd=root)
+                           capture_output=True, text=True, timeout=120, cwd=root)
     except subprocess.TimeoutExpired:
         # (seen when a second process holds the device: the driver's restore after an eviction then takes minutes - with or
         # without this library's kernels in flight.  The soak takes 5 s when it has the device to itself, which conftest.py
         # arranges by running it first; profiles/r05_eviction_soak.txt has such runs.)
-        pytest.skip('queue evictions stall on this box (another process on the device?): the soak did not finish within 240 s')
+        pytest.skip('queue evictions stall on this box (another process on the device?): the soak did not finish within 120 s')
     assert p.returncode == 0, p.stderr[-2000:]
     res = json.loads(p.stdout.strip().splitlines()[-1])
     assert res['bad'] == 0, '%d point results differed between repetitions (%d evictions provoked)' % (res['bad'], res['evictions'])
