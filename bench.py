@@ -72,6 +72,9 @@ def parse_args(argv=None):
     ap.add_argument('--scaling', choices=('weak', 'strong'), default=None,
                     help='N > 1, grid mode: strong (default) = the same grid sharded; weak = grid rows x N')
     ap.add_argument('--no-weak', action='store_true', help='skip the secondary weak-scaling measurement')
+    ap.add_argument('--rebalance', type=int, default=3,
+                    help='N > 1, strong scaling: rounds of measured feedback on the shard cuts BEFORE the warm-up (every rank times '
+                         'its kernels over 3 steps, one all_gather, dist.rebalance_cuts; the cuts with the smallest slowest rank are kept); 0 = the estimated cuts')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-also-defaults', action='store_true',
                     help="N = 1, grid mode: skip the second measurement on the reference's DEFAULT configuration (img_size 35, "
@@ -136,25 +139,67 @@ class GridRun(object):
     def __init__(self, args, dev, world, rank, local_rank, t1, t2, n_rows, angles, rot):
         import torch
         from sea_ice_drift_amd import _capi, synthetic as syn
-        from sea_ice_drift_amd.dist import PackedGatherer, shard_indices_by_cost
         self.torch = torch
         s = args.img_size
         H = W = args.size
         border = args.border if args.border == 'mixed' else int(args.border)
         self.g = g = syn.make_grid(H, W, (n_rows, args.grid), border=border)
         self.n_total = g['c1'].size
-        self.idx = idx = shard_indices_by_cost(g['border'], world, rank, s, len(angles))   # (world 1: all points)
+        from sea_ice_drift_amd.dist import shard_cuts_by_cost
+        self.args, self.dev, self.s, self.angles, self.rot = args, dev, s, angles, rot
+        self.rank, self.world = rank, world
+        self.order, self.cuts, self.cost = shard_cuts_by_cost(g['border'], world, s, len(angles))   # (world 1: all points)
         self.ctx = _capi.PMContext(local_rank)
         self.ctx.set_stream(torch.cuda.current_stream().cuda_stream)
         self.ctx.bind_pair_tensors(t1, t2)
-        self.ctx.set_points(g['c1'][idx], g['r1'][idx], g['c2fg'][idx], g['r2fg'][idx], g['border'][idx], s, 0.0,
-                            angles, rot=rot)
-        self.gather = PackedGatherer(self.n_total, idx, dev, force_collective=args.force_collective,
-                                     timing=world > 1 or args.force_collective)
+        self.reshard(self.cuts)
+
+    def reshard(self, cuts):
+        """This rank's run of the border-ordered points under `cuts` (every rank calls this with the same cuts: the gatherer's
+        set-up is a collective)."""
+        from sea_ice_drift_amd.dist import PackedGatherer, indices_of_cut
+        g = self.g
+        self.cuts = cuts
+        self.idx = idx = indices_of_cut(self.order, cuts, self.rank)
+        self.ctx.set_points(g['c1'][idx], g['r1'][idx], g['c2fg'][idx], g['r2fg'][idx], g['border'][idx], self.s, 0.0,
+                            self.angles, rot=self.rot)
+        self.gather = PackedGatherer(self.n_total, idx, self.dev, force_collective=self.args.force_collective,
+                                     timing=self.world > 1 or self.args.force_collective)
         out_t, ij_t = self.gather.local_views()
         self.ctx.bind_results_tensors(out_t, ij_t)
         self.info = self.ctx.work_info()
-        self.rank, self.world = rank, world
+
+    def kernel_ms(self, steps=3):
+        """This rank's kernels alone (HIP events on the launch stream around `steps` runs, after one untimed run)."""
+        torch = self.torch
+        self.ctx.run()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(steps):
+            self.ctx.run()
+        b.record()
+        b.synchronize()
+        self.ctx.check()
+        return a.elapsed_time(b) / steps
+
+    def rebalance(self, rounds):
+        """Measured feedback on the cuts (N > 1): the estimate prices a launch as cost + tail and leaves the slowest of eight
+        shards ~4 % above the mean; here every rank times its own kernels, one all_gather makes the
+        times known everywhere, ``dist.rebalance_cuts`` moves the cuts, and the cuts with the smallest slowest rank are kept.
+        Set-up work, before the warm-up; a fixed number of rounds, the same collectives on every rank."""
+        from sea_ice_drift_amd.dist import per_rank_breakdown, rebalance_cuts
+        import numpy as np
+        history, best = [], (float('inf'), self.cuts)
+        for it in range(rounds + 1):
+            t = per_rank_breakdown([self.kernel_ms()], self.dev)[:, 0]
+            history.append({'points': np.diff(self.cuts).tolist(), 'kernel_ms': [round(float(v), 4) for v in t]})
+            if t.max() < best[0]:
+                best = (float(t.max()), self.cuts)
+            if it < rounds:
+                self.reshard(rebalance_cuts(self.cost, self.cuts, t))
+        if best[1] is not self.cuts:
+            self.reshard(best[1])
+        return {'rounds': rounds, 'kept_slowest_kernel_ms': best[0], 'history': history}
 
     def step(self, ev=None):
         if ev is not None:
@@ -347,6 +392,7 @@ def grid_mode(args, torch, dist, dev, world, rank, local_rank):
 
     headline_rows = args.grid * world if (args.scaling == 'weak' and world > 1) else args.grid
     run = GridRun(args, dev, world, rank, local_rank, t1, t2, headline_rows, angles, rot)
+    rebalanced = run.rebalance(args.rebalance) if (world > 1 and args.scaling == 'strong' and args.rebalance > 0) else None
     run.gather.timings()                                   # (reset: construction and warm-up are not the timed steps)
     elapsed, kern_ms = timed_steps(torch, dist, world, run, args.steps, args.warmup, discard_warmup=run.gather.timings)
     exchange = run.gather.timings()
@@ -358,8 +404,8 @@ def grid_mode(args, torch, dist, dev, world, rank, local_rank):
     res, res_ij = run.results() if rank == 0 else (None, None)
     n_total, info, g = run.n_total, run.info, run.g
     zero_copy, device_unpermute = getattr(run.gather, 'zero_copy', False), getattr(run.gather, 'device_unpermute', False)
-    from sea_ice_drift_amd.dist import shard_indices_by_cost
-    n_local = len(run.idx)
+    import numpy as _np
+    n_local, points_all = len(run.idx), [int(v) for v in _np.diff(run.cuts)]
     run.close()
 
     weak = None
@@ -393,14 +439,15 @@ def grid_mode(args, torch, dist, dev, world, rank, local_rank):
                                                              angles[-1], border),
                    'points_total': int(n_total), 'points_per_gpu': int(n_local),
                    # (shards of equal estimated cost are unequal in length: rank 0 holds the largest windows)
-                   'points_per_gpu_all': [int(len(shard_indices_by_cost(run.g['border'], world, r, s, len(angles)))) for r in range(world)],
+                   'points_per_gpu_all': points_all,
                    'results': ('written by the kernels into pinned host memory (zero copy); step = launches + stream synchronise'
                                if zero_copy else 'device block -> one gather -> one kernel that un-permutes into pinned host memory'
                                if device_unpermute else 'device block -> (gather, un-permutation) -> one copy to pinned host memory'),
                    'parity_reads': 'the output of one more, untimed step run after the result buffers were overwritten with NaN / -1',
                    'parallelism': ('single GPU, no collective' if world == 1 else
-                                   'points cut into %d runs of equal estimated cost (neighbouring borders per GPU), one RCCL gather of the packed '
-                                   'result blocks to rank 0' % world)},
+                                   'points cut into %d runs of equal estimated cost (neighbouring borders per GPU)%s, one RCCL gather of the packed '
+                                   'result blocks to rank 0' % (world, ', cuts moved by %d rounds of measured feedback before the warm-up' % args.rebalance
+                                                                if rebalanced else ''))},
         'roofline': {
             # the sweep runs on v_mfma_i32_16x16x64_i8: the matrix cores are the roofline that bounds it
             'bound': 'mfma', 'achieved': mfma_achieved, 'peak': MFMA_I8_PEAK_TOPS, 'unit': 'TFLOP/s',
@@ -420,6 +467,8 @@ def grid_mode(args, torch, dist, dev, world, rank, local_rank):
     }
     if weak is not None:
         line['weak_scaling'] = weak
+    if rebalanced is not None:
+        line['config']['rebalance'] = rebalanced
     if per_rank is not None and exchange['steps'] > 0:
         # where a step of the N-GPU path goes: rank 0's own kernels, then the exchange step (HIP events on the launch
         # stream; the gather also holds the wait for the slowest rank), the un-permutation into pinned host memory - and the

@@ -58,13 +58,14 @@ def _shard_times(cost, cls, cuts):
     return t
 
 
-def shard_indices_by_cost(border, world_size, rank, img_size=34, n_angles=15, flags=1):
-    """Indices owned by `rank` when the points, ordered by border (largest first, stable), are cut into `world_size`
-    contiguous runs of equal estimated TIME.  A rank then holds one or two neighbouring border classes instead of an
-    eighth of every class, i.e. one or two launches that are eight times longer: at 5 000 points per rank the tails of
-    three short launches cost a quarter of the step.  The time of a run is the cost of its points
-    (``point_cost``) plus the tails of its launches (``_shard_times``): cut by cost alone, the rank with the largest borders -
-    one workgroup per CU, 7 rounds of 256 points - came out 6 % slower than the others on the GPU (tools/shard_sim.py).
+def shard_cuts_by_cost(border, world_size, img_size=34, n_angles=15, flags=1):
+    """(order, cuts, cost): the points ordered by border (largest first, stable), the ``world_size + 1`` positions that cut
+    that order into contiguous runs of equal estimated TIME, and the estimated cost of every point in that order.  A rank then
+    holds one or two neighbouring border classes instead of an eighth of every class, i.e. one or two launches that are eight
+    times longer: at 5 000 points per rank the tails of three short launches cost a quarter of the step.
+    The time of a run is the cost of its points (``point_cost``) plus the tails of its launches (``_shard_times``): cut by cost
+    alone, the rank with the largest borders - one workgroup per CU, 7 rounds of 256 points - came out 6 % slower than the
+    others on the GPU (tools/shard_sim.py).
 
     Every rank's kernels must finish before the gather can complete, so the step time is the slowest rank's kernel time
     plus the exchange step; shortening rank 0's shard would not hide the exchange (it starts when the LAST rank is done).
@@ -74,28 +75,66 @@ def shard_indices_by_cost(border, world_size, rank, img_size=34, n_angles=15, fl
     order = np.argsort(-border, kind='stable')
     n = order.size
     if n == 0 or world_size <= 1:
-        return np.sort(order) if rank == 0 else np.zeros(0, dtype=order.dtype)
+        return order, np.array([0] + [n] * max(world_size, 1), dtype=np.int64), np.zeros(n)
     cost = point_cost(border[order], img_size, n_angles, flags)          # (flags of the run: sid_pm.h SID_PM_HES_NORM = 1 ...)
     cls = _capi.estimate_residency(border[order], img_size, n_angles, flags)
     cum = np.concatenate([[0.0], np.cumsum(cost)])
     share = np.full(world_size, cum[-1] / world_size)               # cost each shard is to hold
-
-    def cuts_for(share):
-        # point k goes to the shard whose cost interval holds the middle of its own
-        edges = np.cumsum(share)[:-1]
-        mid = cum[:-1] + 0.5 * cost
-        c = np.searchsorted(mid, edges, side='left')
-        return np.concatenate([[0], c, [n]]).astype(np.int64)
     best_cuts, best = None, np.inf
     for _ in range(24):                                             # move cost from the slow shards to the fast ones
-        cuts = cuts_for(share)
+        cuts = _cuts_for_shares(cost, cum, share)
         t = _shard_times(cost, cls, cuts)
         if t.max() < best:
             best, best_cuts = t.max(), cuts
         share = np.maximum(share + 0.7 * (t.mean() - t), 0.0)
         share *= cum[-1] / share.sum()
-    a, b = best_cuts[rank], best_cuts[rank + 1]
-    return np.sort(order[a:b])
+    return order, best_cuts, cost
+
+
+def _cuts_for_shares(cost, cum, share):
+    """Cut positions for the given cost per shard: point k goes to the shard whose cost interval holds the middle of its own."""
+    edges = np.cumsum(share)[:-1]
+    mid = cum[:-1] + 0.5 * cost
+    c = np.searchsorted(mid, edges, side='left')
+    return np.concatenate([[0], c, [cost.size]]).astype(np.int64)
+
+
+def shard_indices_by_cost(border, world_size, rank, img_size=34, n_angles=15, flags=1):
+    """Indices (ascending) owned by `rank` under ``shard_cuts_by_cost``."""
+    order, cuts, _ = shard_cuts_by_cost(border, world_size, img_size, n_angles, flags)
+    return indices_of_cut(order, cuts, rank)
+
+
+def indices_of_cut(order, cuts, rank):
+    """Indices (ascending) of shard `rank` of the border-ordered points cut at ``cuts``."""
+    if rank + 1 >= len(cuts):
+        return np.zeros(0, dtype=order.dtype)
+    return np.sort(order[cuts[rank]:cuts[rank + 1]])
+
+
+def rebalance_cuts(cost, cuts, measured, damping=0.6):
+    """New cut positions from the kernel times the ranks MEASURED with the current ones (``measured[r]``, any unit; the same
+    array on every rank, e.g. from ``per_rank_breakdown``).  The estimate prices a launch as cost + tail; what a device does with
+    a launch whose last round of workgroups is nearly empty, or with two short launches side by side, it can only fit (the
+    slowest of eight simulated shards stays 4 % above the mean).  The measured time of a shard is spread
+    over its points in proportion to their estimated costs, the border order is cut into runs of equal spread time, and the
+    cuts move ``damping`` of the way there (a launch's tail does not shrink with its length: the full step overshoots).
+    Callers iterate - measure, rebalance, measure - and keep the cuts with the smallest slowest time.  Pure function."""
+    cuts = np.asarray(cuts, dtype=np.int64)
+    measured = np.asarray(measured, dtype=np.float64)
+    world = cuts.size - 1
+    if world <= 1 or cost.size == 0 or not np.all(np.isfinite(measured)) or measured.min() <= 0.0:
+        return cuts.copy()
+    w = np.array(cost, dtype=np.float64)
+    for r in range(world):
+        a, b = cuts[r], cuts[r + 1]
+        if b > a:
+            w[a:b] *= measured[r] / max(w[a:b].sum(), 1e-300)       # the shard's measured time, spread like its estimated cost
+    cum = np.concatenate([[0.0], np.cumsum(w)])
+    target = _cuts_for_shares(w, cum, np.full(world, cum[-1] / world))
+    new = np.rint(cuts + damping * (target - cuts)).astype(np.int64)
+    new[0], new[-1] = 0, cost.size
+    return np.maximum.accumulate(new)                               # (monotone: an empty shard is legal, a negative one is not)
 
 
 class PackedGatherer(object):

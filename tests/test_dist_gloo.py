@@ -9,7 +9,8 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from sea_ice_drift_amd.dist import PackedGatherer, per_rank_breakdown, point_cost, shard_indices_by_cost
+from sea_ice_drift_amd.dist import (PackedGatherer, indices_of_cut, per_rank_breakdown, point_cost, rebalance_cuts,
+                                    shard_cuts_by_cost, shard_indices_by_cost)
 
 
 def _free_port():
@@ -79,6 +80,36 @@ def test_cost_shards_partition_and_balance():
     assert shard_indices_by_cost(np.zeros(0), 4, 1).size == 0
     np.testing.assert_array_equal(np.sort(np.concatenate([shard_indices_by_cost(np.full(5, 70.0), 2, r) for r in range(2)])),
                                   np.arange(5))
+
+
+def test_measured_feedback_moves_the_cuts_towards_equal_times():
+    """``rebalance_cuts``: a device whose launches cost something else than the estimate says (here: every residency class off
+    by its own factor, plus a fixed tail per shard) - a few rounds of measure / rebalance bring the slowest shard to within 1 %
+    of the mean; the cuts stay a partition at every round; degenerate inputs leave them alone."""
+    from sea_ice_drift_amd import _capi, synthetic as syn
+    g = syn.make_grid(10000, 10000, 200)
+    world = 8
+    order, cuts, cost = shard_cuts_by_cost(g['border'], world)
+    assert cuts[0] == 0 and cuts[-1] == order.size and (np.diff(cuts) > 0).all()
+    for r in range(world):
+        np.testing.assert_array_equal(indices_of_cut(order, cuts, r), shard_indices_by_cost(g['border'], world, r))
+    cls = _capi.estimate_residency(g['border'][order], 34, 15, 1) & 15
+    factor = np.where(cls == 1, 0.9, np.where(cls == 2, 1.08, np.where(cls == 3, 1.03, 1.0)))
+
+    def device(cuts):
+        return np.array([(cost[a:b] * factor[a:b]).sum() + 4.0e4 for a, b in zip(cuts[:-1], cuts[1:])])
+    t0 = device(cuts)
+    assert t0.max() / t0.mean() > 1.02
+    c = cuts
+    for _ in range(6):
+        c = rebalance_cuts(cost, c, device(c))
+        assert c[0] == 0 and c[-1] == order.size and (np.diff(c) >= 0).all()
+        assert sorted(np.concatenate([indices_of_cut(order, c, r) for r in range(world)]).tolist()) == list(range(order.size))
+    t = device(c)
+    assert t.max() / t.mean() < 1.01 and t.max() < t0.max()
+    np.testing.assert_array_equal(rebalance_cuts(cost, cuts, np.full(world, np.nan)), cuts)      # no usable measurement
+    np.testing.assert_array_equal(rebalance_cuts(cost, cuts, np.zeros(world)), cuts)
+    np.testing.assert_array_equal(rebalance_cuts(cost, cuts, t0 * 0 + 1.0, damping=0.0), cuts)  # no step
 
 
 def _roundtrip(world, n_total):
