@@ -17,8 +17,10 @@ touches torch or the GPU (a process that has initialised the GPU is never replac
     rank the kernels write their 52 B per point straight into the pinned host buffer (zero copy; the step ends with the
     stream synchronised and the results readable on the host - the parity check reads exactly that buffer).
     N > 1 is STRONG scaling by default - the same 200x200 grid cut into runs of equal estimated cost (by search border)
-    (sea_ice_drift_amd/dist.py) - and the weak figure ((200*N)x200 grid, 40 000 points per GPU) is measured
-    after it and reported under "weak_scaling"; ``--scaling weak`` makes the weak workload the headline.
+    (sea_ice_drift_amd/dist.py), the cuts then moved by --rebalance (3) rounds of MEASURED feedback during set-up, before the
+    warm-up: every rank times its own kernels, one all_gather, dist.rebalance_cuts; reported under config.rebalance - and
+    the weak figure ((200*N)x200 grid, 40 000 points per GPU) is measured after it and reported under "weak_scaling";
+    ``--scaling weak`` makes the weak workload the headline.
 
 --mode ftpm (BASELINE.json configs[3])
     the public chain on the same pair: SeaIceDrift.get_drift_FT (key-point detector and Hamming matcher on the GPU, the
