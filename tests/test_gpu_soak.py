@@ -81,19 +81,24 @@ def test_recycled_blocks_survive_queue_evictions(angles, img_size, c_oracle, tmp
     from per-XCD free lists (round 5).  300 repetitions of a 6 400-point run while a host thread provokes evictions of the
     process's GPU queues (tools/eviction_soak.py: wavefronts in flight are saved and restored on OTHER compute units - what broke
     round 4's pool of blocks picked by hardware slot): every repetition bit-identical to the first, the first equal to the
-    oracle.  A process of its own, run before every other GPU test (conftest.py), with a hard timeout: once a second process
-    holds the device an eviction has stalled for minutes, and a blocked runtime call cannot be interrupted from Python."""
+    oracle.  A process of its own, run before every other GPU test (conftest.py), with a hard timeout and one retry: an eviction
+    has stalled for minutes on some boxes, and a blocked runtime call cannot be interrupted from Python."""
     import json, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    try:
-        dump = str(tmp_path / 'first_run.npz')
-        p = subprocess.run([sys.executable, os.path.join(root, 'tools', 'eviction_soak.py'), str(angles), str(img_size), '300', dump],
-                           capture_output=True, text=True, timeout=120, cwd=root)
-    except subprocess.TimeoutExpired:
-        # (seen when a second process holds the device: the driver's restore after an eviction then takes minutes - with or
-        # without this library's kernels in flight.  The soak takes 5 s when it has the device to itself, which conftest.py
-        # arranges by running it first; profiles/r05_eviction_soak.txt has such runs.)
-        pytest.skip('queue evictions stall on this box (another process on the device?): the soak did not finish within 120 s')
+    dump = str(tmp_path / 'first_run.npz')
+    p = None
+    for attempt in range(2):
+        try:
+            p = subprocess.run([sys.executable, os.path.join(root, 'tools', 'eviction_soak.py'), str(angles), str(img_size), '300', dump],
+                               capture_output=True, text=True, timeout=90, cwd=root)
+            break
+        except subprocess.TimeoutExpired:
+            # (seen on some boxes, with or without this library's kernels in flight: the driver's restore after an eviction takes
+            # minutes - always for the whole process, so a second process gets a second chance.  The soak takes 5 s when it
+            # runs; conftest.py runs it before every other GPU test; profiles/r05_eviction_soak.txt has such runs.)
+            continue
+    if p is None:
+        pytest.skip('queue evictions stall on this box: the soak did not finish within 90 s, twice')
     assert p.returncode == 0, p.stderr[-2000:]
     res = json.loads(p.stdout.strip().splitlines()[-1])
     assert res['bad'] == 0, '%d point results differed between repetitions (%d evictions provoked)' % (res['bad'], res['evictions'])
