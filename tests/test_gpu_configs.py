@@ -92,6 +92,13 @@ def test_config3_dry_run_bench_spawns_its_own_ranks():
     pr = bd['per_rank']
     assert len(pr['kernel_ms']) == 2 and min(pr['kernel_ms']) > 0 and pr['points'] == two['config']['points_per_gpu_all']
     assert bd['slowest_rank'] in (0, 1) and bd['slowest_kernel_ms'] == max(pr['kernel_ms'])
+    # the shard cuts were moved by measured feedback before the warm-up (3 rounds: 4 measurements, every one a partition of the grid;
+    # the cuts in use are the measured ones with the smallest slowest rank)
+    rb = two['config']['rebalance']
+    assert rb['rounds'] == 3 and len(rb['history']) == 4 and all(sum(h['points']) == 3600 and min(h['kernel_ms']) > 0 for h in rb['history'])
+    assert abs(rb['kept_slowest_kernel_ms'] - min(max(h['kernel_ms']) for h in rb['history'])) < 1e-3
+    assert two['config']['points_per_gpu_all'] in [h['points'] for h in rb['history']]
+    assert 'rebalance' not in one['config']
 
 
 def test_config5_dry_run_two_ranks_stream_their_shares():
