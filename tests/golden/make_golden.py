@@ -12,6 +12,8 @@ them, with a sha256) and the outputs the reference's functions returned:
                      template_matcher=<restated TM_CCOEFF_NORMED> injected through the
                      reference's own plug point (cv2 is absent: parity unpinned at that call)
   g3b_use_mcc_order1.npz  pmlib.use_mcc(rot_order=1) on G3's pair and points
+  g3c_large_rotations.npz  pmlib.use_mcc on G3's pair and points with scene rotations alpha0 of 30, 90 and -137.5 degrees
+                     (pmlib.py:79-87,151: the sampling angle is angle - alpha0), rot_order 0 and 1, sizes 34 / 35
   g4_pattern_matching.npz  pmlib.pattern_matching    (pmlib.py:326-497) end to end on an
                      affine stand-in for Nansat, incl. the kernel-input vectors it built
   g5_fullsize.npz    sha256 of the 10000x10000 benchmark pair + C-oracle results on a 1 %
@@ -111,6 +113,29 @@ def make_g3b(pmlib):
                             for i in range(len(c1))], dtype=np.float64)
             d['out_s%d_k%d' % (s, k)] = res
     np.savez_compressed(os.path.join(HERE, 'g3b_use_mcc_order1.npz'), **d)
+
+
+G3C_ALPHA0 = [30.0, 90.0, -137.5]
+G3C_ANGLE_SETS = [[-3, 0, 3], list(range(-7, 8))]
+
+
+def make_g3c(pmlib):
+    """use_mcc with LARGE effective rotations: the template is sampled at angle - alpha0 (pmlib.py:151) and alpha0
+    (pmlib.py:79-87) is tens of degrees for ascending / descending pairs.  G3's pair and points; alpha0 in G3C_ALPHA0, angle sets
+    G3C_ANGLE_SETS, template sides 34 / 35, rot_order 0 and 1; restated matcher injected as in G3.  (The synthetic pair is not
+    rotated, so the peaks are weak - the fixture pins arithmetic, not geophysics.)"""
+    img1, img2 = g3_pair()
+    c1, r1, c2fg, r2fg, border = g3_points()
+    d = dict(pair_sha=syn.sha256(img1, img2), alpha0=np.array(G3C_ALPHA0))
+    for s in (34, 35):
+        for ai, alpha0 in enumerate(G3C_ALPHA0):
+            for k, angles in enumerate(G3C_ANGLE_SETS):
+                for order in (0, 1):
+                    res = np.array([pmlib.use_mcc(c1[i], r1[i], c2fg[i], r2fg[i], border[i], img1, img2, s, alpha0,
+                                                  angles=angles, rot_order=order, template_matcher=po.match_template)
+                                    for i in range(len(c1))], dtype=np.float64)
+                    d['out_s%d_a%d_k%d_o%d' % (s, ai, k, order)] = res
+    np.savez_compressed(os.path.join(HERE, 'g3c_large_rotations.npz'), **d)
 
 
 def g2_inputs():
@@ -346,7 +371,7 @@ def make_g7():
 
 
 def main():
-    which = sys.argv[1:] or ['g1', 'g1b', 'g2', 'g3', 'g3b', 'g4', 'g5', 'g6', 'g7']
+    which = sys.argv[1:] or ['g1', 'g1b', 'g2', 'g3', 'g3b', 'g3c', 'g4', 'g5', 'g6', 'g7', 'g8']
     if 'g7' in which:
         t = time.time()
         make_g7()
@@ -357,7 +382,7 @@ def main():
         make_g6(reflib)
         print('g6 done in %.1f s' % (time.time() - t))
     c_oracle.build()
-    for name, fn in (('g1', make_g1), ('g1b', make_g1b), ('g2', make_g2), ('g3', make_g3), ('g3b', make_g3b), ('g4', make_g4)):
+    for name, fn in (('g1', make_g1), ('g1b', make_g1b), ('g2', make_g2), ('g3', make_g3), ('g3b', make_g3b), ('g3c', make_g3c), ('g4', make_g4)):
         if name in which:
             t = time.time()
             fn(pmlib)

@@ -187,3 +187,26 @@ def test_g5_fullsize_subsample_present():
     g = load('g5_fullsize.npz')
     assert g['out'].shape == (400, 5) and g['ij'].shape == (400, 3)
     assert np.isfinite(g['out']).all()
+
+
+# ---------------------------------------------------------------- G3c large effective rotations
+@pytest.mark.parametrize('s', [34, 35])
+def test_g3c_large_rotations(c_oracle, s):
+    """Fixture G3c: the reference's use_mcc with alpha0 of 30 / 90 / -137.5 degrees (pmlib.py:79-87,151: the template is sampled
+    at angle - alpha0), rot_order 0 and 1 - the C oracle on every case, the NumPy oracle on the cheapest."""
+    g = load('g3c_large_rotations.npz')
+    g3 = load('g3_use_mcc.npz')
+    img1, img2 = mg.g3_pair()
+    assert syn.sha256(img1, img2) == str(g['pair_sha'])
+    v = [g3[k] for k in ('c1', 'r1', 'c2fg', 'r2fg', 'border')]
+    for ai, alpha0 in enumerate(mg.G3C_ALPHA0):
+        for k, angles in enumerate(mg.G3C_ANGLE_SETS):
+            for order in (0, 1):
+                exp = g['out_s%d_a%d_k%d_o%d' % (s, ai, k, order)]
+                flags = 1 | (8 if order else 0)
+                got, ij = c_oracle.pm_batch(img1, img2, *v, s, alpha0, angles, rot=rot_for(angles, alpha0, s), flags=flags, nthreads=4)
+                np.testing.assert_array_equal(got, exp)
+                assert ((ij[:, 2] == -1) == np.isnan(exp[:, 0])).all()
+                if k == 0 and ai == 2:
+                    got_n, _ = po.pm_batch(img1, img2, *v, s, alpha0, angles, flags=flags)
+                    np.testing.assert_array_equal(got_n, exp)
