@@ -47,6 +47,11 @@ int sid_fg_interp_linear(int device, const double *pts, int64_t n_pts, const int
 /* seeds [n_seeds][2], q [n_q][2] -> dist [n_q] = min over seeds of the Euclidean distance */
 int sid_fg_nearest_dist(int device, const double *seeds, int64_t n_seeds, const double *q, int64_t n_q, double *dist);
 
+/* get_distance_to_nearest_keypoint (pmlib.py:61-77) at full resolution: dist [rows][cols] = distance of every pixel (row, column)
+ * to the nearest of seeds [n_seeds][2] = (row, column) - the reference's distance_transform_edt image, evaluated per pixel through
+ * the same buckets (sqrt of the exact integer squared distance in float64: the same numbers). */
+int sid_fg_distance_image(int device, const double *seeds, int64_t n_seeds, int64_t rows, int64_t cols, double *dist);
+
 const char *sid_fg_last_error(void);
 /* Free the grow-only device scratch block of the two entry points on `device` (every device: -1).  The blocks are kept between calls so that no call pays for
  * hipMalloc / hipFree; a long-lived process that is done with the GPU hands the memory back with this (the Python mirror's

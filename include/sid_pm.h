@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define SID_PM_ABI_VERSION 3
+#define SID_PM_ABI_VERSION 4
 
 /* return codes */
 #define SID_PM_OK               0
@@ -73,13 +73,19 @@ int         sid_pm_device_count(int *count);
  *   c1,r1            [n] template centre on image 1 (float pixel coordinates)
  *   c2fg,r2fg        [n] first-guess centre on image 2
  *   border           [n] search half-width around the first guess (pixels)
- *   img_size         template side s (reference default 35; 34 in the benchmark)
+ *   img_size         template side s (reference default 35; 34 in the benchmark), 2..255.  Sides up to 64 with a
+ *                    search window of at most 257 px run one workgroup per point; larger sides and larger
+ *                    windows (any border, any rectangular shape) run the large-window pipeline - the placements of
+ *                    ONE point tiled over the whole device, the NCC matrices of all angles in global memory
  *   alpha0           scene rotation in degrees (pmlib.py:428)
  *   angles           [n_angles] trial angles in degrees, in the reference's list order
- *   rot              optional [n_angles][4] = {cos a, sin a, tcT0, tcT1} with
+ *   rot              REQUIRED [n_angles][4] = {cos a, sin a, tcT0, tcT1} with
  *                    a = radians(angle - alpha0), tcT = [tc,tc].dot([[cos,-sin],[sin,cos]]),
- *                    tc = int(s/2.)+1 (pmlib.py:105-110), as the caller's NumPy computed them;
- *                    NULL = derive with libm cos/sin (may differ from NumPy in the last bit)
+ *                    tc = int(s/2.)+1 (pmlib.py:105-110), as the caller's NumPy computed them.  The sample
+ *                    positions of a template are floor(x + 0.5) of float64 coordinates built from these four
+ *                    numbers; a cos / sin that differs from NumPy's in the last bit can tip one at a rounding
+ *                    tie, so the library does not derive them itself: NULL is SID_PM_ERR_ARG (ABI 4; ABI <= 3
+ *                    fell back to libm).  INTEGRATION.md section 2 has the three NumPy lines.
  *   out              [n][5] float64: c2, r2, angle, r, h            (pmlib.py:212)
  *   out_ij           optional [n][3] int32: peak row, peak col, angle index (-1 = NaN point)
  */
@@ -189,6 +195,34 @@ int sid_pm_estimate_cost(const double *border, int64_t n, int img_size, int n_an
 #define SID_PM_CLASS_BIG    32
 #define SID_PM_CLASS_W3B    64
 int sid_pm_estimate_residency(const double *border, int64_t n, int img_size, int n_angles, uint32_t flags, int32_t *launch_class);
+
+/* ---- the per-point functions of the reference as calls of their own ---- */
+
+/* rotate_and_match (pmlib.py:117-174): the rotated templates of side img_size around (c1, r1) on image 1 of the handle's
+ * current pair against the window rows [win_row0, win_row0 + win_rows) x columns [win_col0, win_col0 + win_cols) of its
+ * image 2 - ANY rectangular shape, up to the whole image (the reference's own test passes the whole of image 2,
+ * tests.py:336-337).  A caller with the reference's arguments (img1, ..., image2, ...) uploads (img1, image2) as the pair
+ * and passes the window (0, 0, rows2, cols2).
+ *   out5            dc, dr, best_a, best_r, best_h                    (pmlib.py:174; dc = col - (win_cols - s) / 2.)
+ *   ij3             optional: peak row, peak column, index of the winning angle (-1: NaN point)
+ *   ccm             optional [win_rows - s + 1][win_cols - s + 1] float32 = best_result, ccm_cap = its capacity in floats
+ *   best_template   optional [s][s] uint8
+ * A template that touches a 0 pixel yields NaN x 5 in out5 and leaves ccm / best_template untouched (pmlib.py:152-154).
+ * Fewer than two placements along an axis is SID_PM_ERR_ARG (np.gradient raises there).  `rot` as in sid_pm_batch (required).
+ * Device scratch: 4 B x placements x n_angles + 24 B x placements (kept with the handle). */
+int sid_pm_rotate_and_match(sid_pm_ctx *ctx, double c1, double r1, int img_size,
+                            int64_t win_row0, int64_t win_col0, int64_t win_rows, int64_t win_cols,
+                            double alpha0, const double *angles, const double *rot, int n_angles, uint32_t flags,
+                            double out5[5], int32_t ij3[3], float *ccm, int64_t ccm_cap, uint8_t *best_template);
+
+/* get_template (pmlib.py:89-115): the s x s uint8 template around (c, r) of a host image, rot4 = {cos a, sin a, tcT0, tcT1}
+ * as above; rot_order 0 or 1.  Only the part of the image the samples can touch travels to the device. */
+int sid_pm_get_template(int device, const uint8_t *img, int64_t rows, int64_t cols, int64_t stride, double c, double r,
+                        const double rot4[4], int img_size, int rot_order, uint8_t *out);
+
+/* get_hessian (pmlib.py:36-59) of a host float32 matrix [rows][cols]: np.gradient twice along each axis, np.hypot, and - with
+ * SID_PM_HES_NORM - (hes - median) / std; SID_PM_HES_SMTH: gaussian_filter(ccm, 1) first.  hes [rows][cols] float32. */
+int sid_pm_get_hessian(int device, const float *ccm, int64_t rows, int64_t cols, uint32_t flags, float *hes);
 
 /* ---- diagnostics used by the parity tests ---- */
 

@@ -45,6 +45,9 @@ def lib():
         L.sid_oracle_pm_batch_gap.restype = C.c_int
         L.sid_oracle_pm_batch_gap.argtypes = L.sid_oracle_pm_batch.argtypes + [_f32p]
         L.sid_oracle_max_threads.restype = C.c_int
+        L.sid_oracle_rotate_and_match.restype = C.c_int
+        L.sid_oracle_rotate_and_match.argtypes = ([_u8p, C.c_int64, C.c_int64, C.c_int64] * 2 +
+                                                  [C.c_double, C.c_double, C.c_int, _f64p, _f64p, C.c_int, C.c_uint, _f64p, _i32p, _f32p, _u8p])
         _lib = L
     return _lib
 
@@ -113,6 +116,29 @@ def pm_batch(img1, img2, c1, r1, c2fg, r2fg, border, img_size, alpha0, angles, r
     if rc:
         raise ValueError('sid_oracle_pm_batch failed: %d' % rc)
     return (out, ij, gap) if want_gap else (out, ij)
+
+
+def rotate_and_match(img1, c1, r1, img_size, image2, alpha0, angles, rot, flags=1):
+    """pmlib.py:117-174 with the whole of ``image2`` (any rectangular shape) as the search window.  ``rot`` = [K,4] rotation
+    terms of angle - alpha0 (NumPy's, as the reference computes them).  -> dict(out = dc, dr, a, r, h; ij = row, col, angle
+    index; ccm; template), NaN / -1 / None for a point the reference answers with NaN x 7."""
+    img1, p1 = _u8(img1)
+    image2, p2 = _u8(image2)
+    angles, pa = _f64(angles)
+    rot, prot = _f64(rot)
+    s = int(img_size)
+    rh, rw = image2.shape[0] - s + 1, image2.shape[1] - s + 1
+    out5 = np.empty(5, dtype=np.float64)
+    ij3 = np.empty(3, dtype=np.int32)
+    ccm = np.empty((max(rh, 0), max(rw, 0)), dtype=np.float32)
+    tmpl = np.empty((s, s), dtype=np.uint8)
+    rc = lib().sid_oracle_rotate_and_match(p1, img1.shape[0], img1.shape[1], img1.strides[0], p2, image2.shape[0], image2.shape[1],
+                                           image2.strides[0], float(c1), float(r1), s, pa, prot, len(angles), int(flags),
+                                           out5.ctypes.data_as(_f64p), ij3.ctypes.data_as(_i32p), ccm.ctypes.data_as(_f32p),
+                                           tmpl.ctypes.data_as(_u8p))
+    if rc < 0:
+        raise ValueError('sid_oracle_rotate_and_match: bad shape')
+    return dict(out=out5, ij=ij3, ccm=ccm if rc == 0 else None, template=tmpl if rc == 0 else None)
 
 
 def max_threads():

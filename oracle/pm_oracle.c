@@ -109,11 +109,11 @@ int sid_oracle_get_template1(const uint8_t *img, int64_t rows, int64_t cols, int
 }
 
 /* ------------------------------------------------------------------ a3 */
-/* Exact integer sums + the double normalisation of the spec.  Scratch: sit (int32 rh*rw),
+/* Exact integer sums + the double normalisation of the spec.  Scratch: sit (uint32 rh*rw: sum W*T <= 255^2 s^2 fits for s <= 257),
  * si/sii (int64 rh*rw).  out: float32 rh*rw. */
 static void match_template_core(const uint8_t *win, int wh, int ww, int64_t wstride,
                                 const uint8_t *tmpl, int s, float *out,
-                                int32_t *sit, int64_t *si, int64_t *sii, int have_sums)
+                                uint32_t *sit, int64_t *si, int64_t *sii, int have_sums)
 {
     const int rh = wh - s + 1, rw = ww - s + 1;
     const int64_t n = (int64_t)s * s;
@@ -150,16 +150,16 @@ static void match_template_core(const uint8_t *win, int wh, int ww, int64_t wstr
         for (int k = 0; k < rh * rw; ++k) out[k] = 1.0f;
         return;
     }
-    memset(sit, 0, sizeof(int32_t) * rh * rw);
+    memset(sit, 0, sizeof(uint32_t) * (size_t)rh * rw);
     for (int y = 0; y < rh; ++y) {
-        int32_t *acc = sit + y * rw;
+        uint32_t *acc = sit + (size_t)y * rw;
         for (int i = 0; i < s; ++i) {
             const uint8_t *wrow = win + (int64_t)(y + i) * wstride;
             const uint8_t *trow = tmpl + i * s;
             for (int j = 0; j < s; ++j) {
-                const int32_t t = trow[j];
+                const uint32_t t = trow[j];
                 const uint8_t *w = wrow + j;
-                for (int x = 0; x < rw; ++x) acc[x] += t * (int32_t)w[x];
+                for (int x = 0; x < rw; ++x) acc[x] += t * (uint32_t)w[x];
             }
         }
     }
@@ -188,7 +188,7 @@ int sid_oracle_match_template(const uint8_t *win, int wh, int ww, int64_t wstrid
 {
     const int rh = wh - s + 1, rw = ww - s + 1;
     if (rh < 1 || rw < 1) return -1;
-    int32_t *sit = (int32_t *)malloc(sizeof(int32_t) * rh * rw);
+    uint32_t *sit = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)rh * rw);
     int64_t *si = (int64_t *)malloc(sizeof(int64_t) * 2 * rh * rw);
     match_template_core(win, wh, ww, wstride, tmpl, s, out, sit, si, si + (size_t)rh * rw, 0);
     free(sit); free(si);
@@ -353,9 +353,9 @@ int sid_oracle_hessian(const float *ccm, int rh, int rw, unsigned flags, float *
 
 /* -------------------------------------------------------- a2, a4, a6 */
 typedef struct {
-    uint8_t *tmpl;
+    uint8_t *tmpl, *tmpl_best;
     float *res, *best, *scratch;
-    int32_t *sit;
+    uint32_t *sit;
     int64_t *si;
     size_t cap;                     /* capacity in placements */
     int s;
@@ -364,20 +364,71 @@ typedef struct {
 static void ws_reserve(sid_ws *w, size_t nplace, int s)
 {
     if (w->cap >= nplace && w->s >= s) return;
-    free(w->tmpl); free(w->res); free(w->best); free(w->scratch); free(w->sit); free(w->si);
+    free(w->tmpl); free(w->tmpl_best); free(w->res); free(w->best); free(w->scratch); free(w->sit); free(w->si);
     w->tmpl = (uint8_t *)malloc((size_t)s * s);
+    w->tmpl_best = (uint8_t *)malloc((size_t)s * s);
     w->res = (float *)malloc(sizeof(float) * nplace);
     w->best = (float *)malloc(sizeof(float) * nplace);
     w->scratch = (float *)malloc(sizeof(float) * 3 * nplace);
-    w->sit = (int32_t *)malloc(sizeof(int32_t) * nplace);
+    w->sit = (uint32_t *)malloc(sizeof(uint32_t) * nplace);
     w->si = (int64_t *)malloc(sizeof(int64_t) * 2 * nplace);
     w->cap = nplace; w->s = s;
 }
 
 static void ws_free(sid_ws *w)
 {
-    free(w->tmpl); free(w->res); free(w->best); free(w->scratch); free(w->sit); free(w->si);
+    free(w->tmpl); free(w->tmpl_best); free(w->res); free(w->best); free(w->scratch); free(w->sit); free(w->si);
     memset(w, 0, sizeof(*w));
+}
+
+/* rotate_and_match (pmlib.py:117-174) on a search window of ANY rectangular shape: win = image2[0][0], wh x ww, wstride.
+ * Returns -1 (NaN x 7 in the reference: a zero pixel in a template, pmlib.py:152-154) or the winning angle's index;
+ * ddrc = {dc, dr} (pmlib.py:168-169), *rr = best_r (after mcc_norm), *hh = best_h, iyx = peak row / col; the winning NCC
+ * matrix stays in w->best and the winning template in w->tmpl_best. */
+static int rotate_and_match_ws(sid_ws *w, const uint8_t *img1, int64_t rows1, int64_t cols1, int64_t stride1,
+                               const uint8_t *win, int wh, int ww, int64_t wstride, double c1, double r1,
+                               int s, const double *rot, int n_angles, unsigned flags,
+                               double *ddrc, float *rr_out, float *hh_out, int *iyx, float *gap)
+{
+    const int rh = wh - s + 1, rw = ww - s + 1;
+    ws_reserve(w, (size_t)rh * rw, s);
+    float best_r = -INFINITY;
+    float top1 = -INFINITY, top2 = -INFINITY;                   /* two largest values over all angles and placements */
+    int best_k = -1; int64_t best_idx = -1;
+    for (int k = 0; k < n_angles; ++k) {
+        if (((flags & SID_FLAG_ROT_ORDER1) ? sid_oracle_get_template1 : sid_oracle_get_template)(img1, rows1, cols1, stride1, c1, r1, rot + 4 * k, s, w->tmpl) == 0)
+            return -1;                                          /* pmlib.py:152-154 -> NaN */
+        match_template_core(win, wh, ww, wstride, w->tmpl, s, w->res, w->sit, w->si,
+                            w->si + (size_t)rh * rw, k > 0);
+        int64_t idx = 0; float mx = w->res[0];
+        for (int64_t p = 1; p < (int64_t)rh * rw; ++p) if (w->res[p] > mx) { mx = w->res[p]; idx = p; }  /* first max */
+        if (gap)
+            for (int64_t p = 0; p < (int64_t)rh * rw; ++p) {
+                const float v = w->res[p];
+                if (v > top1) { top2 = top1; top1 = v; } else if (v > top2) top2 = v;
+            }
+        if (mx > best_r) {                                      /* strict (pmlib.py:160) */
+            best_r = mx; best_k = k; best_idx = idx;
+            float *t = w->best; w->best = w->res; w->res = t;
+            memcpy(w->tmpl_best, w->tmpl, (size_t)s * s);
+        }
+    }
+    if (best_k < 0) return -1;
+    const int iy = (int)(best_idx / rw), ix = (int)(best_idx % rw);
+    *hh_out = sid_oracle_hessian_at(w->best, rh, rw, flags, iy, ix, w->scratch);
+    ddrc[1] = iy - (wh - s) / 2.; ddrc[0] = ix - (ww - s) / 2.;
+    float rr = best_r;
+    if (flags & SID_FLAG_MCC_NORM) {
+        float med, sd;
+        median_std_f32(w->best, (int64_t)rh * rw, w->scratch, &med, &sd);
+        rr = (best_r - med) / sd;
+    }
+    *rr_out = rr;
+    iyx[0] = iy; iyx[1] = ix;
+    /* distance of the peak to the runner-up anywhere in the (angle, row, col) volume: a float32/DFT matcher
+     * (cv2) could pick the other one when this is below its noise (~1e-6) */
+    if (gap) *gap = top1 - top2;
+    return best_k;
 }
 
 /* One grid point: use_mcc + rotate_and_match.  out5 = c2, r2, a, r, h ; ij3 = row, col, angle idx */
@@ -396,46 +447,39 @@ static void use_mcc_ws(sid_ws *w, const uint8_t *img1, int64_t rows1, int64_t co
     if (gap) *gap = NAN;
     if (!(r0 >= 0 && c0 >= 0 && r1e <= rows2 && c1e <= cols2 && r1e - r0 >= s + 1 && c1e - c0 >= s + 1)) return;
     const int wh = (int)(r1e - r0), ww = (int)(c1e - c0);
-    const int rh = wh - s + 1, rw = ww - s + 1;
-    ws_reserve(w, (size_t)rh * rw, s);
-    const uint8_t *win = img2 + r0 * stride2 + c0;
+    double ddrc[2]; float rr, hh; int iyx[2];
+    const int best_k = rotate_and_match_ws(w, img1, rows1, cols1, stride1, img2 + r0 * stride2 + c0, wh, ww, stride2, c1, r1,
+                                           s, rot, n_angles, flags, ddrc, &rr, &hh, iyx, gap);
+    if (best_k < 0) { if (gap) *gap = NAN; return; }
+    out5[0] = c2fg + ddrc[0]; out5[1] = r2fg + ddrc[1]; out5[2] = angles[best_k];
+    out5[3] = (double)rr; out5[4] = (double)hh;
+    if (ij3) { ij3[0] = iyx[0]; ij3[1] = iyx[1]; ij3[2] = best_k; }
+}
 
-    float best_r = -INFINITY;
-    float top1 = -INFINITY, top2 = -INFINITY;                   /* two largest values over all angles and placements */
-    int best_k = -1, best_idx = -1;
-    for (int k = 0; k < n_angles; ++k) {
-        if (((flags & SID_FLAG_ROT_ORDER1) ? sid_oracle_get_template1 : sid_oracle_get_template)(img1, rows1, cols1, stride1, c1, r1, rot + 4 * k, s, w->tmpl) == 0)
-            return;                                             /* pmlib.py:152-154 -> NaN */
-        match_template_core(win, wh, ww, stride2, w->tmpl, s, w->res, w->sit, w->si,
-                            w->si + (size_t)rh * rw, k > 0);
-        int idx = 0; float mx = w->res[0];
-        for (int p = 1; p < rh * rw; ++p) if (w->res[p] > mx) { mx = w->res[p]; idx = p; }  /* first max */
-        if (gap)
-            for (int p = 0; p < rh * rw; ++p) {
-                const float v = w->res[p];
-                if (v > top1) { top2 = top1; top1 = v; } else if (v > top2) top2 = v;
-            }
-        if (mx > best_r) {                                      /* strict (pmlib.py:160) */
-            best_r = mx; best_k = k; best_idx = idx;
-            float *t = w->best; w->best = w->res; w->res = t;
-        }
+/* rotate_and_match (pmlib.py:117-174) as a call of its own: the search window is the whole of `image2` (any rectangular
+ * shape, e.g. the reference's tests.py:336-337).  out5 = dc, dr, best_a, best_r, best_h; ij3 = peak row, col, angle index;
+ * ccm [rh*rw] and tmpl [s*s] may be NULL.  Returns 0, 1 when the point is NaN x 7 (ij3 = -1), -1 on a bad shape. */
+int sid_oracle_rotate_and_match(const uint8_t *img1, int64_t rows1, int64_t cols1, int64_t stride1,
+                                const uint8_t *image2, int64_t rows2, int64_t cols2, int64_t stride2,
+                                double c1, double r1, int img_size, const double *angles, const double *rot, int n_angles,
+                                unsigned flags, double *out5, int32_t *ij3, float *ccm, uint8_t *tmpl)
+{
+    const int s = img_size;
+    if (n_angles < 1 || s < 2 || rows2 - s + 1 < 2 || cols2 - s + 1 < 2 || !rot) return -1;
+    sid_ws w; memset(&w, 0, sizeof(w));
+    double ddrc[2]; float rr, hh; int iyx[2];
+    for (int k = 0; k < 5; ++k) out5[k] = NAN;
+    if (ij3) { ij3[0] = ij3[1] = ij3[2] = -1; }
+    const int best_k = rotate_and_match_ws(&w, img1, rows1, cols1, stride1, image2, (int)rows2, (int)cols2, stride2, c1, r1,
+                                           s, rot, n_angles, flags, ddrc, &rr, &hh, iyx, NULL);
+    if (best_k >= 0) {
+        out5[0] = ddrc[0]; out5[1] = ddrc[1]; out5[2] = angles[best_k]; out5[3] = (double)rr; out5[4] = (double)hh;
+        if (ij3) { ij3[0] = iyx[0]; ij3[1] = iyx[1]; ij3[2] = best_k; }
+        if (ccm) memcpy(ccm, w.best, sizeof(float) * (size_t)(rows2 - s + 1) * (size_t)(cols2 - s + 1));
+        if (tmpl) memcpy(tmpl, w.tmpl_best, (size_t)s * s);
     }
-    if (best_k < 0) return;
-    const int iy = best_idx / rw, ix = best_idx % rw;
-    const float best_h = sid_oracle_hessian_at(w->best, rh, rw, flags, iy, ix, w->scratch);
-    const double dr = iy - (wh - s) / 2., dc = ix - (ww - s) / 2.;
-    float rr = best_r;
-    if (flags & SID_FLAG_MCC_NORM) {
-        float med, sd;
-        median_std_f32(w->best, (int64_t)rh * rw, w->scratch, &med, &sd);
-        rr = (best_r - med) / sd;
-    }
-    out5[0] = c2fg + dc; out5[1] = r2fg + dr; out5[2] = angles[best_k];
-    out5[3] = (double)rr; out5[4] = (double)best_h;
-    if (ij3) { ij3[0] = iy; ij3[1] = ix; ij3[2] = best_k; }
-    /* distance of the peak to the runner-up anywhere in the (angle, row, col) volume: a float32/DFT matcher
-     * (cv2) could pick the other one when this is below its noise (~1e-6) */
-    if (gap) *gap = top1 - top2;
+    ws_free(&w);
+    return best_k >= 0 ? 0 : 1;
 }
 
 /* rot may be NULL: then cos/sin/tcT are derived here with libm (NumPy's own cos/sin can

@@ -16,7 +16,7 @@ HES_SMTH = 2
 MCC_NORM = 4
 ROT_ORDER1 = 8          # rot_order=1: bilinear template sampling (include/sid_pm.h)
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 # every symbol include/sid_pm.h declares
 SYMBOLS = (
@@ -25,6 +25,7 @@ SYMBOLS = (
     'sid_pm_select_pair', 'sid_pm_bind_pair', 'sid_pm_set_points', 'sid_pm_bind_results', 'sid_pm_run', 'sid_pm_sync', 'sid_pm_check', 'sid_pm_unpermute',
     'sid_pm_fetch', 'sid_pm_device_results', 'sid_pm_work_info', 'sid_pm_debug_point', 'sid_pm_debug_ncc_selftest',
     'sid_pm_debug_rsqrt', 'sid_pm_debug_hypot_selftest', 'sid_pm_estimate_cost', 'sid_pm_estimate_residency',
+    'sid_pm_rotate_and_match', 'sid_pm_get_template', 'sid_pm_get_hessian',
 )
 
 # every symbol include/sid_ft.h declares (feature-tracking matcher, same library)
@@ -38,7 +39,7 @@ STAGE_SYMBOLS = ('sid_stage_create', 'sid_stage_destroy', 'sid_stage_begin', 'si
 ORB_SYMBOLS = ('sid_orb_detect', 'sid_orb_last_error', 'sid_orb_release')
 
 # every symbol include/sid_fg.h declares (first-guess evaluation, same library)
-FG_SYMBOLS = ('sid_fg_interp_linear', 'sid_fg_nearest_dist', 'sid_fg_last_error', 'sid_fg_release')
+FG_SYMBOLS = ('sid_fg_interp_linear', 'sid_fg_nearest_dist', 'sid_fg_distance_image', 'sid_fg_last_error', 'sid_fg_release')
 
 _u8p = C.POINTER(C.c_uint8)
 _f64p = C.POINTER(C.c_double)
@@ -106,6 +107,11 @@ def lib():
     L.sid_pm_estimate_cost.argtypes = [_f64p, C.c_int64, C.c_int, C.c_int, C.c_uint32, _f64p]
     L.sid_pm_estimate_residency.argtypes = [_f64p, C.c_int64, C.c_int, C.c_int, C.c_uint32, _i32p]
     L.sid_pm_debug_hypot_selftest.argtypes = [C.c_void_p, C.c_uint64, C.c_int64, C.POINTER(C.c_uint64)]
+    if hasattr(L, 'sid_pm_rotate_and_match'):
+        L.sid_pm_rotate_and_match.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_int, C.c_int64, C.c_int64, C.c_int64, C.c_int64,
+                                              C.c_double, _f64p, _f64p, C.c_int, C.c_uint32, _f64p, _i32p, _f32p, C.c_int64, _u8p]
+        L.sid_pm_get_template.argtypes = [C.c_int, _u8p, C.c_int64, C.c_int64, C.c_int64, C.c_double, C.c_double, _f64p, C.c_int, C.c_int, _u8p]
+        L.sid_pm_get_hessian.argtypes = [C.c_int, _f32p, C.c_int64, C.c_int64, C.c_uint32, _f32p]
     L.sid_ft_knn2.argtypes = [C.c_int, _u8p, C.c_int64, _u8p, C.c_int64, _i32p, _i32p]
     L.sid_ft_knn2_device.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.sid_ft_workspace_bytes.argtypes = [C.c_int64, C.c_int64]
@@ -130,13 +136,15 @@ def lib():
     L.sid_orb_last_error.restype = C.c_char_p
     L.sid_fg_interp_linear.argtypes = [C.c_int, _f64p, C.c_int64, _i32p, C.c_int64, _f64p, _f64p, C.c_int64, _f64p, _i32p, _i32p]
     L.sid_fg_nearest_dist.argtypes = [C.c_int, _f64p, C.c_int64, _f64p, C.c_int64, _f64p]
+    if hasattr(L, 'sid_fg_distance_image'):
+        L.sid_fg_distance_image.argtypes = [C.c_int, _f64p, C.c_int64, C.c_int64, C.c_int64, _f64p]
     L.sid_fg_last_error.restype = C.c_char_p
     # SID_PM_LIB (A/B runs against the library of an earlier round) may lack the entry points added since
-    optional = ('sid_pm_check', 'sid_pm_unpermute') if os.environ.get('SID_PM_LIB') else ()
+    optional = ('sid_pm_check', 'sid_pm_unpermute', 'sid_pm_rotate_and_match', 'sid_pm_get_template', 'sid_pm_get_hessian') if os.environ.get('SID_PM_LIB') else ()
     for name in SYMBOLS:
         if name not in optional:
             getattr(L, name)                  # AttributeError here = header/library mismatch
-    if L.sid_pm_abi_version() != ABI_VERSION:
+    if L.sid_pm_abi_version() != ABI_VERSION and not os.environ.get('SID_PM_LIB'):
         raise ImportError('libsid_pm.so ABI %d != binding ABI %d' % (L.sid_pm_abi_version(), ABI_VERSION))
     _lib = L
     return L
@@ -213,6 +221,32 @@ def estimate_residency(border, img_size=34, n_angles=15, flags=HES_NORM):
     return out
 
 
+def rotation_terms(angle_deg, img_size):
+    """(cos a, sin a, tcT0, tcT1) for one sampling angle, computed with NumPy exactly like the reference's get_template
+    (pmlib.py:105-110): tc = int(s/2.)+1, a = radians(angle), transform = [[cos,-sin],[sin,cos]], tcT = [tc,tc].dot(transform).
+    The C ABI requires these numbers from its caller (include/sid_pm.h: `rot`), so that the device samples the same float64
+    coordinates the reference's scipy call would."""
+    tc = int(img_size / 2.) + 1
+    tc = np.array([tc, tc])
+    a = np.radians(angle_deg)
+    transform = np.array([[np.cos(a), -np.sin(a)], [np.sin(a), np.cos(a)]])
+    tct = tc.dot(transform)
+    return float(transform[0, 0]), float(transform[1, 0]), float(tct[0]), float(tct[1])
+
+
+def rotation_table(angles, alpha0, img_size):
+    """[K,4] table of rotation_terms(angle - alpha0) (pmlib.py:151)."""
+    return np.array([rotation_terms(a - alpha0, img_size) for a in angles], dtype=np.float64).reshape(-1, 4)
+
+
+def _rot_arg(rot, angles, alpha0, img_size):
+    """The `rot` argument of the C ABI: the caller's table, or NumPy's own values (never the library's: sid_pm.h)."""
+    rot = rotation_table(angles, alpha0, img_size) if rot is None else _f64(rot)
+    if rot.shape != (len(angles), 4):
+        raise ValueError('rot must be [n_angles, 4]')
+    return rot
+
+
 def flags_from_kwargs(hes_norm=True, hes_smth=False, mcc_norm=False, rot_order=0):
     if rot_order not in (0, 1):
         raise NotImplementedError('rot_order=%r' % (rot_order,))
@@ -226,10 +260,8 @@ def pm_batch(img1, img2, c1, r1, c2fg, r2fg, border, img_size, alpha0, angles, r
     v = [_f64(x) for x in (c1, r1, c2fg, r2fg, border)]
     n = len(v[0])
     angles = _f64(angles)
-    rotp = None
-    if rot is not None:
-        rot = _f64(rot)
-        rotp = _p(rot, _f64p)
+    rot = _rot_arg(rot, angles, alpha0, img_size) if len(angles) else _f64(np.zeros((0, 4)))
+    rotp = _p(rot, _f64p)
     out = np.empty((n, 5), dtype=np.float64)
     ij = np.empty((n, 3), dtype=np.int32)
     _check(lib().sid_pm_batch(_p(img1, _u8p), img1.shape[0], img1.shape[1], img1.strides[0],
@@ -342,12 +374,8 @@ class PMContext(object):
         if any(len(x) != n for x in v):
             raise ValueError('point vectors differ in length')
         angles = _f64(angles)
-        rotp = None
-        if rot is not None:
-            rot = _f64(rot)
-            if rot.shape != (len(angles), 4):
-                raise ValueError('rot must be [n_angles, 4]')
-            rotp = _p(rot, _f64p)
+        rot = _rot_arg(rot, angles, alpha0, img_size) if len(angles) else _f64(np.zeros((0, 4)))
+        rotp = _p(rot, _f64p)
         _check(lib().sid_pm_set_points(self._h, *[_p(x, _f64p) for x in v], n, int(img_size), float(alpha0),
                                        _p(angles, _f64p), rotp, len(angles), int(flags)))
         self.n = n
@@ -406,10 +434,8 @@ class PMContext(object):
     def debug_point(self, c1, r1, c2fg, r2fg, border, img_size, alpha0, angles, rot=None, flags=HES_NORM,
                     cap=256 * 256):
         angles = _f64(angles)
-        rotp = None
-        if rot is not None:
-            rot = _f64(rot)
-            rotp = _p(rot, _f64p)
+        rot = _rot_arg(rot, angles, alpha0, img_size)
+        rotp = _p(rot, _f64p)
         K, s = len(angles), int(img_size)
         tm = np.zeros((K, s, s), dtype=np.uint8)
         ccm = np.zeros(cap, dtype=np.float32)
@@ -426,6 +452,30 @@ class PMContext(object):
         n = rh * rw
         return dict(templates=tm, ccm=ccm[:n].reshape(rh, rw), hes=hes[:n].reshape(rh, rw), out=out5, ij=ij3,
                     cycles=cyc)
+
+    def rotate_and_match(self, c1, r1, img_size, alpha0, angles, rot=None, flags=HES_NORM, window=None, want_ccm=True,
+                         want_template=True):
+        """``sid_pm_rotate_and_match`` on the handle's current pair: the templates around (c1, r1) of image 1 against ``window`` =
+        (row0, col0, rows, cols) of image 2 (None: the whole image).  -> dict(out = dc, dr, a, r, h; ij = peak row, peak column,
+        angle index (-1: NaN point); ccm [rh, rw] float32 and template [s, s] uint8, None for a NaN point)."""
+        angles = _f64(angles)
+        rot = _rot_arg(rot, angles, alpha0, img_size)
+        s = int(img_size)
+        if window is None:
+            raise ValueError('window = (row0, col0, rows, cols) of image 2')
+        r0, c0, wh, ww = [int(v) for v in window]
+        rh, rw = wh - s + 1, ww - s + 1
+        out5 = np.zeros(5, dtype=np.float64)
+        ij3 = np.zeros(3, dtype=np.int32)
+        ccm = np.zeros(max(rh, 0) * max(rw, 0), dtype=np.float32) if want_ccm else None
+        tm = np.zeros((s, s), dtype=np.uint8) if want_template else None
+        _check(lib().sid_pm_rotate_and_match(self._h, float(c1), float(r1), s, r0, c0, wh, ww, float(alpha0), _p(angles, _f64p),
+                                             _p(rot, _f64p), len(angles), int(flags), _p(out5, _f64p), _p(ij3, _i32p),
+                                             _p(ccm, _f32p) if want_ccm else None, ccm.size if want_ccm else 0,
+                                             _p(tm, _u8p) if want_template else None))
+        ok = ij3[2] >= 0
+        return dict(out=out5, ij=ij3, ccm=ccm.reshape(rh, rw) if (want_ccm and ok) else None,
+                    template=tm if (want_template and ok) else None)
 
     def debug_rsqrt(self, x):
         x = _f64(x)
@@ -444,6 +494,27 @@ class PMContext(object):
         counts = (C.c_uint64 * 2)()
         _check(lib().sid_pm_debug_hypot_selftest(self._h, int(seed), int(evaluations), counts))
         return int(counts[0]), int(counts[1])
+
+
+def get_template(img, c, r, rot4, img_size, rot_order=0, device=0):
+    """``sid_pm_get_template``: the s x s uint8 template around (c, r) of a host uint8 image (pmlib.py:89-115)."""
+    img = _u8(img)
+    rot4 = _f64(rot4).reshape(4)
+    s = int(img_size)
+    out = np.empty((s, s), dtype=np.uint8)
+    _check(lib().sid_pm_get_template(int(device), _p(img, _u8p), img.shape[0], img.shape[1], img.strides[0], float(c), float(r),
+                                     _p(rot4, _f64p), s, int(rot_order), _p(out, _u8p)))
+    return out
+
+
+def get_hessian(ccm, flags=HES_NORM, device=0):
+    """``sid_pm_get_hessian``: the Hessian magnitudes of a float32 matrix (pmlib.py:36-59)."""
+    ccm = np.ascontiguousarray(ccm, dtype=np.float32)
+    if ccm.ndim != 2:
+        raise ValueError('get_hessian needs a 2-D matrix')
+    out = np.empty_like(ccm)
+    _check(lib().sid_pm_get_hessian(int(device), _p(ccm, _f32p), ccm.shape[0], ccm.shape[1], int(flags), _p(out, _f32p)))
+    return out
 
 
 def ft_knn2(desc1, desc2, device=0):
@@ -550,6 +621,18 @@ def fg_nearest_dist(seeds, q, device=0):
     out = np.empty(len(q), dtype=np.float64)
     L = lib()
     rc = L.sid_fg_nearest_dist(int(device), _p(seeds, _f64p), len(seeds), _p(q, _f64p), len(q), _p(out, _f64p))
+    if rc != 0:
+        raise SidPmError(rc, L.sid_fg_last_error().decode())
+    return out
+
+
+def fg_distance_image(seeds, rows, cols, device=0):
+    """Distance of every pixel of a rows x cols image to the nearest of seeds [n,2] = (row, column)
+    (include/sid_fg.h sid_fg_distance_image) -> float64 [rows, cols]."""
+    seeds = _f64(seeds)
+    out = np.empty((int(rows), int(cols)), dtype=np.float64)
+    L = lib()
+    rc = L.sid_fg_distance_image(int(device), _p(seeds, _f64p), len(seeds), int(rows), int(cols), _p(out, _f64p))
     if rc != 0:
         raise SidPmError(rc, L.sid_fg_last_error().decode())
     return out

@@ -274,11 +274,13 @@ __global__ __launch_bounds__(256) void k_resolve(const Simp *simp, int64_t ns, c
     }
 }
 
-__global__ __launch_bounds__(256) void k_nearest(const double *seeds, int64_t ns, const double *q, int64_t nq, double *dist)
+// q == nullptr: the queries are the pixels of an image with `qcols` columns, query i = (row i / qcols, column i % qcols)
+// (sid_fg_distance_image: the reference's full-resolution distance image, pmlib.py:61-77)
+__global__ __launch_bounds__(256) void k_nearest(const double *seeds, int64_t ns, const double *q, int64_t nq, double *dist, int64_t qcols)
 {
     __shared__ double sx[1024], sy[1024];
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const double x = i < nq ? q[2 * i] : 0.0, y = i < nq ? q[2 * i + 1] : 0.0;
+    const double x = i >= nq ? 0.0 : q ? q[2 * i] : (double)(i / qcols), y = i >= nq ? 0.0 : q ? q[2 * i + 1] : (double)(i % qcols);
     double best = INFINITY;
     for (int64_t base = 0; base < ns; base += 1024) {
         __syncthreads();
@@ -313,11 +315,11 @@ __global__ void k_seed_bin(const double *seeds, int64_t ns, GridGeo g, int32_t *
     if (PASS == 1) ids[start[cell] + pos] = (int32_t)k;
 }
 __global__ __launch_bounds__(256) void k_nearest_grid(const double *seeds, const int32_t *start, const int32_t *ids, GridGeo g, double wx, double wy,
-                                                       double margin, const double *q, int64_t nq, double *dist)
+                                                       double margin, const double *q, int64_t nq, double *dist, int64_t qcols)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nq) return;
-    const double x = q[2 * i], y = q[2 * i + 1];
+    const double x = q ? q[2 * i] : (double)(i / qcols), y = q ? q[2 * i + 1] : (double)(i % qcols);
     const int cx = cell_of(x, g.x0, g.ix), cy = cell_of(y, g.y0, g.iy);
     double best = INFINITY;
     for (int r = 0; r < kGrid; ++r) {
@@ -448,7 +450,7 @@ SID_EXPORT int sid_fg_interp_linear(int device, const double *pts, int64_t n_pts
     }
     HIP_TRY(hipMemcpyAsync(d_pts, pts, sizeof(double) * 2 * n_pts, hipMemcpyHostToDevice, 0));
     HIP_TRY(hipMemcpyAsync(d_val, values, sizeof(double) * 2 * n_pts, hipMemcpyHostToDevice, 0));
-    HIP_TRY(hipMemcpyAsync(d_q, q, sizeof(double) * 2 * n_q, hipMemcpyHostToDevice, 0));
+    if (q) HIP_TRY(hipMemcpyAsync(d_q, q, sizeof(double) * 2 * n_q, hipMemcpyHostToDevice, 0));
     HIP_TRY(hipMemcpyAsync(d_simp, simplices, sizeof(int32_t) * 3 * n_simp, hipMemcpyHostToDevice, 0));
     hipLaunchKernelGGL(k_transform, dim3((unsigned)((n_simp + 255) / 256)), dim3(256), 0, 0, d_pts, d_simp, n_simp, d_t);
     {
@@ -492,10 +494,26 @@ done:
     return rc;
 }
 
+static int nearest_dist_impl(int device, const double *seeds, int64_t n_seeds, const double *q, int64_t n_q, double *dist, int64_t qcols);
+
 SID_EXPORT int sid_fg_nearest_dist(int device, const double *seeds, int64_t n_seeds, const double *q, int64_t n_q, double *dist)
 {
     if (n_q == 0) return SID_PM_OK;
     if (!seeds || !q || !dist || n_seeds < 1 || n_q < 0) return fail(SID_PM_ERR_ARG, "bad argument");
+    return nearest_dist_impl(device, seeds, n_seeds, q, n_q, dist, 1);
+}
+
+SID_EXPORT int sid_fg_distance_image(int device, const double *seeds, int64_t n_seeds, int64_t rows, int64_t cols, double *dist)
+{
+    if (rows == 0 || cols == 0) return SID_PM_OK;
+    if (!seeds || !dist || n_seeds < 1 || rows < 0 || cols < 0 || rows > (int64_t)1 << 31 || cols > (int64_t)1 << 31 || rows * cols > (int64_t)1 << 36)
+        return fail(SID_PM_ERR_ARG, "bad argument");
+    return nearest_dist_impl(device, seeds, n_seeds, nullptr, rows * cols, dist, cols);
+}
+
+// q == nullptr: the queries are the pixels (row, column) of an image with `qcols` columns
+static int nearest_dist_impl(int device, const double *seeds, int64_t n_seeds, const double *q, int64_t n_q, double *dist, int64_t qcols)
+{
     int prev = 0;
     if (int rc0 = pick_device(device, prev)) return rc0;
     int rc = SID_PM_OK;
@@ -504,15 +522,16 @@ SID_EXPORT int sid_fg_nearest_dist(int device, const double *seeds, int64_t n_se
     unsigned char *blk = nullptr;
     double *d_s = nullptr, *d_q = nullptr, *d_d = nullptr;
     int32_t *d_cnt = nullptr, *d_start = nullptr, *d_ids = nullptr;
-    if ((rc = pool_reserve(device, up(sizeof(double) * 2 * n_seeds) + up(sizeof(double) * 2 * n_q) + up(sizeof(double) * n_q) +
+    if ((rc = pool_reserve(device, up(sizeof(double) * 2 * n_seeds) + up(sizeof(double) * 2 * (q ? n_q : 1)) + up(sizeof(double) * n_q) +
                                    up(sizeof(int32_t) * (kGrid * kGrid + 1)) * 2 + up(sizeof(int32_t) * n_seeds), &blk))) { (void)hipSetDevice(prev); return rc; }
     {
         Carver cv(blk);
-        d_s = cv.take<double>(2 * n_seeds); d_q = cv.take<double>(2 * n_q); d_d = cv.take<double>(n_q);
+        d_s = cv.take<double>(2 * n_seeds); d_q = cv.take<double>(2 * (q ? n_q : 1)); d_d = cv.take<double>(n_q);
+        if (!q) d_q = nullptr;
         d_cnt = cv.take<int32_t>(kGrid * kGrid + 1); d_start = cv.take<int32_t>(kGrid * kGrid + 1); d_ids = cv.take<int32_t>(n_seeds);
     }
     HIP_TRY(hipMemcpyAsync(d_s, seeds, sizeof(double) * 2 * n_seeds, hipMemcpyHostToDevice, 0));
-    HIP_TRY(hipMemcpyAsync(d_q, q, sizeof(double) * 2 * n_q, hipMemcpyHostToDevice, 0));
+    if (q) HIP_TRY(hipMemcpyAsync(d_q, q, sizeof(double) * 2 * n_q, hipMemcpyHostToDevice, 0));
     {
         // bounding box of the seeds (host: they are host arrays); the buckets pay from a few hundred seeds on, and need finite
         // coordinates and a box with an area (SID_FG_NO_GRID=1: brute force always; A/B runs and the parity test of both)
@@ -534,9 +553,9 @@ SID_EXPORT int sid_fg_nearest_dist(int device, const double *seeds, int64_t n_se
             hipLaunchKernelGGL(k_grid_scan, dim3(1), dim3(1024), 0, 0, d_cnt, d_start);
             hipLaunchKernelGGL(k_seed_bin<1>, dim3(nb), dim3(256), 0, 0, d_s, n_seeds, geo, d_cnt, d_start, d_ids);
             hipLaunchKernelGGL(k_nearest_grid, dim3((unsigned)((n_q + 255) / 256)), dim3(256), 0, 0, d_s, d_start, d_ids, geo, w / kGrid, h / kGrid, margin,
-                               d_q, n_q, d_d);
+                               (const double *)d_q, n_q, d_d, qcols);
         } else {
-            hipLaunchKernelGGL(k_nearest, dim3((unsigned)((n_q + 255) / 256)), dim3(256), 0, 0, d_s, n_seeds, d_q, n_q, d_d);
+            hipLaunchKernelGGL(k_nearest, dim3((unsigned)((n_q + 255) / 256)), dim3(256), 0, 0, d_s, n_seeds, (const double *)d_q, n_q, d_d, qcols);
         }
     }
     HIP_TRY(hipGetLastError());

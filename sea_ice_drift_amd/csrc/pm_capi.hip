@@ -19,6 +19,7 @@
 
 #include "../../include/sid_pm.h"
 #include "pm_kernel.h"
+#include "pm_large.h"
 
 #define SID_EXPORT extern "C" __attribute__((visibility("default")))
 
@@ -118,6 +119,13 @@ struct sid_pm_ctx {
     double *user_out = nullptr;         // caller-owned result arrays (bind_results)
     int32_t *user_ij = nullptr;
     std::vector<Bucket> buckets;
+    // points beyond the launch classes of the one-workgroup-per-point kernels (search window too large for the LDS, template side
+    // above 64): each runs the large-window pipeline (pm_large.hip) after the launches of the others
+    std::vector<int32_t> large_idx;
+    DevBuf<int32_t> d_nan_idx;          // ... and, when NO other kernel of the run exists (template side above 64), the points without a valid window
+    int n_nan_idx = 0;
+    sid::LwWorkspace lw;
+    DevBuf<double> lw_small;            // rotate_and_match as a call of its own: angles, rotation terms, the five results
     int64_t n = 0;
     int img_size = 0, n_angles = 0;
     uint32_t flags = 0;
@@ -133,20 +141,14 @@ struct Guard {
     ~Guard() { if (prev >= 0) (void)hipSetDevice(prev); }
 };
 
-void make_rot(const double *angles, int n_angles, double alpha0, int s, const double *rot_in,
-              std::vector<double> &rot)
+// rotation terms [K][4] = cos, sin, tcT0, tcT1 of angle - alpha0 (pmlib.py:105-110), as the CALLER's NumPy computed them:
+// required (include/sid_pm.h) - libm's cos / sin may differ from NumPy's in the last bit, which can tip a sample at a rounding tie
+int make_rot(int n_angles, const double *rot_in, std::vector<double> &rot)
 {
-    rot.resize(4 * (size_t)n_angles);
-    if (rot_in) { memcpy(rot.data(), rot_in, sizeof(double) * rot.size()); return; }
-    // pmlib.py:105-110 with libm in place of NumPy's cos/sin
-    const double tc = (double)((int)((double)s / 2.) + 1);
-    for (int k = 0; k < n_angles; ++k) {
-        const double a = (angles[k] - alpha0) * (M_PI / 180.0);
-        const double ca = cos(a), sa = sin(a);
-        rot[4 * k + 0] = ca; rot[4 * k + 1] = sa;
-        rot[4 * k + 2] = tc * ca + tc * sa;
-        rot[4 * k + 3] = tc * (-sa) + tc * ca;
-    }
+    if (!rot_in) return fail(SID_PM_ERR_ARG, "rot is required: [n_angles][4] = cos, sin, tcT0, tcT1 as the caller's NumPy computed them (pmlib.py:105-110; include/sid_pm.h)");
+    rot.assign(rot_in, rot_in + 4 * (size_t)n_angles);
+    for (const double v : rot) if (!(fabs(v) < 1e6)) return fail(SID_PM_ERR_ARG, "rot holds a non-finite or absurd value");
+    return SID_PM_OK;
 }
 
 // Sampling table of the MFMA kernel.  The reference rounds the template centres to integers before the
@@ -342,8 +344,8 @@ int check_sweep(int img_size, const double *angles, int n_angles, uint32_t flags
         return fail(SID_PM_ERR_ARG, "angles must hold at least one angle (the reference's loop, pmlib.py:150, "
                                     "leaves best_result undefined for an empty list)");
     if (n_angles > sid::kMaxAngles) return fail(SID_PM_ERR_UNSUPPORTED, "more than %d angles", sid::kMaxAngles);
-    if (!sid::mfma_img_size_supported(img_size))
-        return fail(SID_PM_ERR_UNSUPPORTED, "img_size=%d: the kernel supports 2..64", img_size);
+    if (img_size < 2 || img_size > sid::kLargeMaxSide)
+        return fail(SID_PM_ERR_UNSUPPORTED, "img_size=%d: the kernels support 2..%d", img_size, sid::kLargeMaxSide);
     if (flags & ~(SID_PM_HES_NORM | SID_PM_HES_SMTH | SID_PM_MCC_NORM | SID_PM_ROT_ORDER1)) return fail(SID_PM_ERR_ARG, "unknown flag bits");
     return SID_PM_OK;
 }
@@ -449,7 +451,7 @@ int classify_points(sid_pm_ctx *ctx)
     static const bool no_fixed_pitch = getenv("SID_PM_NO_FIXED_PITCH") != nullptr;         // (run-time pitch everywhere: gs instantiations; A/B runs)
     // Everything the launch needs to know about a point follows from the SHAPE of its search window, and a run has a few
     // dozen shapes (one per border): the LDS layouts are evaluated per shape, the points are only binned.
-    struct Shape { int wh, ww, lds, band, cls, nat_pitch, pitch; double work; std::vector<int32_t> idx; bool gs = false, big = false; int w3p = 0; bool keep = false; };
+    struct Shape { int wh, ww, lds, band, cls, nat_pitch, pitch; double work; std::vector<int32_t> idx; bool gs = false, big = false; int w3p = 0; bool keep = false; bool large = false; };
     std::vector<Shape> shapes;
     std::vector<int32_t> slot_of((size_t)1 << 16, -1);                // (wh, ww) -> shape, direct-mapped on a hash of the pair
     auto find_shape = [&](int wh, int ww) -> int {
@@ -463,7 +465,10 @@ int classify_points(sid_pm_ctx *ctx)
     ctx->gs_keep_si = getenv("SID_PM_NO_GSI") == nullptr;
     ctx->gs_keep_acc = keep_acc_policy(rp, rpp, K);
     const uint32_t flags = ctx->flags;
-    const int lds_min = lds_need(rp, rpp, s + 1, s + 1, s, K, flags, 4, 0, false);
+    // template sides the one-point kernels do not take: every point with a valid window runs the large-window pipeline
+    const bool small_ok = sid::mfma_img_size_supported(s);
+    ctx->large_idx.clear(); ctx->n_nan_idx = 0;
+    const int lds_min = small_ok ? lds_need(rp, rpp, s + 1, s + 1, s, K, flags, 4, 0, false) : 0;
     {   // shape 0: points whose window does not lie inside image 2 (they write NaN at once; minimal footprint)
         Shape z{0, 0, lds_min, 4, std::min(kMaxPerCu, blocks_per_cu(lds_min)), 0, 0, 0.0, {}};   // (NaN writers: any class)
         shapes.push_back(z);
@@ -474,25 +479,33 @@ int classify_points(sid_pm_ctx *ctx)
     for (int64_t i = 0; i < n; ++i) {
         int wh = 0, ww = 0;
         if (!window_dims(c2fg[i], r2fg[i], border[i], s, rows2, cols2, wh, ww)) { shapes[0].idx.push_back((int32_t)i); continue; }
+        if (wh - s + 1 >= 65536 * 16 || ww - s + 1 >= 65536 * 64) return fail(SID_PM_ERR_UNSUPPORTED, "point %lld: search window %dx%d too large", (long long)i, wh, ww);
         int k = find_shape(wh, ww);
         if (k < 0) {
             Shape sh{wh, ww, 0, 4, 0, 0, 0, 0.0, {}};
-            const ShapeClass sc = shape_class(rp, rpp, wh, ww, s, K, flags, band8_ok, no_fixed_pitch);
-            if (sc.lds > sid::max_lds_bytes())
-                return fail(SID_PM_ERR_UNSUPPORTED, "point %lld: search window %dx%d needs %d bytes of LDS (> %d)",
-                            (long long)i, wh, ww, sc.lds, sid::max_lds_bytes());
+            ShapeClass sc{false, 4, 1, 0, 0};
+            if (small_ok) sc = shape_class(rp, rpp, wh, ww, s, K, flags, band8_ok, no_fixed_pitch);
+            // a window whose tables do not fit the LDS of one workgroup: the placement space is tiled over the device instead
+            if (!small_ok || sc.lds > sid::max_lds_bytes() || getenv("SID_PM_ALL_LARGE") != nullptr) { sh.large = true; sc = ShapeClass{false, 4, 1, 0, 0}; }
             sh.lds = sc.lds; sh.band = sc.band; sh.cls = sc.cls; sh.gs = sc.gs; sh.nat_pitch = sc.nat_pitch; sh.big = sc.big; sh.w3p = sc.w3_pitch;
             sh.work = (double)(wh - s + 1) * (double)(ww - s + 1);
             k = (int)shapes.size();
             shapes.push_back(sh);
         }
         Shape &sh = shapes[(size_t)k];
-        sh.idx.push_back((int32_t)i);
+        if (sh.large) ctx->large_idx.push_back((int32_t)i);
+        else sh.idx.push_back((int32_t)i);
         shape_of[(size_t)i] = (int32_t)k;
         macs += (double)K * sh.work * s * s;
         // window + bounding box of the rotated template + 5 inputs + outputs
         bytes += (double)wh * ww + 51.0 * 51.0 + 40.0 + 52.0;
         valid += 1;
+    }
+    if (!small_ok) {                                                  // no one-point kernel of this template side: the NaN rows are written by lw_write_nan
+        ctx->n_nan_idx = (int)shapes[0].idx.size();
+        if (int rc = ctx->d_nan_idx.reserve(std::max<size_t>(shapes[0].idx.size(), 1))) return rc;
+        if (ctx->n_nan_idx) HIP_TRY(hipMemcpy(ctx->d_nan_idx.p, shapes[0].idx.data(), sizeof(int32_t) * shapes[0].idx.size(), hipMemcpyHostToDevice));
+        shapes[0].idx.clear();
     }
     // launch order of the shapes: biggest footprints (fewest workgroups per CU) first, one launch per (class, band), longest first
     std::vector<int> ord;
@@ -625,8 +638,8 @@ int classify_points(sid_pm_ctx *ctx)
             HIP_TRY(hipMemcpyAsync(ctx->ring.p, init.data(), init.size() * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
             HIP_TRY(hipStreamSynchronize(ctx->stream));
         }
-        goff.resize((size_t)n);
-        for (int64_t p = 0; p < n; ++p) {
+        goff.resize(order.size());
+        for (int64_t p = 0; p < (int64_t)order.size(); ++p) {
             goff[(size_t)p] = (uint32_t)gsii_granules;
             gsii_granules += gran_shape[(size_t)shape_of[(size_t)order[(size_t)p]]];
         }
@@ -645,22 +658,24 @@ int classify_points(sid_pm_ctx *ctx)
     std::vector<sid::PointRec> recs;
     if (rp) {
         const double *c1v = ctx->h_c1.data(), *r1v = ctx->h_r1.data();
-        recs.resize((size_t)n);
-        for (int64_t p = 0; p < n; ++p) {
+        recs.resize(order.size());
+        for (int64_t p = 0; p < (int64_t)order.size(); ++p) {
             const int32_t i = order[(size_t)p];
             recs[(size_t)p] = sid::PointRec{i, goff[(size_t)p], c1v[i], r1v[i], c2fg[i], r2fg[i], border[i]};
         }
     }
-    if (n > 0) {
-        HIP_TRY(hipMemcpyAsync(ctx->d_order, order.data(), sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
-        if (rp) HIP_TRY(hipMemcpyAsync(ctx->d_goff.p, goff.data(), sizeof(uint32_t) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
-        if (rp) HIP_TRY(hipMemcpyAsync(ctx->d_rec.p, recs.data(), sizeof(sid::PointRec) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+    if (!order.empty()) {                                             // (the points of the large-window pipeline are in no launch)
+        HIP_TRY(hipMemcpyAsync(ctx->d_order, order.data(), sizeof(int32_t) * order.size(), hipMemcpyHostToDevice, ctx->stream));
+        if (rp) HIP_TRY(hipMemcpyAsync(ctx->d_goff.p, goff.data(), sizeof(uint32_t) * order.size(), hipMemcpyHostToDevice, ctx->stream));
+        if (rp) HIP_TRY(hipMemcpyAsync(ctx->d_rec.p, recs.data(), sizeof(sid::PointRec) * order.size(), hipMemcpyHostToDevice, ctx->stream));
         HIP_TRY(hipStreamSynchronize(ctx->stream));               // `order` and `goff` are locals
     }
     if (getenv("SID_PM_VERBOSE") != nullptr)                          // the launches of a step, one line each
         for (const Bucket &b : ctx->buckets)
             fprintf(stderr, "sid_pm: launch of %d points, %d B of LDS (%d per CU), band %d, window pitch %d, %d wavefronts per SIMD\n",
                     b.count, b.lds, std::min(b.occ, blocks_per_cu(b.lds)), b.band, b.pitch, b.occ);
+    if (getenv("SID_PM_VERBOSE") != nullptr && !ctx->large_idx.empty())
+        fprintf(stderr, "sid_pm: %zu points through the large-window pipeline (one point at a time, tiled over the device)\n", ctx->large_idx.size());
     ctx->cls_rows2 = rows2; ctx->cls_cols2 = cols2;
     const double img_bytes = (double)ctx->cur[0].rows * ctx->cur[0].cols + (double)rows2 * cols2;
     ctx->info[0] = (double)ctx->buckets.size();
@@ -669,6 +684,37 @@ int classify_points(sid_pm_ctx *ctx)
     ctx->info[3] = std::min(bytes, img_bytes + 92.0 * valid);
     ctx->info[4] = (double)lds_max;
     ctx->info[5] = 0;
+    return SID_PM_OK;
+}
+
+// The points of the resident set that are beyond the one-point kernels, one after the other through the large-window pipeline
+// (pm_large.hip): a stream of launches, nothing read back; results straight into the rows of the run's result arrays.
+int run_large_points(sid_pm_ctx *ctx, const sid::PMArgs &A)
+{
+    if (ctx->n_nan_idx) {
+        const int e = sid::lw_write_nan(ctx->d_nan_idx.p, ctx->n_nan_idx, A.out, A.out_ij, ctx->stream);
+        if (e) return fail(SID_PM_ERR_HIP, "large-window pipeline: %s", hipGetErrorString((hipError_t)e));
+    }
+    for (const int32_t i : ctx->large_idx) {
+        int wh = 0, ww = 0;
+        const double c2 = ctx->h_c2fg[(size_t)i], r2 = ctx->h_r2fg[(size_t)i], b = ctx->h_border[(size_t)i];
+        if (!window_dims(c2, r2, b, ctx->img_size, ctx->cur[1].rows, ctx->cur[1].cols, wh, ww)) continue;   // (cannot happen: classified with this pair)
+        const int hws = (int)((double)ctx->img_size / 2.0);
+        sid::LargeCall c;
+        c.img1 = A.img1; c.rows1 = A.rows1; c.cols1 = A.cols1; c.stride1 = A.stride1;
+        c.img2 = A.img2; c.stride2 = A.stride2;
+        c.win_r0 = (int64_t)(r2 - hws - b); c.win_c0 = (int64_t)(c2 - hws - b); c.wh = wh; c.ww = ww;
+        c.c1 = ctx->h_c1[(size_t)i]; c.r1 = ctx->h_r1[(size_t)i];
+        c.s = ctx->img_size; c.K = ctx->n_angles; c.flags = ctx->flags;
+        c.d_rot = ctx->d_rot; c.d_angles = ctx->d_angles;
+        c.add_c = c2; c.add_r = r2;
+        memcpy(c.gauss_w, A.gauss_w, sizeof c.gauss_w);
+        c.out5 = A.out + 5 * (size_t)i; c.ij3 = A.out_ij ? A.out_ij + 3 * (size_t)i : nullptr;
+        const int e = sid::lw_run(c, ctx->lw, ctx->stream);
+        if (e == -1) return fail(SID_PM_ERR_NOMEM, "point %d: the large-window pipeline needs %.2f GB of device scratch for its %dx%d window (%d angles)",
+                                 (int)i, (double)sid::lw_scratch_bytes(wh, ww, c.s, c.K, c.flags) * 1e-9, wh, ww, c.K);
+        if (e) return fail(SID_PM_ERR_HIP, "large-window pipeline: %s", hipGetErrorString((hipError_t)e));
+    }
     return SID_PM_OK;
 }
 
@@ -754,6 +800,7 @@ SID_EXPORT void sid_pm_destroy(sid_pm_ctx *ctx)
     if (ctx->fork_ev) (void)hipEventDestroy(ctx->fork_ev);
     for (auto &pair : ctx->own) for (auto &b : pair) b.release();
     ctx->arena.release();
+    sid::lw_workspace_release(ctx->lw); ctx->d_nan_idx.release(); ctx->lw_small.release();
     ctx->out.release(); ctx->out_ij.release(); ctx->dbg_err.release(); ctx->gsii.release(); ctx->d_goff.release(); ctx->d_rec.release(); ctx->ring.release(); ctx->pool.release();
     if (ctx->h_refused) (void)hipHostFree(ctx->h_refused);
     delete ctx;
@@ -837,12 +884,13 @@ SID_EXPORT int sid_pm_set_points(sid_pm_ctx *ctx, const double *c1, const double
     Guard g(ctx->device);
     const int s = img_size, K = n_angles;
 
+    (void)alpha0;
     std::vector<double> rotv;
-    make_rot(angles, K, alpha0, s, rot, rotv);
+    if (int rc = make_rot(K, rot, rotv)) return rc;
     std::vector<uint16_t> sampv;
     int nflag = 0;
     // (rot_order = 1: no offset table - every template sample is interpolated in float64 by the general sampler)
-    if (!getenv("SID_PM_NO_SAMP_TABLE") && !(flags & SID_PM_ROT_ORDER1)) nflag = make_samp(rotv, K, s, sampv);
+    if (!getenv("SID_PM_NO_SAMP_TABLE") && !(flags & SID_PM_ROT_ORDER1) && sid::mfma_img_size_supported(s)) nflag = make_samp(rotv, K, s, sampv);
     std::vector<uint32_t> samp2v;
     // (measured +2 % on the 15-angle step - fifteen table loads per angle instead of five, a uniform branch per chunk - although
     // it executes a third fewer VALU instructions in the template phase: built on request only, SID_PM_SAMP2=1)
@@ -972,6 +1020,7 @@ SID_EXPORT int sid_pm_run(sid_pm_ctx *ctx)
         }
     }
     if (int rc = join()) return rc;
+    if (int rc = run_large_points(ctx, A)) return rc;
     if (ctx->cur_slot >= 0) {
         HIP_TRY(hipEventRecord(ctx->slot_done[ctx->cur_slot], ctx->stream));
         ctx->done_rec[ctx->cur_slot] = true;
@@ -1105,6 +1154,124 @@ SID_EXPORT int sid_pm_batch(const uint8_t *img1, int64_t rows1, int64_t cols1, i
     return rc;
 }
 
+// ---- rotate_and_match / get_template / get_hessian as calls of their own (reference pmlib.py:117-174, :89-115, :36-59) ----
+SID_EXPORT int sid_pm_rotate_and_match(sid_pm_ctx *ctx, double c1, double r1, int img_size,
+                                       int64_t win_row0, int64_t win_col0, int64_t win_rows, int64_t win_cols,
+                                       double alpha0, const double *angles, const double *rot, int n_angles, uint32_t flags,
+                                       double out5[5], int32_t ij3[3], float *ccm, int64_t ccm_cap, uint8_t *best_template)
+{
+    (void)alpha0;
+    if (!ctx || !out5) return fail(SID_PM_ERR_ARG, "null argument");
+    if (!ctx->have_pair) return fail(SID_PM_ERR_STATE, "rotate_and_match needs an image pair (upload_pair / bind_pair first)");
+    if (int rc = check_sweep(img_size, angles, n_angles, flags)) return rc;
+    if (!rot) return fail(SID_PM_ERR_ARG, "rot is required: the rotation terms as the caller's NumPy computed them (pmlib.py:105-110)");
+    const int s = img_size, K = n_angles;
+    if (win_row0 < 0 || win_col0 < 0 || win_rows < 1 || win_cols < 1 || win_row0 + win_rows > ctx->cur[1].rows || win_col0 + win_cols > ctx->cur[1].cols)
+        return fail(SID_PM_ERR_ARG, "the window does not lie inside image 2");
+    // cv2.matchTemplate needs a window at least as large as the template, np.gradient two values along each axis (pmlib.py:156, :51)
+    if (win_rows - s + 1 < 2 || win_cols - s + 1 < 2)
+        return fail(SID_PM_ERR_ARG, "window %lldx%lld: fewer than two placements of a %d px template along an axis", (long long)win_rows, (long long)win_cols, s);
+    if (win_rows > 0x7fffffff || win_cols > 0x7fffffff || win_rows - s + 1 >= 65536 * 16 || win_cols - s + 1 >= 65536ll * 64)
+        return fail(SID_PM_ERR_UNSUPPORTED, "window too large");
+    const int64_t np = (win_rows - s + 1) * (win_cols - s + 1);
+    if (np >= 0xffffffffll) return fail(SID_PM_ERR_UNSUPPORTED, "more than 2^32 placements");
+    if (ccm && ccm_cap < np) return fail(SID_PM_ERR_ARG, "ccm capacity %lld < %lld placements", (long long)ccm_cap, (long long)np);
+    Guard g(ctx->device);
+    // small device block: [K angles | 4K rotation terms | 5 results | 3 int32]
+    if (int rc = ctx->lw_small.reserve((size_t)K * 5 + 8)) return rc;
+    std::vector<double> host((size_t)K * 5);
+    memcpy(host.data(), angles, sizeof(double) * (size_t)K);
+    memcpy(host.data() + K, rot, sizeof(double) * 4 * (size_t)K);
+    HIP_TRY(hipMemcpyAsync(ctx->lw_small.p, host.data(), sizeof(double) * host.size(), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));                       // (`host` is a local)
+    if (ctx->cur_slot >= 0 && ctx->ready_rec[ctx->cur_slot]) HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->slot_ready[ctx->cur_slot], 0));
+    sid::LargeCall c;
+    c.img1 = ctx->cur[0].ptr; c.rows1 = ctx->cur[0].rows; c.cols1 = ctx->cur[0].cols; c.stride1 = ctx->cur[0].stride;
+    c.img2 = ctx->cur[1].ptr; c.stride2 = ctx->cur[1].stride;
+    c.win_r0 = win_row0; c.win_c0 = win_col0; c.wh = (int)win_rows; c.ww = (int)win_cols;
+    c.c1 = c1; c.r1 = r1; c.s = s; c.K = K; c.flags = flags;
+    c.d_angles = ctx->lw_small.p; c.d_rot = ctx->lw_small.p + K;
+    c.add_c = 0.0; c.add_r = 0.0;
+    gauss_taps(c.gauss_w);
+    c.out5 = ctx->lw_small.p + 5 * (size_t)K;
+    c.ij3 = reinterpret_cast<int32_t *>(ctx->lw_small.p + 5 * (size_t)K + 5);
+    const int e = sid::lw_run(c, ctx->lw, ctx->stream);
+    if (e == -1) return fail(SID_PM_ERR_NOMEM, "rotate_and_match needs %.2f GB of device scratch for a %dx%d window and %d angles",
+                             (double)sid::lw_scratch_bytes(c.wh, c.ww, s, K, flags) * 1e-9, c.wh, c.ww, K);
+    if (e) return fail(SID_PM_ERR_HIP, "large-window pipeline: %s", hipGetErrorString((hipError_t)e));
+    if (ctx->cur_slot >= 0) { HIP_TRY(hipEventRecord(ctx->slot_done[ctx->cur_slot], ctx->stream)); ctx->done_rec[ctx->cur_slot] = true; }
+    int32_t ij[3] = {-1, -1, -1};
+    HIP_TRY(hipMemcpyAsync(out5, c.out5, sizeof(double) * 5, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(ij, c.ij3, sizeof ij, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (ij3) memcpy(ij3, ij, sizeof ij);
+    if (ij[2] >= 0) {                                                 // (a NaN point has no matrix and no template: pmlib.py:152-154)
+        if (ccm) HIP_TRY(hipMemcpy(ccm, sid::lw_ncc_matrix(ctx->lw, c.wh, c.ww, s, ij[2]), sizeof(float) * (size_t)np, hipMemcpyDeviceToHost));
+        if (best_template) HIP_TRY(hipMemcpy(best_template, sid::lw_template(ctx->lw, s, ij[2]), (size_t)s * s, hipMemcpyDeviceToHost));
+    }
+    return SID_PM_OK;
+}
+
+SID_EXPORT int sid_pm_get_template(int device, const uint8_t *img, int64_t rows, int64_t cols, int64_t stride, double c, double r,
+                                   const double rot4[4], int img_size, int rot_order, uint8_t *out)
+{
+    if (!img || !rot4 || !out || rows < 1 || cols < 1 || stride < cols) return fail(SID_PM_ERR_ARG, "bad argument");
+    if (img_size < 1 || img_size > 4096) return fail(SID_PM_ERR_UNSUPPORTED, "img_size=%d", img_size);
+    if (rot_order != 0 && rot_order != 1) return fail(SID_PM_ERR_UNSUPPORTED, "rot_order=%d: 0 (nearest) and 1 (bilinear) are implemented", rot_order);
+    if (!(fabs(c) < 1e15 && fabs(r) < 1e15)) return fail(SID_PM_ERR_ARG, "non-finite centre");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return fail(SID_PM_ERR_NODEVICE, "no such device");
+    Guard g(device);
+    const int s = img_size;
+    // only the part of the image the samples can touch travels to the device: the samples lie within hypot(s, s) + |tcT| of (r, c)
+    const double reach = 1.5 * (double)s + fabs(rot4[2]) + fabs(rot4[3]) + 4.0;
+    const int64_t row0 = std::max<int64_t>(0, (int64_t)floor(r - reach)), row1 = std::min<int64_t>(rows, (int64_t)ceil(r + reach) + 1);
+    const int64_t col0 = std::max<int64_t>(0, (int64_t)floor(c - reach)), col1 = std::min<int64_t>(cols, (int64_t)ceil(c + reach) + 1);
+    DevBuf<uint8_t> dimg, dout;
+    DevBuf<double> drot;
+    int rc = SID_PM_OK;
+    const int64_t nr = std::max<int64_t>(row1 - row0, 0), nc = std::max<int64_t>(col1 - col0, 0);
+    if ((rc = dimg.reserve((size_t)std::max<int64_t>(nr * nc, 1))) || (rc = dout.reserve((size_t)s * s)) || (rc = drot.reserve(4))) { dimg.release(); dout.release(); drot.release(); return rc; }
+    hipError_t e = hipSuccess;
+    if (nr > 0 && nc > 0) e = hipMemcpy2D(dimg.p, (size_t)nc, img + row0 * stride + col0, (size_t)stride, (size_t)nc, (size_t)nr, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(drot.p, rot4, sizeof(double) * 4, hipMemcpyHostToDevice);
+    // (a template wholly outside the image samples nothing: every coordinate fails the bounds test and yields 0)
+    if (e == hipSuccess) e = (hipError_t)sid::lw_get_template(dimg.p, nc > 0 ? nc : 1, row0, col0, nr, nc, rows, cols, c, r, drot.p, s, rot_order, dout.p, nullptr);
+    if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
+    if (e == hipSuccess) e = hipMemcpy(out, dout.p, (size_t)s * s, hipMemcpyDeviceToHost);
+    dimg.release(); dout.release(); drot.release();
+    if (e != hipSuccess) return fail(SID_PM_ERR_HIP, "get_template: %s", hipGetErrorString(e));
+    return SID_PM_OK;
+}
+
+SID_EXPORT int sid_pm_get_hessian(int device, const float *ccm, int64_t rows, int64_t cols, uint32_t flags, float *hes)
+{
+    if (!ccm || !hes) return fail(SID_PM_ERR_ARG, "null argument");
+    if (flags & ~(SID_PM_HES_NORM | SID_PM_HES_SMTH)) return fail(SID_PM_ERR_ARG, "get_hessian takes SID_PM_HES_NORM and SID_PM_HES_SMTH");
+    // np.gradient needs two values along each axis (pmlib.py:51)
+    if (rows < 2 || cols < 2 || rows * cols >= 0xffffffffll) return fail(SID_PM_ERR_ARG, "matrix %lldx%lld: at least 2x2, fewer than 2^32 values", (long long)rows, (long long)cols);
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return fail(SID_PM_ERR_NODEVICE, "no such device");
+    Guard g(device);
+    const size_t n = (size_t)(rows * cols);
+    DevBuf<float> din, dout;
+    sid::LwWorkspace W;
+    int rc = SID_PM_OK;
+    if ((rc = din.reserve(n)) || (rc = dout.reserve(n))) { din.release(); dout.release(); return rc; }
+    double gw[5];
+    gauss_taps(gw);
+    hipError_t e = hipMemcpy(din.p, ccm, sizeof(float) * n, hipMemcpyHostToDevice);
+    int le = 0;
+    if (e == hipSuccess) le = sid::lw_get_hessian(din.p, (int)rows, (int)cols, flags, gw, dout.p, W, nullptr);
+    if (le == 0 && e == hipSuccess) e = hipStreamSynchronize(nullptr);
+    if (le == 0 && e == hipSuccess) e = hipMemcpy(hes, dout.p, sizeof(float) * n, hipMemcpyDeviceToHost);
+    din.release(); dout.release(); sid::lw_workspace_release(W);
+    if (le == -1) return fail(SID_PM_ERR_NOMEM, "get_hessian: device scratch");
+    if (le) return fail(SID_PM_ERR_HIP, "get_hessian: %s", hipGetErrorString((hipError_t)le));
+    if (e != hipSuccess) return fail(SID_PM_ERR_HIP, "get_hessian: %s", hipGetErrorString(e));
+    return SID_PM_OK;
+}
+
 SID_EXPORT int sid_pm_debug_point(sid_pm_ctx *ctx, double c1, double r1, double c2fg, double r2fg,
                                   double border, int img_size, double alpha0, const double *angles,
                                   const double *rot, int n_angles, uint32_t flags,
@@ -1122,8 +1289,10 @@ SID_EXPORT int sid_pm_debug_point(sid_pm_ctx *ctx, double c1, double r1, double 
     if (window_dims(c2fg, r2fg, border, s, ctx->cur[1].rows, ctx->cur[1].cols, wh, ww))
         lds = lds_need(rp, rpp, wh, ww, s, K, flags);
     if (lds > sid::max_lds_bytes()) return fail(SID_PM_ERR_UNSUPPORTED, "search window too large for LDS");
+    (void)alpha0;
+    if (!sid::mfma_img_size_supported(s)) return fail(SID_PM_ERR_UNSUPPORTED, "debug_point: template sides 2..64 (sid_pm_rotate_and_match returns the matrix and the template of any size)");
     std::vector<double> rotv;
-    make_rot(angles, K, alpha0, s, rot, rotv);
+    if (int rc = make_rot(K, rot, rotv)) return rc;
 
     DevBuf<double> dv, dang, drot, dout;
     DevBuf<int32_t> dord, dij, dshape;

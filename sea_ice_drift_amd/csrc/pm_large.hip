@@ -1,0 +1,726 @@
+// pm_large.hip - rotate_and_match (reference pmlib.py:117-174) for search windows and template sides BEYOND the launch classes
+// of the one-workgroup-per-point kernels (pm_kernel_mfma.hip / pm_kernel_rp.inc keep a point's whole state in LDS: windows up
+// to 257 px, template sides up to 64).  Here the placement space of ONE point is tiled over the whole device:
+//
+//   lw_templates   K rotated templates (scipy order 0 / 1 arithmetic, pmlib.py:89-115) -> uint8 [K][s][s], their sums, the
+//                  zero-pixel flag (pmlib.py:152-154) and the int8 operand table of the matrix instructions
+//   lw_rowsums /   exact sum w' and sum w'^2 of every placement (w' = w - 128): running sums along rows, then down columns
+//   lw_colsums
+//   lw_corr        exact sum w' t' of every placement and angle on v_mfma_i32_16x16x64_i8 - M = 16 angles, N = 16 placements,
+//                  K = 64 template columns of one template row; a workgroup owns a tile of 16 x 64 placements staged through
+//                  LDS, a wavefront a band of 4 output rows fed by one window fragment per row (the band trick of the
+//                  one-point kernels) - normalised at once into the float32 NCC value of the specification (DESIGN.md
+//                  section 3; pmlib.py:156) and stored: the NCC matrices of ALL candidate angles live in global memory.
+//                  Arg-max per angle: a 64-bit atomic max on (value key, ~flat index) - np.argmax's first maximum.
+//   lw_pick        angle pick with the reference's strict > (pmlib.py:158-165)
+//   lw_smooth /    get_hessian (pmlib.py:36-59) over the winning matrix: optional sigma-1 Gaussian, np.gradient twice, hypot;
+//   lw_hessian     exact median by radix select over the global matrix (lw_hist / lw_hist_scan), std from float64 sums
+//   lw_finish      displacement (pmlib.py:168-169), mcc_norm (:171-172), the five results
+//
+// Nothing is read back by the host between the kernels: the state of the point (LwState) lives in device memory, so a run of
+// large points is a stream of launches.  HBM-bound except lw_corr; sized for 288 GB (K x placements x 4 B of NCC values).
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <string.h>
+#include <algorithm>
+#include <mutex>
+#include <set>
+#include <utility>
+
+#include "pm_kernel.h"
+#include "pm_large.h"
+
+namespace sid {
+
+namespace {
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef uint32_t u32;
+typedef unsigned long long u64;
+
+constexpr int kTH = 16, kTW = 64;          // placements per workgroup tile of lw_corr (rows x columns)
+
+struct LwState {
+    u64 best[kMaxAngles];                  // per angle: (key of the maximum << 32) | (0xffffffff - flat index of its first occurrence)
+    double sT[kMaxAngles], rT[kMaxAngles]; // sum t' and 1 / sqrt(N sum t'^2 - (sum t')^2) per template
+    int32_t constT[kMaxAngles];            // dT == 0: the NCC matrix is all ones (OpenCV)
+    int32_t zero;                          // a template holds a 0 pixel: NaN x 7 (pmlib.py:152-154)
+    int32_t valid, kbest, iy, ix;
+    float best_r;
+    u32 sel_prefix[2][2], sel_rank[2][2];  // radix select of two order statistics (the middles) of [0] the Hessian magnitudes, [1] the NCC matrix
+    u32 hist[2][2][256];
+    double sums[2][2];                     // sum x, sum x^2 of the same two matrices
+};
+
+struct LwParams {
+    const uint8_t *img1; long long rows1, cols1, stride1, row0, col0;   // image 1 (row0 / col0: origin of the part that is on the device)
+    const uint8_t *win; long long wstride;                             // first pixel of the window on image 2
+    int wh, ww, rh, rw, s, K;
+    u32 flags;
+    double c1, r1;
+    const double *rot, *angles;
+    double add_c, add_r;
+    double gw[5];
+    LwState *st;
+    uint8_t *tmpl; uint8_t *opA;
+    int32_t *hs1; u32 *hs2; int32_t *si; u32 *sii;
+    float *ncc, *hes, *tmpa, *tmpb;
+    double *partial;
+    double *out5; int32_t *ij3;
+};
+
+__device__ __forceinline__ u32 f2key(float f) { u32 b = __float_as_uint(f); return (b & 0x80000000u) ? ~b : (b | 0x80000000u); }
+__device__ __forceinline__ float key2f(u32 k) { u32 b = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k; return __uint_as_float(b); }
+
+// ---------------------------------------------------------------------------------------------- templates
+// One sample of get_template: scipy's NI_GeometricTransform coordinates (matrix = transform.T, float64, the reference's operation
+// order), order 0: floor(x + 0.5); order 1: the four taps in float64, uint8 output rounding (oracle: sid_oracle_get_template /
+// sid_oracle_get_template1; fixtures G1 / G1b).
+__device__ __forceinline__ int lw_sample(const uint8_t *img, long long stride, long long row0, long long col0, long long rows, long long cols,
+                                         double c, double r, const double *rot4, int i, int j, bool lin)
+{
+    const double cosa = rot4[0], sina = rot4[1];
+    const double off0 = r - rot4[2], off1 = c - rot4[3];
+    double rr = 0.0 + (double)i * cosa;
+    rr = rr + (double)j * sina;
+    rr = rr + off0;
+    double cc = 0.0 + (double)i * (-sina);
+    cc = cc + (double)j * cosa;
+    cc = cc + off1;
+    if (!(rr >= 0.0 && rr <= (double)(rows - 1) && cc >= 0.0 && cc <= (double)(cols - 1))) return 0;
+    if (lin) {
+        const double fr = floor(rr), fc = floor(cc);
+        const double yr = rr - fr, yc = cc - fc;
+        const double w0r = 1.0 - yr, w0c = 1.0 - yc;
+        const long long r0 = (long long)fr, c0 = (long long)fc;
+        long long r1 = r0 + 1, c1 = c0 + 1;                         // the tap behind the last sample is mirrored (its weight is 0)
+        if (r1 >= rows) r1 = 2 * rows - 2 - r1;
+        if (c1 >= cols) c1 = 2 * cols - 2 - c1;
+        if (r1 < 0) r1 = 0;
+        if (c1 < 0) c1 = 0;
+        const uint8_t *p0 = img + (r0 - row0) * stride - col0, *p1 = img + (r1 - row0) * stride - col0;
+        double t = 0.0;
+        t = t + ((double)p0[c0] * w0r) * w0c;
+        t = t + ((double)p0[c1] * w0r) * yc;
+        t = t + ((double)p1[c0] * yr) * w0c;
+        t = t + ((double)p1[c1] * yr) * yc;
+        t = t > 0.0 ? t + 0.5 : 0.0;
+        t = t > 255.0 ? 255.0 : t;
+        return (int)t;
+    }
+    const long long ri = (long long)floor(rr + 0.5), ci = (long long)floor(cc + 0.5);
+    return img[(ri - row0) * stride + (ci - col0)];
+}
+
+__global__ __launch_bounds__(256) void lw_templates_kernel(const LwParams P)
+{
+    __shared__ long long red[256][2];
+    __shared__ int redmin[256];
+    const int k = blockIdx.x, tid = threadIdx.x, s = P.s;
+    const bool lin = (P.flags & 8u) != 0u;
+    uint8_t *T = P.tmpl + (size_t)k * s * s;
+    long long st = 0, stt = 0;
+    int vmin = 255;
+    for (int idx = tid; idx < s * s; idx += 256) {
+        const int i = idx / s, j = idx - i * s;
+        const int v = lw_sample(P.img1, P.stride1, P.row0, P.col0, P.rows1, P.cols1, P.c1, P.r1, P.rot + 4 * k, i, j, lin);
+        T[idx] = (uint8_t)v;
+        const long long tp = v - 128;
+        st += tp; stt += tp * tp;
+        vmin = v < vmin ? v : vmin;
+    }
+    red[tid][0] = st; red[tid][1] = stt; redmin[tid] = vmin;
+    __syncthreads();
+    for (int h = 128; h > 0; h >>= 1) {
+        if (tid < h) {
+            red[tid][0] += red[tid + h][0]; red[tid][1] += red[tid + h][1];
+            redmin[tid] = redmin[tid + h] < redmin[tid] ? redmin[tid + h] : redmin[tid];
+        }
+        __syncthreads();
+    }
+    if (tid == 0 && P.st) {
+        const long long n = (long long)s * s, dT = n * red[0][1] - red[0][0] * red[0][0];
+        P.st->sT[k] = (double)red[0][0];
+        P.st->constT[k] = dT == 0 ? 1 : 0;
+        P.st->rT[k] = dT == 0 ? 0.0 : 1.0 / sqrt((double)dT);
+        if (redmin[0] == 0) atomicOr(&P.st->zero, 1);
+    }
+    if (!P.opA) return;
+    // operand table of lw_corr: [group of 16 angles][template row -3 .. s + 2][block of 64 columns][k-group of 16 columns]
+    // [angle slot][16 B] - a wavefront's A operand of one (row, block) is 1 KB contiguous, lane l at l * 16.  Rows outside the
+    // template, columns beyond s and the slots of absent angles are zero (the table is cleared before the launch).
+    const int nJB = (s + 63) >> 6, grp = k >> 4, slot = k & 15, nrows = s + 6;
+    for (int e = tid; e < s * nJB * 4; e += 256) {
+        const int i = e / (nJB * 4), rem = e - i * (nJB * 4), jb = rem >> 2, kg = rem & 3;
+        u32 w[4];
+        for (int q = 0; q < 4; ++q) {
+            u32 x = 0;
+            for (int b = 0; b < 4; ++b) {
+                const int col = 64 * jb + 16 * kg + 4 * q + b;
+                const u32 byte = col < s ? (u32)((int)T[i * s + col] - 128) & 0xffu : 0u;
+                x |= byte << (8 * b);
+            }
+            w[q] = x;
+        }
+        uint4 *dst = reinterpret_cast<uint4 *>(P.opA + ((((size_t)grp * nrows + (size_t)(i + 3)) * nJB + jb) * 4 + kg) * 256 + slot * 16);
+        *dst = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- box sums
+// running sums along the window rows: hs1[rho][x] = sum_{j < s} w'[rho][x + j], hs2 likewise of w'^2.  A thread owns four
+// consecutive x of one row: one full sum, three slides.
+__global__ __launch_bounds__(256) void lw_rowsums_kernel(const LwParams P)
+{
+    const int rho = blockIdx.y, x0 = (blockIdx.x * 256 + threadIdx.x) * 4;
+    if (x0 >= P.rw) return;
+    const uint8_t *row = P.win + (long long)rho * P.wstride;
+    int a = 0; u32 b = 0;
+    for (int j = 0; j < P.s; ++j) { const int v = (int)row[x0 + j] - 128; a += v; b += (u32)(v * v); }
+    const size_t o = (size_t)rho * P.rw + x0;
+    P.hs1[o] = a; P.hs2[o] = b;
+    for (int d = 1; d < 4 && x0 + d < P.rw; ++d) {
+        const int vo = (int)row[x0 + d - 1] - 128, vn = (int)row[x0 + d - 1 + P.s] - 128;
+        a += vn - vo; b += (u32)(vn * vn) - (u32)(vo * vo);
+        P.hs1[o + d] = a; P.hs2[o + d] = b;
+    }
+}
+
+// ... then down the columns: si[y][x] = sum_{i < s} hs1[y + i][x].  A thread owns 32 consecutive y of one column (coalesced in x).
+__global__ __launch_bounds__(256) void lw_colsums_kernel(const LwParams P)
+{
+    const int x = blockIdx.x * 256 + threadIdx.x, y0 = blockIdx.y * 32;
+    if (x >= P.rw) return;
+    const size_t rw = (size_t)P.rw;
+    int a = 0; u32 b = 0;
+    for (int i = 0; i < P.s; ++i) { a += P.hs1[(size_t)(y0 + i) * rw + x]; b += P.hs2[(size_t)(y0 + i) * rw + x]; }
+    P.si[(size_t)y0 * rw + x] = a; P.sii[(size_t)y0 * rw + x] = b;
+    for (int d = 1; d < 32 && y0 + d < P.rh; ++d) {
+        a += P.hs1[(size_t)(y0 + d - 1 + P.s) * rw + x] - P.hs1[(size_t)(y0 + d - 1) * rw + x];
+        b += P.hs2[(size_t)(y0 + d - 1 + P.s) * rw + x] - P.hs2[(size_t)(y0 + d - 1) * rw + x];
+        P.si[(size_t)(y0 + d) * rw + x] = a; P.sii[(size_t)(y0 + d) * rw + x] = b;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- correlation + NCC
+// The specification's normalisation (oracle match_template_core): exact integers, then IEEE double with
+// one rounding per operation (this file is compiled with -ffp-contract=off like the others).
+__device__ __forceinline__ float lw_ncc(int acc, double swd, double dI, double rI, bool lowvar, double nd, double sT, double rT, bool constT)
+{
+    if (constT) return 1.0f;
+    if (lowvar) return 0.0f;
+    const double numer = nd * (double)acc - swd * sT;                 // exact
+    double q = numer * rI;
+    q = q * rT;
+    const double aq = fabs(q);
+    return aq < 1.0 ? (float)q : (aq < 1.125 ? (q > 0.0 ? 1.0f : -1.0f) : 0.0f);
+}
+
+__host__ __device__ inline int lw_pitch(int s) { return kTW + 64 * ((s + 63) >> 6); }
+
+__global__ __launch_bounds__(256) void lw_corr_kernel(const LwParams P)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int s = P.s, nJB = (s + 63) >> 6, pitch = lw_pitch(s), rowsT = kTH + s - 1;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, n = lane & 15, kg = lane >> 4;
+    const int x0 = blockIdx.x * kTW, y0 = blockIdx.y * kTH, grp = blockIdx.z;
+    // window tile -> LDS as re-centred int8; outside the window: 0 (those products belong to placements that are not stored)
+    for (int e = tid; e < rowsT * (pitch >> 2); e += 256) {
+        const int tr = e / (pitch >> 2), tc = (e - tr * (pitch >> 2)) << 2;
+        const int wy = y0 + tr;
+        u32 x = 0;
+        if (wy < P.wh) {
+            const uint8_t *row = P.win + (long long)wy * P.wstride;
+            for (int b = 0; b < 4; ++b) {
+                const int wx = x0 + tc + b;
+                const u32 byte = wx < P.ww ? (u32)((int)row[wx] - 128) & 0xffu : 0u;
+                x |= byte << (8 * b);
+            }
+        }
+        *reinterpret_cast<u32 *>(smem + tr * pitch + tc) = x;
+    }
+    __syncthreads();
+    v4i acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = v4i{0, 0, 0, 0};
+    const int nrows = s + 6;
+    const uint8_t *opA = P.opA + (size_t)grp * nrows * nJB * 1024 + (size_t)lane * 16;
+    const u32 sh = (u32)(n & 3);
+    const uint8_t *bbase = smem + (4 * wv) * pitch + 16 * kg + (n & ~3);
+    for (int jb = 0; jb < nJB; ++jb) {
+        v4i a1 = v4i{0, 0, 0, 0}, a2 = a1, a3 = a1;                   // template rows rho - 1, rho - 2, rho - 3
+        for (int rho = 0; rho < s + 3; ++rho) {                       // window row of the band; output row yb pairs it with template row rho - yb
+            const v4i a0 = *reinterpret_cast<const v4i *>(opA + ((size_t)(rho + 3) * nJB + jb) * 1024);
+            const uint8_t *brow = bbase + rho * pitch + 64 * jb;
+#pragma unroll
+            for (int xt = 0; xt < 4; ++xt) {
+                const u32 *q = reinterpret_cast<const u32 *>(brow + 16 * xt);
+                const u32 r0 = q[0], r1 = q[1], r2 = q[2], r3 = q[3], r4 = q[4];
+                v4i b;
+                b[0] = (int)__builtin_amdgcn_alignbyte(r1, r0, sh);
+                b[1] = (int)__builtin_amdgcn_alignbyte(r2, r1, sh);
+                b[2] = (int)__builtin_amdgcn_alignbyte(r3, r2, sh);
+                b[3] = (int)__builtin_amdgcn_alignbyte(r4, r3, sh);
+                acc[0][xt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0, b, acc[0][xt], 0, 0, 0);
+                acc[1][xt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1, b, acc[1][xt], 0, 0, 0);
+                acc[2][xt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a2, b, acc[2][xt], 0, 0, 0);
+                acc[3][xt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a3, b, acc[3][xt], 0, 0, 0);
+            }
+            a3 = a2; a2 = a1; a1 = a0;
+        }
+    }
+    // accumulator register r of lane (n, kg) = angle slot 4 kg + r at placement column n of its tile
+    const double nd = (double)s * (double)s;
+    const size_t np = (size_t)P.rh * P.rw;
+    double sT[4], rT[4]; bool cT[4], have[4];
+    int kk[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        kk[r] = grp * 16 + 4 * kg + r;
+        have[r] = kk[r] < P.K;
+        const int kq = have[r] ? kk[r] : 0;
+        sT[r] = P.st->sT[kq]; rT[r] = P.st->rT[kq]; cT[r] = P.st->constT[kq] != 0;
+    }
+    u64 best[4] = {0ull, 0ull, 0ull, 0ull};
+#pragma unroll
+    for (int yb = 0; yb < 4; ++yb) {
+        const int y = y0 + 4 * wv + yb;
+#pragma unroll
+        for (int xt = 0; xt < 4; ++xt) {
+            const int x = x0 + 16 * xt + n;
+            if (y < P.rh && x < P.rw) {
+                const size_t p = (size_t)y * P.rw + x;
+                const double swd = (double)P.si[p], siid = (double)P.sii[p];
+                const double dI = nd * siid - swd * swd;                           // exact
+                const double s2 = siid + 256.0 * swd + 16384.0 * nd;               // sum w^2 in the uint8 domain
+                const bool lowvar = (2.0 * dI <= nd) && (dI * 8388608.0 <= 10.0 * nd * s2);
+                const double rI = 1.0 / sqrt(dI);
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (have[r]) {
+                        const float v = lw_ncc(acc[yb][xt][r], swd, dI, rI, lowvar, nd, sT[r], rT[r], cT[r]);
+                        P.ncc[(size_t)kk[r] * np + p] = v;
+                        const u64 key = ((u64)f2key(v) << 32) | (u64)(0xffffffffu - (u32)p);
+                        best[r] = key > best[r] ? key : best[r];
+                    }
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        u64 b = best[r];
+        for (int m = 1; m < 16; m <<= 1) {
+            const u64 o = (u64)__shfl_xor((unsigned long long)b, m, 64);
+            b = o > b ? o : b;
+        }
+        if (n == 0 && have[r] && b) atomicMax(&P.st->best[kk[r]], b);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- angle pick
+__global__ void lw_pick_kernel(const LwParams P)
+{
+    if (threadIdx.x != 0) return;
+    LwState *S = P.st;
+    const u32 n = (u32)((size_t)P.rh * P.rw);
+    for (int w = 0; w < 2; ++w) {                                     // the two middles (equal for an odd count): np.median
+        S->sel_prefix[w][0] = S->sel_prefix[w][1] = 0u;
+        S->sel_rank[w][0] = (n & 1u) ? n / 2u : n / 2u - 1u;
+        S->sel_rank[w][1] = n / 2u;
+    }
+    if (S->zero) {                                                    // pmlib.py:152-154
+        S->valid = 0; S->kbest = 0;
+        const double nan = __longlong_as_double(0x7ff8000000000000ll);
+        for (int q = 0; q < 5; ++q) P.out5[q] = nan;
+        if (P.ij3) { P.ij3[0] = P.ij3[1] = P.ij3[2] = -1; }
+        return;
+    }
+    float bestv = -INFINITY;
+    int bk = 0; u32 bidx = 0;
+    for (int k = 0; k < P.K; ++k) {
+        const u64 key = S->best[k];
+        const float v = key2f((u32)(key >> 32));
+        if (v > bestv) { bestv = v; bk = k; bidx = 0xffffffffu - (u32)key; }   // strict: the first angle keeps a tie (pmlib.py:160)
+    }
+    S->valid = 1; S->kbest = bk; S->best_r = bestv;
+    S->iy = (int)(bidx / (u32)P.rw); S->ix = (int)(bidx % (u32)P.rw);
+}
+
+// ---------------------------------------------------------------------------------------------- get_hessian
+// scipy.ndimage.gaussian_filter(ccm, 1) (pmlib.py:46-47): per axis a radius-4 kernel in double, 'reflect' boundary, float32
+// after each axis (oracle gaussian_smooth_sigma1: centre first, then the pairs from the outermost in).
+__device__ __forceinline__ int lw_reflect(int q, int n)
+{
+    while (q < 0 || q >= n) { if (q < 0) q = -q - 1; if (q >= n) q = 2 * n - 1 - q; }
+    return q;
+}
+
+__global__ __launch_bounds__(256) void lw_smooth_kernel(const LwParams P, const float *base, size_t kstride, float *dst, int pass)
+{
+    const size_t np = (size_t)P.rh * P.rw, e = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= np || !P.st->valid) return;
+    const float *src = base + (size_t)P.st->kbest * kstride;
+    const int y = (int)(e / P.rw), x = (int)(e - (size_t)y * P.rw);
+    const int p = pass == 0 ? y : x, n = pass == 0 ? P.rh : P.rw;
+    double acc = (double)src[e] * P.gw[4];
+    for (int k = 4; k >= 1; --k) {
+        const int ql = lw_reflect(p - k, n), qr = lw_reflect(p + k, n);
+        const double l = pass == 0 ? src[(size_t)ql * P.rw + x] : src[(size_t)y * P.rw + ql];
+        const double r = pass == 0 ? src[(size_t)qr * P.rw + x] : src[(size_t)y * P.rw + qr];
+        acc += (l + r) * P.gw[4 - k];
+    }
+    dst[e] = (float)acc;
+}
+
+__device__ __forceinline__ float lw_grad1(const float *f, size_t stride, int k, int n)
+{
+    if (k == 0) return f[stride] - f[0];
+    if (k == n - 1) return f[(size_t)(n - 1) * stride] - f[(size_t)(n - 2) * stride];
+    return (f[(size_t)(k + 1) * stride] - f[(size_t)(k - 1) * stride]) / 2.0f;
+}
+__device__ __forceinline__ float lw_grad2(const float *f, size_t stride, int k, int n)
+{
+    if (k == 0) return lw_grad1(f, stride, 1, n) - lw_grad1(f, stride, 0, n);
+    if (k == n - 1) return lw_grad1(f, stride, n - 1, n) - lw_grad1(f, stride, n - 2, n);
+    return (lw_grad1(f, stride, k + 1, n) - lw_grad1(f, stride, k - 1, n)) / 2.0f;
+}
+
+// sum and sum of squares of a block's values in double, in a fixed order -> partial[2 * block]
+__device__ __forceinline__ void lw_block_sums(double a, double b, double *partial)
+{
+    __shared__ double red[256][2];
+    const int tid = threadIdx.x;
+    red[tid][0] = a; red[tid][1] = b;
+    __syncthreads();
+    for (int h = 128; h > 0; h >>= 1) {
+        if (tid < h) { red[tid][0] += red[tid + h][0]; red[tid][1] += red[tid + h][1]; }
+        __syncthreads();
+    }
+    if (tid == 0) { partial[2 * (size_t)blockIdx.x] = red[0][0]; partial[2 * (size_t)blockIdx.x + 1] = red[0][1]; }
+}
+
+// np.gradient twice along each axis, np.hypot (pmlib.py:51-55) - float32 arithmetic as NumPy's; hypotf as glibc evaluates it
+__global__ __launch_bounds__(256) void lw_hessian_kernel(const LwParams P, const float *base, size_t kstride, float *hes, double *partial)
+{
+    const size_t np = (size_t)P.rh * P.rw, e = (size_t)blockIdx.x * 256 + threadIdx.x;
+    double a = 0.0, b = 0.0;
+    if (e < np && P.st->valid) {
+        const float *src = base + (size_t)P.st->kbest * kstride;
+        const int y = (int)(e / P.rw), x = (int)(e - (size_t)y * P.rw);
+        const float d2x = lw_grad2(src + (size_t)y * P.rw, 1, x, P.rw);
+        const float d2y = lw_grad2(src + x, (size_t)P.rw, y, P.rh);
+        const float h = (float)sqrt((double)d2x * (double)d2x + (double)d2y * (double)d2y);
+        hes[e] = h;
+        a = (double)h; b = (double)h * (double)h;
+    }
+    lw_block_sums(a, b, partial);
+}
+
+__global__ __launch_bounds__(256) void lw_sums_kernel(const LwParams P, const float *base, size_t kstride, double *partial)
+{
+    const size_t np = (size_t)P.rh * P.rw, e = (size_t)blockIdx.x * 256 + threadIdx.x;
+    double a = 0.0, b = 0.0;
+    if (e < np && P.st->valid) {
+        const float v = (base + (size_t)P.st->kbest * kstride)[e];
+        a = (double)v; b = (double)v * (double)v;
+    }
+    lw_block_sums(a, b, partial);
+}
+
+// second level: the partials of nblk blocks in a fixed order -> st->sums[which]
+__global__ __launch_bounds__(256) void lw_sums_final_kernel(const LwParams P, const double *partial, int nblk, int which)
+{
+    __shared__ double red[256][2];
+    const int tid = threadIdx.x;
+    double a = 0.0, b = 0.0;
+    for (int i = tid; i < nblk; i += 256) { a += partial[2 * (size_t)i]; b += partial[2 * (size_t)i + 1]; }
+    red[tid][0] = a; red[tid][1] = b;
+    __syncthreads();
+    for (int h = 128; h > 0; h >>= 1) {
+        if (tid < h) { red[tid][0] += red[tid + h][0]; red[tid][1] += red[tid + h][1]; }
+        __syncthreads();
+    }
+    if (tid == 0) { P.st->sums[which][0] = red[0][0]; P.st->sums[which][1] = red[0][1]; }
+}
+
+// exact order statistics by radix select, 8 bits per pass over the global matrix: histogram of the next byte among the
+// elements that match the prefix found so far, for both wanted ranks at once
+__global__ __launch_bounds__(256) void lw_hist_kernel(const LwParams P, const float *base, size_t kstride, int pass, int which)
+{
+    __shared__ u32 h[2][256];
+    const int tid = threadIdx.x;
+    h[0][tid] = 0u; h[1][tid] = 0u;
+    __syncthreads();
+    if (P.st->valid) {
+        const float *src = base + (size_t)P.st->kbest * kstride;
+        const size_t np = (size_t)P.rh * P.rw;
+        const u32 p0 = P.st->sel_prefix[which][0], p1 = P.st->sel_prefix[which][1];
+        const int hi = 32 - 8 * pass, lo = 24 - 8 * pass;
+        for (size_t e = (size_t)blockIdx.x * 256 + tid; e < np; e += (size_t)gridDim.x * 256) {
+            const u32 key = f2key(src[e]);
+            const u32 bin = (key >> lo) & 255u;
+            if (pass == 0 || (key >> hi) == (p0 >> hi)) atomicAdd(&h[0][bin], 1u);
+            if (pass == 0 || (key >> hi) == (p1 >> hi)) atomicAdd(&h[1][bin], 1u);
+        }
+    }
+    __syncthreads();
+    if (h[0][tid]) atomicAdd(&P.st->hist[which][0][tid], h[0][tid]);
+    if (h[1][tid]) atomicAdd(&P.st->hist[which][1][tid], h[1][tid]);
+}
+
+__global__ void lw_hist_scan_kernel(const LwParams P, int pass, int which)
+{
+    LwState *S = P.st;
+    const int b = threadIdx.x;
+    if (b < 2 && S->valid) {
+        u32 cum = 0, rank = S->sel_rank[which][b];
+        for (int bin = 0; bin < 256; ++bin) {
+            const u32 c = S->hist[which][b][bin];
+            if (rank < cum + c) { S->sel_prefix[which][b] |= (u32)bin << (24 - 8 * pass); S->sel_rank[which][b] = rank - cum; break; }
+            cum += c;
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 512; i += blockDim.x) S->hist[which][i >> 8][i & 255] = 0u;
+}
+
+// np.median (mean of the two middles in float32) and np.std (from float64 sums: DESIGN.md section 3, 1e-5 on h)
+__device__ __forceinline__ void lw_med_std(const LwState *S, int which, size_t n, float &med, float &sd)
+{
+    const float a = key2f(S->sel_prefix[which][0]), b = key2f(S->sel_prefix[which][1]);
+    med = (n & 1) ? b : (a + b) / 2.0f;
+    const double mean = S->sums[which][0] / (double)n;
+    double var = S->sums[which][1] / (double)n - mean * mean;
+    var = var > 0.0 ? var : 0.0;
+    sd = sqrtf((float)var);
+}
+
+__global__ void lw_finish_kernel(const LwParams P)
+{
+    if (threadIdx.x != 0) return;
+    const LwState *S = P.st;
+    if (!S->valid) return;
+    const size_t n = (size_t)P.rh * P.rw;
+    float h = P.hes[(size_t)S->iy * P.rw + S->ix];
+    if (P.flags & 1u) { float med, sd; lw_med_std(S, 0, n, med, sd); h = (h - med) / sd; }
+    float r = S->best_r;
+    if (P.flags & 4u) { float med, sd; lw_med_std(S, 1, n, med, sd); r = (r - med) / sd; }
+    const double dr = (double)S->iy - (double)(P.wh - P.s) / 2., dc = (double)S->ix - (double)(P.ww - P.s) / 2.;   // pmlib.py:168-169
+    P.out5[0] = P.add_c + dc; P.out5[1] = P.add_r + dr; P.out5[2] = P.angles[S->kbest];
+    P.out5[3] = (double)r; P.out5[4] = (double)h;
+    if (P.ij3) { P.ij3[0] = S->iy; P.ij3[1] = S->ix; P.ij3[2] = S->kbest; }
+}
+
+// get_hessian as a call of its own: the whole matrix normalised
+__global__ __launch_bounds__(256) void lw_normalise_kernel(const LwParams P, float *hes)
+{
+    const size_t np = (size_t)P.rh * P.rw, e = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= np) return;
+    float med, sd;
+    lw_med_std(P.st, 0, np, med, sd);
+    hes[e] = (hes[e] - med) / sd;
+}
+
+__global__ void lw_state_init_kernel(const LwParams P)
+{
+    if (threadIdx.x != 0) return;
+    LwState *S = P.st;
+    const u32 n = (u32)((size_t)P.rh * P.rw);
+    S->valid = 1; S->kbest = 0; S->zero = 0;
+    for (int w = 0; w < 2; ++w) {
+        S->sel_prefix[w][0] = S->sel_prefix[w][1] = 0u;
+        S->sel_rank[w][0] = (n & 1u) ? n / 2u : n / 2u - 1u;
+        S->sel_rank[w][1] = n / 2u;
+    }
+}
+
+__global__ void lw_nan_kernel(const int32_t *idx, int n, double *out, int32_t *out_ij)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const size_t i = (size_t)idx[t];
+    const double nan = __longlong_as_double(0x7ff8000000000000ll);
+    for (int q = 0; q < 5; ++q) out[i * 5 + q] = nan;
+    if (out_ij) { out_ij[i * 3] = -1; out_ij[i * 3 + 1] = -1; out_ij[i * 3 + 2] = -1; }
+}
+
+// ---------------------------------------------------------------------------------------------- host
+enum { B_STATE = 0, B_TMPL, B_OPA, B_HS1, B_HS2, B_SI, B_SII, B_NCC, B_HES, B_TMPA, B_TMPB, B_PART };
+
+int reserve(LwWorkspace &W, int i, size_t bytes)
+{
+    if (bytes <= W.cap[i]) return 0;
+    if (W.buf[i]) (void)hipFree(W.buf[i]);
+    W.buf[i] = nullptr; W.cap[i] = 0;
+    if (hipMalloc(&W.buf[i], bytes) != hipSuccess) { (void)hipGetLastError(); return -1; }
+    W.cap[i] = bytes;
+    return 0;
+}
+
+size_t opa_bytes(int s, int K) { return (size_t)((K + 15) / 16) * (size_t)(s + 6) * (size_t)((s + 63) >> 6) * 1024; }
+
+hipError_t allow_lds(int bytes)
+{
+    static std::mutex mu;
+    static std::set<int> done;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    std::lock_guard<std::mutex> lock(mu);
+    if (done.count(dev)) return hipSuccess;
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(lw_corr_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds_bytes());
+    if (e == hipSuccess) done.insert(dev);
+    (void)bytes;
+    return e;
+}
+
+// median + sums of one matrix: four histogram passes (two ranks at once) -> st->sel_prefix[which]
+void launch_select(const LwParams &P, const float *base, size_t kstride, int which, hipStream_t st)
+{
+    const size_t np = (size_t)P.rh * P.rw;
+    const unsigned nb = (unsigned)std::min<size_t>((np + 255) / 256, 2048);
+    for (int pass = 0; pass < 4; ++pass) {
+        hipLaunchKernelGGL(lw_hist_kernel, dim3(nb), dim3(256), 0, st, P, base, kstride, pass, which);
+        hipLaunchKernelGGL(lw_hist_scan_kernel, dim3(1), dim3(64), 0, st, P, pass, which);
+    }
+}
+
+}  // namespace
+
+void lw_workspace_release(LwWorkspace &W)
+{
+    for (int i = 0; i < 12; ++i) { if (W.buf[i]) (void)hipFree(W.buf[i]); W.buf[i] = nullptr; W.cap[i] = 0; }
+}
+
+size_t lw_scratch_bytes(int wh, int ww, int s, int K, uint32_t flags)
+{
+    const size_t rh = (size_t)(wh - s + 1), rw = (size_t)(ww - s + 1), np = rh * rw;
+    size_t b = sizeof(LwState) + (size_t)K * s * s + opa_bytes(s, K) + (size_t)wh * rw * 8 + np * 8 + (size_t)K * np * 4 + np * 4;
+    if (flags & 2u) b += np * 8;
+    b += ((np + 255) / 256) * 32;
+    return b;
+}
+
+int lw_run(const LargeCall &c, LwWorkspace &W, void *stream)
+{
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const int s = c.s, K = c.K, rh = c.wh - s + 1, rw = c.ww - s + 1;
+    if (s < 2 || s > kLargeMaxSide || K < 1 || K > kMaxAngles || rh < 2 || rw < 2) return (int)hipErrorInvalidValue;
+    const size_t np = (size_t)rh * rw;
+    if (np >= 0xffffffffull) return (int)hipErrorInvalidValue;
+    const size_t nblk = (np + 255) / 256;
+    if (reserve(W, B_STATE, sizeof(LwState)) || reserve(W, B_TMPL, (size_t)K * s * s) || reserve(W, B_OPA, opa_bytes(s, K)) ||
+        reserve(W, B_HS1, (size_t)c.wh * rw * 4) || reserve(W, B_HS2, (size_t)c.wh * rw * 4) || reserve(W, B_SI, np * 4) ||
+        reserve(W, B_SII, np * 4) || reserve(W, B_NCC, (size_t)K * np * 4) || reserve(W, B_HES, np * 4) ||
+        ((c.flags & 2u) && (reserve(W, B_TMPA, np * 4) || reserve(W, B_TMPB, np * 4))) || reserve(W, B_PART, nblk * 32))
+        return -1;
+    LwParams P;
+    memset(&P, 0, sizeof P);
+    P.img1 = c.img1; P.rows1 = c.rows1; P.cols1 = c.cols1; P.stride1 = c.stride1; P.row0 = 0; P.col0 = 0;
+    P.win = c.img2 + c.win_r0 * c.stride2 + c.win_c0; P.wstride = c.stride2;
+    P.wh = c.wh; P.ww = c.ww; P.rh = rh; P.rw = rw; P.s = s; P.K = K; P.flags = c.flags;
+    P.c1 = c.c1; P.r1 = c.r1; P.rot = c.d_rot; P.angles = c.d_angles; P.add_c = c.add_c; P.add_r = c.add_r;
+    for (int q = 0; q < 5; ++q) P.gw[q] = c.gauss_w[q];
+    P.st = static_cast<LwState *>(W.buf[B_STATE]);
+    P.tmpl = static_cast<uint8_t *>(W.buf[B_TMPL]); P.opA = static_cast<uint8_t *>(W.buf[B_OPA]);
+    P.hs1 = static_cast<int32_t *>(W.buf[B_HS1]); P.hs2 = static_cast<u32 *>(W.buf[B_HS2]);
+    P.si = static_cast<int32_t *>(W.buf[B_SI]); P.sii = static_cast<u32 *>(W.buf[B_SII]);
+    P.ncc = static_cast<float *>(W.buf[B_NCC]); P.hes = static_cast<float *>(W.buf[B_HES]);
+    P.tmpa = static_cast<float *>(W.buf[B_TMPA]); P.tmpb = static_cast<float *>(W.buf[B_TMPB]);
+    P.partial = static_cast<double *>(W.buf[B_PART]);
+    P.out5 = c.out5; P.ij3 = c.ij3;
+    hipError_t e = allow_lds(0);
+    if (e != hipSuccess) return (int)e;
+    if ((e = hipMemsetAsync(P.st, 0, sizeof(LwState), st)) != hipSuccess) return (int)e;
+    if ((e = hipMemsetAsync(P.opA, 0, opa_bytes(s, K), st)) != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(lw_templates_kernel, dim3((unsigned)K), dim3(256), 0, st, P);
+    hipLaunchKernelGGL(lw_rowsums_kernel, dim3((unsigned)((rw + 1023) / 1024), (unsigned)c.wh), dim3(256), 0, st, P);
+    hipLaunchKernelGGL(lw_colsums_kernel, dim3((unsigned)((rw + 255) / 256), (unsigned)((rh + 31) / 32)), dim3(256), 0, st, P);
+    const int lds = (kTH + s - 1) * lw_pitch(s);
+    hipLaunchKernelGGL(lw_corr_kernel, dim3((unsigned)((rw + kTW - 1) / kTW), (unsigned)((rh + kTH - 1) / kTH), (unsigned)((K + 15) / 16)),
+                       dim3(256), (size_t)lds, st, P);
+    hipLaunchKernelGGL(lw_pick_kernel, dim3(1), dim3(64), 0, st, P);
+    const float *hsrc = P.ncc;
+    size_t hstride = np;
+    if (c.flags & 2u) {
+        hipLaunchKernelGGL(lw_smooth_kernel, dim3((unsigned)nblk), dim3(256), 0, st, P, (const float *)P.ncc, np, P.tmpa, 0);
+        hipLaunchKernelGGL(lw_smooth_kernel, dim3((unsigned)nblk), dim3(256), 0, st, P, (const float *)P.tmpa, (size_t)0, P.tmpb, 1);
+        hsrc = P.tmpb; hstride = 0;
+    }
+    hipLaunchKernelGGL(lw_hessian_kernel, dim3((unsigned)nblk), dim3(256), 0, st, P, hsrc, hstride, P.hes, P.partial);
+    if (c.flags & 1u) {
+        hipLaunchKernelGGL(lw_sums_final_kernel, dim3(1), dim3(256), 0, st, P, (const double *)P.partial, (int)nblk, 0);
+        launch_select(P, P.hes, 0, 0, st);
+    }
+    if (c.flags & 4u) {
+        hipLaunchKernelGGL(lw_sums_kernel, dim3((unsigned)nblk), dim3(256), 0, st, P, (const float *)P.ncc, np, P.partial);
+        hipLaunchKernelGGL(lw_sums_final_kernel, dim3(1), dim3(256), 0, st, P, (const double *)P.partial, (int)nblk, 1);
+        launch_select(P, P.ncc, np, 1, st);
+    }
+    hipLaunchKernelGGL(lw_finish_kernel, dim3(1), dim3(64), 0, st, P);
+    return (int)hipGetLastError();
+}
+
+const float *lw_ncc_matrix(const LwWorkspace &W, int wh, int ww, int s, int k)
+{
+    return static_cast<const float *>(W.buf[B_NCC]) + (size_t)k * (size_t)(wh - s + 1) * (size_t)(ww - s + 1);
+}
+
+const uint8_t *lw_template(const LwWorkspace &W, int s, int k) { return static_cast<const uint8_t *>(W.buf[B_TMPL]) + (size_t)k * s * s; }
+
+int lw_write_nan(const int32_t *d_idx, int n, double *out, int32_t *out_ij, void *stream)
+{
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(lw_nan_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), d_idx, n, out, out_ij);
+    return (int)hipGetLastError();
+}
+
+int lw_get_template(const uint8_t *d_img, int64_t stride, int64_t row0, int64_t col0, int64_t nrows, int64_t ncols, int64_t rows, int64_t cols,
+                    double c, double r, const double *d_rot4, int s, int order, uint8_t *d_out, void *stream)
+{
+    (void)nrows; (void)ncols;
+    if (s < 1 || s > 4096) return (int)hipErrorInvalidValue;
+    LwParams P;
+    memset(&P, 0, sizeof P);
+    P.img1 = d_img; P.rows1 = rows; P.cols1 = cols; P.stride1 = stride; P.row0 = row0; P.col0 = col0;
+    P.s = s; P.K = 1; P.flags = order == 1 ? 8u : 0u; P.c1 = c; P.r1 = r; P.rot = d_rot4; P.tmpl = d_out;
+    hipLaunchKernelGGL(lw_templates_kernel, dim3(1), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), P);
+    return (int)hipGetLastError();
+}
+
+int lw_get_hessian(const float *d_ccm, int rh, int rw, uint32_t flags, const double gauss_w[5], float *d_hes, LwWorkspace &W, void *stream)
+{
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (rh < 2 || rw < 2) return (int)hipErrorInvalidValue;
+    const size_t np = (size_t)rh * rw, nblk = (np + 255) / 256;
+    if (np >= 0xffffffffull) return (int)hipErrorInvalidValue;
+    if (reserve(W, B_STATE, sizeof(LwState)) || reserve(W, B_PART, nblk * 32) ||
+        ((flags & 2u) && (reserve(W, B_TMPA, np * 4) || reserve(W, B_TMPB, np * 4)))) return -1;
+    LwParams P;
+    memset(&P, 0, sizeof P);
+    P.rh = rh; P.rw = rw; P.flags = flags;
+    for (int q = 0; q < 5; ++q) P.gw[q] = gauss_w[q];
+    P.st = static_cast<LwState *>(W.buf[B_STATE]);
+    P.tmpa = static_cast<float *>(W.buf[B_TMPA]); P.tmpb = static_cast<float *>(W.buf[B_TMPB]);
+    P.partial = static_cast<double *>(W.buf[B_PART]); P.hes = d_hes;
+    hipError_t e = hipMemsetAsync(P.st, 0, sizeof(LwState), st);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(lw_state_init_kernel, dim3(1), dim3(64), 0, st, P);
+    const float *src = d_ccm;
+    if (flags & 2u) {
+        hipLaunchKernelGGL(lw_smooth_kernel, dim3((unsigned)nblk), dim3(256), 0, st, P, d_ccm, (size_t)0, P.tmpa, 0);
+        hipLaunchKernelGGL(lw_smooth_kernel, dim3((unsigned)nblk), dim3(256), 0, st, P, (const float *)P.tmpa, (size_t)0, P.tmpb, 1);
+        src = P.tmpb;
+    }
+    hipLaunchKernelGGL(lw_hessian_kernel, dim3((unsigned)nblk), dim3(256), 0, st, P, src, (size_t)0, d_hes, P.partial);
+    if (flags & 1u) {
+        hipLaunchKernelGGL(lw_sums_final_kernel, dim3(1), dim3(256), 0, st, P, (const double *)P.partial, (int)nblk, 0);
+        launch_select(P, d_hes, 0, 0, st);
+        hipLaunchKernelGGL(lw_normalise_kernel, dim3((unsigned)nblk), dim3(256), 0, st, P, d_hes);
+    }
+    return (int)hipGetLastError();
+}
+
+}  // namespace sid

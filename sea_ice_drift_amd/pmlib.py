@@ -12,11 +12,16 @@ The structure is  prelude (host, NumPy)  ->  dispatch (GPU)  ->  postlude (host,
 * the dispatch replaces the ``multiprocessing.Pool.map`` of pmlib.py:436-448 with the HIP
   kernel behind the C ABI (``_capi``).  ``threads`` is accepted for signature compatibility
   and ignored.  There is no CPU fallback: without the HIP library / a gfx950 device this
-  raises.  Options the kernel does not implement (``rot_order`` above 1, an ``mtype`` other
-  than TM_CCOEFF_NORMED, a user ``template_matcher``, ``img_size`` outside 2..64) raise
+  raises.  Options the kernels do not implement (``rot_order`` above 1, an ``mtype`` other
+  than TM_CCOEFF_NORMED, a user ``template_matcher``, ``img_size`` outside 2..255) raise
   ``NotImplementedError``;
 * ``pm_postlude``  turns the (N,5) result block into the seven output grids as
                    pmlib.py:451-497 does.
+
+The per-point functions of the reference are here with their own signatures as well - ``rotate_and_match`` (pmlib.py:117-174,
+any rectangular ``image2`` up to a whole image: the large-window pipeline of csrc/pm_large.hip), ``use_mcc`` (:176-212),
+``get_template`` (:89-115), ``get_hessian`` (:36-59), ``get_distance_to_nearest_keypoint`` (:61-77) - each a call into the
+HIP library.
 """
 from __future__ import absolute_import, print_function
 
@@ -35,22 +40,8 @@ TM_CCOEFF_NORMED = 5                  # cv2.TM_CCOEFF_NORMED, the reference's de
 
 
 # ------------------------------------------------------------------ small pieces
-def rotation_terms(angle_deg, img_size):
-    """(cos a, sin a, tcT0, tcT1) for one trial angle, computed with NumPy exactly like the
-    reference's get_template (pmlib.py:105-110): tc = int(s/2.)+1, a = radians(angle),
-    transform = [[cos,-sin],[sin,cos]], tcT = [tc,tc].dot(transform).  Passed to the C ABI so
-    the device samples the same float64 coordinates the reference's scipy call would."""
-    tc = int(img_size / 2.) + 1
-    tc = np.array([tc, tc])
-    a = np.radians(angle_deg)
-    transform = np.array([[np.cos(a), -np.sin(a)], [np.sin(a), np.cos(a)]])
-    tct = tc.dot(transform)
-    return float(transform[0, 0]), float(transform[1, 0]), float(tct[0]), float(tct[1])
-
-
-def rotation_table(angles, alpha0, img_size):
-    """[K,4] table of rotation_terms(angle - alpha0) (pmlib.py:151)."""
-    return np.array([rotation_terms(a - alpha0, img_size) for a in angles], dtype=np.float64).reshape(-1, 4)
+rotation_terms = _capi.rotation_terms       # (cos a, sin a, tcT0, tcT1) with NumPy, as pmlib.py:105-110 computes them
+rotation_table = _capi.rotation_table       # [K,4] of rotation_terms(angle - alpha0) (pmlib.py:151)
 
 
 def get_initial_rotation(n1, n2):
@@ -283,6 +274,80 @@ def pm_dispatch(img1, img2, c1, r1, c2fg, r2fg, border, img_size, alpha0, device
             raise
         ctx.run()
         return ctx.fetch(want_ij=False)
+
+
+def get_template(img, c, r, a, s, rot_order=0, **kwargs):
+    """Rotated and shifted square template: same signature and return as the reference's get_template (pmlib.py:89-115) -
+    the (s, s) uint8 array scipy's affine_transform would give for ``rot_order`` 0 or 1, sampled on the GPU."""
+    if isinstance(rot_order, bool) or rot_order not in (0, 1):
+        raise NotImplementedError("rot_order=%r: templates are sampled nearest-neighbour (0) or bilinear (1); orders 2..5 need "
+                                  "scipy's whole-image spline prefilter" % (rot_order,))
+    return _capi.get_template(img, c, r, rotation_terms(a, s), s, rot_order=int(rot_order), device=int(kwargs.get('device', 0)))
+
+
+def get_hessian(ccm, hes_norm=True, hes_smth=False, **kwargs):
+    """Hessian of a cross-correlation matrix: same signature and return as the reference's get_hessian (pmlib.py:36-59) for
+    the float32 matrices cv2.matchTemplate produces.  The raw magnitudes and the median are exact; np.std comes from float64
+    sums, so a normalised value agrees with NumPy's to ~1e-7 relative (north_star's bar on h is 1e-5)."""
+    ccm = np.asarray(ccm)
+    if ccm.dtype != np.float32:
+        raise NotImplementedError('get_hessian on the device takes float32 matrices (what cv2.matchTemplate returns, pmlib.py:156); '
+                                  'got %s' % ccm.dtype)
+    flags = (_capi.HES_NORM if hes_norm else 0) | (_capi.HES_SMTH if hes_smth else 0)
+    return _capi.get_hessian(ccm, flags=flags, device=int(kwargs.get('device', 0)))
+
+
+def get_distance_to_nearest_keypoint(x1, y1, shape, device=0):
+    """Full-resolution matrix of the distance to the nearest key point in pixels: same signature and return as the reference's
+    get_distance_to_nearest_keypoint (pmlib.py:61-77: seed[uint16(y1), uint16(x1)] = True, then scipy's exact Euclidean distance
+    transform) - evaluated per pixel on the GPU through buckets of seeds; both are the square root, in float64, of an exact
+    integer squared distance."""
+    seed_r, seed_c = np.atleast_1d(np.uint16(y1)), np.atleast_1d(np.uint16(x1))
+    if seed_r.size == 0:
+        raise ValueError('get_distance_to_nearest_keypoint needs at least one key point')
+    if seed_r.max() >= shape[0] or seed_c.max() >= shape[1]:
+        bad = int(np.argmax((seed_r >= shape[0]) | (seed_c >= shape[1])))
+        raise IndexError('key point %d at pixel (row %d, col %d) is out of bounds for an image of shape %s (reference pmlib.py:73)'
+                         % (bad, int(seed_r[bad]), int(seed_c[bad]), tuple(shape[:2])))
+    seeds = np.unique(np.stack([seed_r.astype(np.float64), seed_c.astype(np.float64)], axis=1), axis=0)
+    return _capi.fg_distance_image(seeds, shape[0], shape[1], device=device)
+
+
+def rotate_and_match(img1, c1, r1, img_size, image2, alpha0, angles=[-3, 0, 3], mtype=TM_CCOEFF_NORMED, template_matcher=None,
+                     mcc_norm=False, **kwargs):
+    """Rotate the template in a range of angles and run MCC for each: same signature and return as the reference's
+    rotate_and_match (pmlib.py:117-174) -
+
+        dc, dr, best_a, best_r, best_h, best_result, best_template
+
+    with ``best_result`` the float32 cross-correlation matrix and ``best_template`` the uint8 template of the winning angle, or
+    seven NaNs when a rotated template touches a 0 pixel (pmlib.py:152-154).  ``image2`` is the search window - any rectangular
+    uint8 array, up to a whole image (tests.py:336-337); its placements are tiled over the whole GPU (csrc/pm_large.hip).
+    ``kwargs``: ``rot_order`` (0 / 1), ``hes_norm``, ``hes_smth`` as in the reference; ``device`` / ``context`` as in pm_dispatch.
+    A window with fewer than two placements along an axis raises ValueError (np.gradient does, in the reference)."""
+    kw = dict(kwargs, angles=angles, mtype=mtype, template_matcher=template_matcher, mcc_norm=mcc_norm)
+    context = kw.pop('context', None)
+    device = kw.pop('device', 0)
+    ang, flags = _sweep_options(kw)
+    if len(ang) == 0:
+        raise UnboundLocalError("rotate_and_match with an empty list of angles (the reference's loop, pmlib.py:150, leaves best_result undefined)")
+    image2 = np.asarray(image2)
+    if image2.ndim != 2 or image2.shape[0] - img_size + 1 < 2 or image2.shape[1] - img_size + 1 < 2:
+        raise ValueError('image2 of shape %s leaves fewer than two placements of a %d px template along an axis '
+                         '(np.gradient needs two: pmlib.py:51)' % (image2.shape, img_size))
+    ctx, lock = _shared_context(device) if context is None else (context, _NoLock())
+    with lock:
+        ctx.upload_pair(img1, image2)
+        try:
+            d = ctx.rotate_and_match(c1, r1, img_size, alpha0, ang, flags=flags, window=(0, 0, image2.shape[0], image2.shape[1]))
+        except _capi.SidPmError as e:
+            if e.code == -4:
+                raise NotImplementedError(str(e))
+            raise
+    if d['ij'][2] < 0:
+        return np.nan, np.nan, np.nan, np.nan, np.nan, np.nan, np.nan
+    dc, dr, _, r, h = d['out']
+    return dc, dr, ang[int(d['ij'][2])], np.float32(r), np.float32(h), d['ccm'], d['template']
 
 
 def use_mcc(c1, r1, c2fg, r2fg, border, img1, img2, img_size, alpha0, **kwargs):

@@ -14,6 +14,9 @@ them, with a sha256) and the outputs the reference's functions returned:
   g3b_use_mcc_order1.npz  pmlib.use_mcc(rot_order=1) on G3's pair and points
   g3c_large_rotations.npz  pmlib.use_mcc on G3's pair and points with scene rotations alpha0 of 30, 90 and -137.5 degrees
                      (pmlib.py:79-87,151: the sampling angle is angle - alpha0), rot_order 0 and 1, sizes 34 / 35
+  g8_rotate_and_match.npz  pmlib.rotate_and_match called directly (pmlib.py:117-174) - the shape of the reference's own test
+                     (tests.py:336-337: whole image 2 as the window, img_size=50, 7 angles), rectangular windows, img_size up to
+                     128 - and pmlib.use_mcc with search borders of 112 / 160 / 250 px; the NCC matrices as sha256 + a subsample
   g4_pattern_matching.npz  pmlib.pattern_matching    (pmlib.py:326-497) end to end on an
                      affine stand-in for Nansat, incl. the kernel-input vectors it built
   g5_fullsize.npz    sha256 of the 10000x10000 benchmark pair + C-oracle results on a 1 %
@@ -189,6 +192,67 @@ def make_g3(pmlib):
         full.append(i)
     d['full_points'] = np.array(full)
     np.savez_compressed(os.path.join(HERE, 'g3_use_mcc.npz'), **d)
+
+
+def g8_pair():
+    img1, img2 = syn.make_pair(640, 700, seed=808, amplitude=5.0, period=500.0)
+    img1 = img1.copy()
+    img1[600:640, 0:40] = 0                          # a zero corner (NaN x 7 for a template that touches it)
+    return img1, img2
+
+
+# rotate_and_match cases: (name, c1, r1, img_size, window of image 2 as (r0, r1, c0, c1) or None = the whole image, alpha0, kwargs)
+G8_RAM = [
+    ('tests_py', 300, 100, 50, None, 0, dict(angles=[-3, -2, -1, 0, 1, 2, 3])),            # tests.py:336-337
+    ('rect', 320.5, 330.25, 35, (100, 420, 150, 633), -3.85, dict(angles=[-3, 0, 3], mcc_norm=True)),
+    ('rect_smth', 200, 250, 34, (60, 331, 40, 500), 30.0, dict(angles=list(range(-7, 8)), hes_smth=True)),
+    ('even', 350, 300, 34, (200, 400, 250, 450), 0.0, dict(angles=[0], hes_norm=False)),       # a 200 x 200 window (even side)
+    ('s64', 330, 320, 64, (150, 500, 150, 520), 2.0, dict(angles=[-2, 0, 2], rot_order=1)),
+    ('s100', 330, 320, 100, (100, 560, 120, 600), 0.0, dict(angles=[-3, 0, 3])),
+    ('s128', 330, 320, 128, None, 0.0, dict(angles=[0, 4])),
+    ('s65', 310.5, 305.5, 65, (100, 400, 100, 431), -90.0, dict(angles=[-1, 0, 1, 2], mcc_norm=True, hes_smth=True)),
+    ('nan', 30, 615, 50, (100, 300, 100, 300), 0.0, dict(angles=[-3, 0, 3])),                # the template touches the zero corner
+    ('tiny', 330, 320, 50, (100, 152, 100, 151), 0.0, dict(angles=[0, 1])),                  # a 3 x 2 NCC matrix
+]
+# use_mcc cases beyond the LDS classes: (name, c1, r1, c2fg, r2fg, border, img_size, alpha0, kwargs)
+G8_MCC = [
+    ('b112', 330.0, 320.0, 333.0, 318.0, 112.0, 34, 0.0, dict(angles=[-3, 0, 3])),
+    ('b160', 340.0, 310.0, 338.0, 312.0, 160.0, 35, -3.85, dict(angles=list(range(-3, 4)))),
+    ('b250', 350.0, 320.0, 350.0, 320.0, 250.0, 34, 0.0, dict(angles=[-3, 0, 3], mcc_norm=True)),
+    ('b30_s100', 330.0, 320.0, 331.0, 322.0, 30.0, 100, 1.5, dict(angles=[-3, 0, 3])),
+    ('b20_s65', 330.5, 320.5, 331.0, 322.0, 20.0, 65, 0.0, dict(angles=list(range(-7, 8)))),
+]
+
+
+def ccm_digest(m):
+    """sha256 of the float32 matrix bytes + a strided subsample (what a fixture keeps of a large NCC matrix)."""
+    import hashlib
+    m = np.ascontiguousarray(m, dtype=np.float32)
+    return hashlib.sha256(m.tobytes()).hexdigest(), m[::max(1, m.shape[0] // 16), ::max(1, m.shape[1] // 16)].copy()
+
+
+def make_g8(pmlib):
+    """rotate_and_match as a call of its own and use_mcc beyond the LDS launch classes, from the imported reference with the
+    restated matcher (its C form - pinned to the NumPy form by tests/test_oracle_golden.py - for speed) injected."""
+    img1, img2 = g8_pair()
+    d = dict(pair_sha=syn.sha256(img1, img2))
+    for name, c1, r1, s, win, alpha0, kw in G8_RAM:
+        image2 = img2 if win is None else img2[win[0]:win[1], win[2]:win[3]]
+        out = pmlib.rotate_and_match(img1, c1, r1, s, image2, alpha0, template_matcher=c_oracle.match_template, **kw)
+        if isinstance(out[5], float):                               # NaN x 7 (pmlib.py:152-154)
+            assert all(np.isnan(x) for x in out)
+            d['ram_%s_scalars' % name] = np.full(5, np.nan)
+            continue
+        d['ram_%s_scalars' % name] = np.array(out[:5], dtype=np.float64)
+        sha, sub = ccm_digest(out[5])
+        d['ram_%s_ccm_sha' % name] = sha
+        d['ram_%s_ccm_sub' % name] = sub
+        d['ram_%s_ccm_shape' % name] = np.array(out[5].shape)
+        d['ram_%s_template' % name] = out[6]
+    for name, c1, r1, c2fg, r2fg, b, s, alpha0, kw in G8_MCC:
+        d['mcc_%s' % name] = np.array(pmlib.use_mcc(c1, r1, c2fg, r2fg, b, img1, img2, s, alpha0,
+                                                    template_matcher=c_oracle.match_template, **kw), dtype=np.float64)
+    np.savez_compressed(os.path.join(HERE, 'g8_rotate_and_match.npz'), **d)
 
 
 def g4_inputs():
@@ -382,7 +446,7 @@ def main():
         make_g6(reflib)
         print('g6 done in %.1f s' % (time.time() - t))
     c_oracle.build()
-    for name, fn in (('g1', make_g1), ('g1b', make_g1b), ('g2', make_g2), ('g3', make_g3), ('g3b', make_g3b), ('g3c', make_g3c), ('g4', make_g4)):
+    for name, fn in (('g1', make_g1), ('g1b', make_g1b), ('g2', make_g2), ('g3', make_g3), ('g3b', make_g3b), ('g3c', make_g3c), ('g4', make_g4), ('g8', make_g8)):
         if name in which:
             t = time.time()
             fn(pmlib)
