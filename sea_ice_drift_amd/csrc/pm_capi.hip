@@ -612,8 +612,8 @@ int classify_points(sid_pm_ctx *ctx)
     std::vector<uint32_t> goff;
     uint64_t gsii_granules = 0;
     if (rp) {
-        // Launches that keep accumulators take their blocks from the per-XCD free lists (PMArgs::ring): 8 x kRing blocks of the
-        // largest such block, whatever the number of points (SID_PM_NO_RECYCLE=1: a block per launch position, as the others)
+        // Launches that keep accumulators take their blocks from the per-XCD free lists (PMArgs::ring): kPoolBlocks blocks (512 per
+        // XCD) of the largest such block, whatever the number of points (SID_PM_NO_RECYCLE=1: a block per launch position, as the others)
         const bool recycle = ctx->gs_keep_acc && getenv("SID_PM_NO_RECYCLE") == nullptr;
         uint32_t stride = 0;
         std::vector<uint32_t> gran_shape(shapes.size(), 0u);
@@ -625,16 +625,12 @@ int classify_points(sid_pm_ctx *ctx)
         }
         ctx->pool_stride = stride;
         if (stride) {
-            if (int rc = ctx->pool.reserve((size_t)8 * sid::kRing * stride)) return rc;
-            if (int rc = ctx->ring.reserve((size_t)8 * sid::kRingWords)) return rc;
-            // every block free (entry i = generation 0, block i), head 0, tail kRing; rewritten at every classification - no
-            // launch of this handle is in flight here - so that an aborted run cannot leave a list short of blocks
-            std::vector<uint32_t> init((size_t)8 * sid::kRingWords, 0u);
-            for (int x = 0; x < 8; ++x) {
-                uint32_t *rx = init.data() + (size_t)x * sid::kRingWords;
-                rx[sid::kRingTail] = (uint32_t)sid::kRing;
-                for (int i = 0; i < sid::kRing; ++i) rx[sid::kRingEnt + i] = (uint32_t)i;
-            }
+            if (int rc = ctx->pool.reserve((size_t)sid::kPoolBlocks * stride)) return rc;
+            if (int rc = ctx->ring.reserve((size_t)sid::kRingU64 * 2)) return rc;
+            // every block free (all bits set).  Rewritten at every classification - no launch of this handle is in flight here -
+            // so that an aborted run cannot leave a list short of blocks
+            std::vector<uint32_t> init((size_t)sid::kRingU64 * 2, 0u);
+            for (int w = 0; w < 8 * sid::kRingWordsPerXcd; ++w) { init[(size_t)w * sid::kRingStride * 2] = 0xffffffffu; init[(size_t)w * sid::kRingStride * 2 + 1] = 0xffffffffu; }
             HIP_TRY(hipMemcpyAsync(ctx->ring.p, init.data(), init.size() * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
             HIP_TRY(hipStreamSynchronize(ctx->stream));
         }
@@ -775,9 +771,9 @@ SID_EXPORT int sid_pm_create(int device, sid_pm_ctx **out)
             if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->join_ev[k], hipEventDisableTiming);
         }
         if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->fork_ev, hipEventDisableTiming);
-        if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void **>(&ctx->h_refused), sizeof(int32_t), hipHostMallocMapped);
+        if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void **>(&ctx->h_refused), 4 * sizeof(int32_t), hipHostMallocMapped);
         if (e != hipSuccess) { sid_pm_destroy(ctx); return fail(SID_PM_ERR_HIP, "stream/event creation failed: %s", hipGetErrorString(e)); }
-        *ctx->h_refused = 0;
+        ctx->h_refused[0] = ctx->h_refused[1] = ctx->h_refused[2] = ctx->h_refused[3] = 0;
     }
     *out = ctx;
     return SID_PM_OK;
@@ -1036,9 +1032,12 @@ SID_EXPORT int sid_pm_check(sid_pm_ctx *ctx)
     if (!ctx) return fail(SID_PM_ERR_ARG, "null ctx");
     if (!ctx->h_refused) return SID_PM_OK;
     const int32_t n = __atomic_exchange_n(ctx->h_refused, 0, __ATOMIC_ACQ_REL);
+    const int32_t polls = __atomic_exchange_n(ctx->h_refused + 1, 0, __ATOMIC_ACQ_REL);
+    if (polls > 0 && getenv("SID_PM_VERBOSE") != nullptr) fprintf(stderr, "sid_pm: %d workgroup(s) found the home words of their XCD's free list empty and took a block of its reserve words\n", (int)polls);
     if (n != 0)
         return fail(SID_PM_ERR_STATE, "%d grid point(s) with a valid search window were refused by their launch (LDS layout of the "
-                                      "kernel and classification of the host disagree); their rows hold NaN", (int)n);
+                                      "kernel and classification of the host disagree, or all %d recycled blocks of global memory of an XCD "
+                                      "were taken - %d pops went to the reserve words); their rows hold NaN", (int)n, sid::kRingWordsPerXcd * 64, (int)polls);
     return SID_PM_OK;
 }
 

@@ -43,7 +43,7 @@ struct PMArgs {
     // points with a valid search window that the kernel refused because the launch did not fit them (LDS size or window
     // pitch chosen by the host's classification): counted here - pinned host memory, read by sid_pm_sync / sid_pm_fetch /
     // sid_pm_check - so that a disagreement between host and device layout is an error, never a silent NaN
-    int32_t *refused;
+    int32_t *refused;                               // [0] refused points; [1] pops that went to the spare blocks (diagnostic)
     // row-pair kernel: sum w'^2 per placement of every point in global memory instead of LDS (7 .. 42 KB per point: the
     // largest LDS item of a point with a large search border, written once and read twice).  gsii_off[j] = offset of launch
     // position j's block in units of 64 entries (256 bytes); the block is written and read by the point's own workgroup
@@ -58,16 +58,25 @@ struct PMArgs {
     // stored sums (rp_winner_kept): no second pass over the window, no operand staging, no matrix instructions.  16 B per
     // placement with four slot groups (the reference's default: 3 angles), 32 B with two (<= 7 angles), 64 B with the full table.
     uint32_t gs_keep_acc;
-    // Recycled blocks (round 5; the safe successor of round 4's hardware-slot pool): the blocks of global memory of a launch
-    // that keeps accumulators come from a FREE LIST per XCD - `ring`: [8 XCDs][kRingWords] u32, a ticket ring of kRing block
-    // numbers (pop: one atomic on `head` + the entry, tagged with its generation; push: one atomic on `tail` + one store) -
-    // instead of one block per launch position.  A block belongs to whoever popped it until that workgroup pushes it back:
-    // ownership is a property of the list, not of where the workgroup happens to run (tools/ubench/slot_life.hip: under a queue
-    // eviction workgroups are saved and restored on OTHER CUs - but on the same XCD, which is all the list relies on: a block
-    // is only ever written and read through ONE XCD's L2).  1024 - 2048 blocks cycle through L2 / the Infinity Cache instead of
-    // 40 000 write-once blocks travelling to HBM.  ring = null: the exclusive block of the launch position (gsii_off).
+    // Recycled blocks: the blocks of global memory of a launch that keeps accumulators come from FREE LISTS per XCD instead of
+    // one block per launch position - 1024 - 2048 blocks cycle through L2 / the Infinity Cache instead of 40 000 write-once blocks
+    // travelling to HBM.  A block belongs to whoever popped it until that workgroup pushes it back: ownership is a property of the
+    // list, not of where the workgroup happens to run (tools/ubench/slot_life.hip: under a queue eviction workgroups are saved and
+    // restored on OTHER CUs - round 4's pool picked by hardware slot broke there).
+    // Round 6: the lists are BITMAPS - kRingWordsPerXcd 64-bit words per XCD, a set bit = a free block - and no operation ever
+    // waits for another workgroup: pop = one atomic AND that clears the lowest set bit of the popper's home word (found in a
+    // copy read first thing in the kernel; the AND's return value tells whether the bit was still there, and is the fresh copy
+    // for the next try if not), then the XCD's other words, then - all of them empty: four times what an XCD holds resident
+    // would have to be in flight - the point is refused (PMArgs::refused: an error, never a hang); push = one atomic OR without
+    // a return value.  Round 5's ticket ring committed a popper to ONE future push: a workgroup that was context-saved (queue
+    // eviction) between taking its ticket and reading its entry found the entry overwritten by the pushes of a whole lap when it
+    // came back and waited for ever - the eviction soak's "timeouts" (reproduced in round 6 with a bounded wait:
+    // profiles/r06_ring_deadlock.txt).  Lock-free stacks (64-bit compare-and-swap, a `next` word per block) fixed that and cost
+    // +12-15 % on the reference's defaults - five serial round trips per point at agent scope (profiles/r06_ab_free_lists.txt).
+    // `ring` = [8 XCDs][kRingWordsPerXcd] words, 64 B apart; block number = word index * 64 + bit; null: the exclusive block of
+    // the launch position (gsii_off).
     uint32_t *ring;
-    uint32_t *pool;                                 // [8 XCDs][kRing blocks][pool_stride u32]
+    uint32_t *pool;                                 // [kPoolBlocks][pool_stride u32]
     uint32_t pool_stride;
     // diagnostics (debug_point only; null in production launches)
     uint8_t *dbg_templates; float *dbg_ccm; float *dbg_hes; int32_t *dbg_shape; int64_t dbg_cap;
@@ -81,8 +90,10 @@ __host__ __device__ inline int round_up(int v, int m) { return (v + m - 1) / m *
 constexpr int kMiscMfmaBytes = 2688;
 constexpr int kTrowPad = 36;         // zero rows around a winner operand block: 16 above, 20 below (the step loop runs in fours)
 constexpr int kQueueCap = 192;       // arg-max candidates waiting for exact evaluation (16 B each)
-constexpr int kRingLog = 8, kRing = 1 << kRingLog;        // recycled blocks per XCD (PMArgs::ring): twice what an XCD can hold resident
-constexpr int kRingHead = 0, kRingTail = 32, kRingEnt = 64, kRingWords = kRingEnt + kRing;   // head and tail in cache lines of their own
+constexpr int kRingWordsPerXcd = 8, kRingHomeWords = 4;    // bitmap words per XCD (PMArgs::ring); a workgroup's home word is one of the first kRingHomeWords, by launch position
+constexpr int kPoolBlocks = 8 * kRingWordsPerXcd * 64;     // 512 blocks per XCD: four times what an XCD holds resident
+constexpr int kRingStride = 8;                             // u64 units between words (a cache line each)
+constexpr int kRingU64 = 8 * kRingWordsPerXcd * kRingStride;
 constexpr int kRpQueueWithSi = 128;  // ... and the sums kept for the winner (RpLdsLayout::si_off) leave it at least this
 constexpr int kRpQueueMin = 64;      // row-pair kernel: the queue shrinks to this where it decides the residency class (overflow is evaluated in place)
 

@@ -109,7 +109,7 @@ struct Geo {
     int gsi;                         // ... the same in the point's block of global memory, behind sum w'^2: offset in u32 entries (0: none)
     int hist_off;                    // 5 KB behind the NCC matrix of the winning angle for ph_hessian_fast (0: none - the general ph_hessian runs)
     int gsa, gsa_rw;                 // kept accumulators (PMArgs::gs_keep_acc): offset of the table in the point's block (u32 entries; 0: none) and its row pitch in placements
-    int blk, blk_xcd;                // recycled block of this point and the XCD ring it came from (PMArgs::ring; -1: none)
+    int blk, blk_xcd;                // recycled block of this point and its home word of the free lists (PMArgs::ring; blk -1: none)
     int lin;                         // rot_order = 1 (SID_PM_ROT_ORDER1, pmlib.py:89): templates sampled bilinearly, every sample through sample_exact
     long long r0, c0;                // window origin on image 2
     double c1, r1, nd;

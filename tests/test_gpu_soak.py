@@ -81,24 +81,34 @@ def test_recycled_blocks_survive_queue_evictions(angles, img_size, c_oracle, tmp
     from per-XCD free lists (round 5).  300 repetitions of a 6 400-point run while a host thread provokes evictions of the
     process's GPU queues (tools/eviction_soak.py: wavefronts in flight are saved and restored on OTHER compute units - what broke
     round 4's pool of blocks picked by hardware slot): every repetition bit-identical to the first, the first equal to the
-    oracle.  A process of its own, run before every other GPU test (conftest.py), with a hard timeout and one retry: an eviction
-    has stalled for minutes on some boxes, and a blocked runtime call cannot be interrupted from Python."""
+    oracle.  A process of its own, run before every other GPU test (conftest.py), with a hard timeout and one retry.
+    A kernel of the library cannot hang on its free list any more - a popper's wait is bounded (ring_take: kRingSpinMax polls,
+    then the point is REFUSED and sid_pm_sync raises) - so a soak that does not finish is either a stall of the driver's own
+    eviction / restore (seen on some boxes for minutes, with idle queues as well) or a defect of the library.  The CONTROL
+    tells them apart: the same process and evictor with no kernel of the library in flight.  Control stalls too: the box cannot
+    run this test (skip, with that evidence).  Control finishes: the library's kernels are what does not return - FAIL."""
     import json, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     dump = str(tmp_path / 'first_run.npz')
+    tool = os.path.join(root, 'tools', 'eviction_soak.py')
     p = None
     for attempt in range(2):
         try:
-            p = subprocess.run([sys.executable, os.path.join(root, 'tools', 'eviction_soak.py'), str(angles), str(img_size), '300', dump],
+            p = subprocess.run([sys.executable, tool, str(angles), str(img_size), '300', dump],
                                capture_output=True, text=True, timeout=90, cwd=root)
             break
         except subprocess.TimeoutExpired:
-            # (seen on some boxes, with or without this library's kernels in flight: the driver's restore after an eviction takes
-            # minutes - always for the whole process, so a second process gets a second chance.  The soak takes 5 s when it
-            # runs; conftest.py runs it before every other GPU test; profiles/r05_eviction_soak.txt has such runs.)
             continue
     if p is None:
-        pytest.skip('queue evictions stall on this box: the soak did not finish within 90 s, twice')
+        try:
+            c = subprocess.run([sys.executable, tool, str(angles), str(img_size), '300', dump, 'control'],
+                               capture_output=True, text=True, timeout=90, cwd=root)
+        except subprocess.TimeoutExpired:
+            pytest.skip('queue evictions stall on this box with IDLE queues as well (control run: no kernel of the library in flight, '
+                        'no result within 90 s): the driver, not the free lists')
+        assert c.returncode == 0, c.stderr[-2000:]
+        pytest.fail('the eviction soak did not finish within 90 s, twice, while the control (same evictor, no kernel of the library '
+                    'in flight) finished: %s' % c.stdout.strip().splitlines()[-1])
     assert p.returncode == 0, p.stderr[-2000:]
     res = json.loads(p.stdout.strip().splitlines()[-1])
     assert res['bad'] == 0, '%d point results differed between repetitions (%d evictions provoked)' % (res['bad'], res['evictions'])
