@@ -145,7 +145,10 @@ int sid_pm_set_points(sid_pm_ctx *ctx, const double *c1, const double *r1, const
  * sid_pm_fetch then - it copies FROM the bound arrays). */
 int sid_pm_bind_results(sid_pm_ctx *ctx, double *d_out, int32_t *d_out_ij);
 
-/* Enqueue the kernels for the resident points on the resident pair (asynchronous). */
+/* Enqueue the kernels for the resident points on the resident pair (asynchronous).  The launches of a run - one per launch class
+ * - follow each other on the handle's stream; a SHORT run (all launches together at most 16 rounds of workgroups: a small batch, or
+ * a rank's shard of an N-GPU run) puts them side by side on three more non-blocking streams the handle owns (created by
+ * sid_pm_create) and joins them on the handle's stream before it returns to it, so the caller sees one stream either way. */
 int sid_pm_run(sid_pm_ctx *ctx);
 /* Wait for the stream; then sid_pm_check. */
 int sid_pm_sync(sid_pm_ctx *ctx);
@@ -194,7 +197,15 @@ int sid_pm_estimate_cost(const double *border, int64_t n, int img_size, int n_an
 #define SID_PM_CLASS_GS     16
 #define SID_PM_CLASS_BIG    32
 #define SID_PM_CLASS_W3B    64
+#define SID_PM_CLASS_LARGE  128  /* beyond one workgroup's LDS (border > 111 px at 34 / 35 px, template side > 64): the point runs the
+                                  * large-window pipeline, one point at a time behind the launches of the others            */
 int sid_pm_estimate_residency(const double *border, int64_t n, int img_size, int n_angles, uint32_t flags, int32_t *launch_class);
+
+/* Estimated kernel time (nanoseconds) of ONE sid_pm_run over points with these borders: the point costs per launch class, the
+ * tail of every launch (its last, half-empty round of workgroups), the launcher's own rule for putting the launches of a short
+ * run side by side (at most 16 rounds of workgroups together), the large-window points behind them.  What the cuts of an N-GPU
+ * split are made with (sea_ice_drift_amd/dist.py): launcher and estimate share the rule, they cannot drift apart.  Host arithmetic. */
+int sid_pm_estimate_run_time(const double *border, int64_t n, int img_size, int n_angles, uint32_t flags, double *time_ns);
 
 /* ---- the per-point functions of the reference as calls of their own ---- */
 

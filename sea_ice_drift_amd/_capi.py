@@ -25,7 +25,7 @@ SYMBOLS = (
     'sid_pm_select_pair', 'sid_pm_bind_pair', 'sid_pm_set_points', 'sid_pm_bind_results', 'sid_pm_run', 'sid_pm_sync', 'sid_pm_check', 'sid_pm_unpermute',
     'sid_pm_fetch', 'sid_pm_device_results', 'sid_pm_work_info', 'sid_pm_debug_point', 'sid_pm_debug_ncc_selftest',
     'sid_pm_debug_rsqrt', 'sid_pm_debug_hypot_selftest', 'sid_pm_estimate_cost', 'sid_pm_estimate_residency',
-    'sid_pm_rotate_and_match', 'sid_pm_get_template', 'sid_pm_get_hessian',
+    'sid_pm_rotate_and_match', 'sid_pm_get_template', 'sid_pm_get_hessian', 'sid_pm_estimate_run_time',
 )
 
 # every symbol include/sid_ft.h declares (feature-tracking matcher, same library)
@@ -107,6 +107,8 @@ def lib():
     L.sid_pm_estimate_cost.argtypes = [_f64p, C.c_int64, C.c_int, C.c_int, C.c_uint32, _f64p]
     L.sid_pm_estimate_residency.argtypes = [_f64p, C.c_int64, C.c_int, C.c_int, C.c_uint32, _i32p]
     L.sid_pm_debug_hypot_selftest.argtypes = [C.c_void_p, C.c_uint64, C.c_int64, C.POINTER(C.c_uint64)]
+    if hasattr(L, 'sid_pm_estimate_run_time'):
+        L.sid_pm_estimate_run_time.argtypes = [_f64p, C.c_int64, C.c_int, C.c_int, C.c_uint32, _f64p]
     if hasattr(L, 'sid_pm_rotate_and_match'):
         L.sid_pm_rotate_and_match.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_int, C.c_int64, C.c_int64, C.c_int64, C.c_int64,
                                               C.c_double, _f64p, _f64p, C.c_int, C.c_uint32, _f64p, _i32p, _f32p, C.c_int64, _u8p]
@@ -140,7 +142,7 @@ def lib():
         L.sid_fg_distance_image.argtypes = [C.c_int, _f64p, C.c_int64, C.c_int64, C.c_int64, _f64p]
     L.sid_fg_last_error.restype = C.c_char_p
     # SID_PM_LIB (A/B runs against the library of an earlier round) may lack the entry points added since
-    optional = ('sid_pm_check', 'sid_pm_unpermute', 'sid_pm_rotate_and_match', 'sid_pm_get_template', 'sid_pm_get_hessian') if os.environ.get('SID_PM_LIB') else ()
+    optional = ('sid_pm_check', 'sid_pm_unpermute', 'sid_pm_rotate_and_match', 'sid_pm_get_template', 'sid_pm_get_hessian', 'sid_pm_estimate_run_time') if os.environ.get('SID_PM_LIB') else ()
     for name in SYMBOLS:
         if name not in optional:
             getattr(L, name)                  # AttributeError here = header/library mismatch
@@ -208,7 +210,16 @@ def estimate_cost(border, img_size=34, n_angles=15, flags=HES_NORM):
     return out
 
 
-CLASS_PER_CU, CLASS_GS, CLASS_BIG = 15, 16, 32          # include/sid_pm.h SID_PM_CLASS_*
+CLASS_PER_CU, CLASS_GS, CLASS_BIG, CLASS_LARGE = 15, 16, 32, 128          # include/sid_pm.h SID_PM_CLASS_*
+
+
+def estimate_run_time(border, img_size=34, n_angles=15, flags=HES_NORM):
+    """Estimated kernel time (ns) of one run over points with these borders (include/sid_pm.h sid_pm_estimate_run_time): point
+    costs, launch tails, the launcher's side-by-side rule, large-window points - host arithmetic of the library."""
+    b = _f64(border).ravel()
+    t = C.c_double(0.0)
+    _check(lib().sid_pm_estimate_run_time(_p(b, _f64p), b.size, int(img_size), int(n_angles), int(flags), C.byref(t)))
+    return t.value
 
 
 def estimate_residency(border, img_size=34, n_angles=15, flags=HES_NORM):

@@ -252,6 +252,17 @@ bool window_dims(double c2fg, double r2fg, double border, int s, int64_t rows2, 
     return true;
 }
 
+// Launches of a SHORT run go side by side on the handle's side streams (sid_pm_run): all launches of the run together are at most
+// kSideRounds rounds of workgroups (SID_PM_SIDE_BY_SIDE=0 / 1: never / always; A/B runs).  ONE rule for the launcher and for
+// the estimate the shard cuts are made with (sid_pm_estimate_run_time).
+constexpr double kSideRounds = 16.0;
+bool side_by_side_rule(size_t n_launches, double rounds)
+{
+    if (n_launches < 2) return false;
+    const char *e = getenv("SID_PM_SIDE_BY_SIDE");
+    return e ? atoi(e) > 0 : rounds <= kSideRounds;
+}
+
 int check_images(const Image &a, const Image &b)
 {
     if (!a.ptr || !b.ptr) return fail(SID_PM_ERR_ARG, "null image pointer");
@@ -962,9 +973,7 @@ SID_EXPORT int sid_pm_run(sid_pm_ctx *ctx)
     if (ctx->buckets.size() > 1) {
         double rounds = 0;
         for (const Bucket &b : ctx->buckets) rounds += (double)b.count / (256.0 * std::max(1, std::min(b.band == 8 ? 2 : 4, blocks_per_cu(b.lds))));
-        constexpr double kSideRounds = 16.0;
-        const char *e = getenv("SID_PM_SIDE_BY_SIDE");
-        side_by_side = e ? atoi(e) > 0 : rounds <= kSideRounds;
+        side_by_side = side_by_side_rule(ctx->buckets.size(), rounds);
     }
     // (SID_PM_SIDE_FIRST=n, experiments: only the first n launches of a long run side by side - the large-window classes, a
     // round or two of workgroups each - then the rest in sequence)
@@ -1432,7 +1441,16 @@ static int estimate_points(const double *border, int64_t n, int img_size, int n_
 {
     if (n < 0 || (n > 0 && (!border || (!cost_ns && !per_cu_out)))) return fail(SID_PM_ERR_ARG, "bad argument");
     const int s = img_size, K = n_angles;
-    if (!sid::mfma_img_size_supported(s) || K < 1) return fail(SID_PM_ERR_UNSUPPORTED, "img_size / angle count not supported");
+    if (s < 2 || s > sid::kLargeMaxSide || K < 1) return fail(SID_PM_ERR_UNSUPPORTED, "img_size / angle count not supported");
+    const bool small_ok = sid::mfma_img_size_supported(s);
+    // a point of the large-window pipeline (pm_large.hip: one point at a time, tiled over the device): ~20 launches of fixed
+    // cost, the matrix instructions of lw_corr, the box sums (profiles/r06_large_window_bench.jsonl: 0.17 / 0.19 / 0.24 ms at
+    // borders 112 / 160 / 250 with 15 angles, 0.27 ms at 100 px; within 30 %)
+    auto large_cost = [&](int wn) {
+        const double r = (double)(wn - s + 1);
+        const double tiles = ceil(r / 64.0) * ceil(r / 16.0) * (double)((K + 15) / 16);
+        return 150000.0 + 10.0 * tiles * (double)(s + 3) * (double)((s + 63) / 64) + 8.0 * (double)s * (double)s;
+    };
     const bool rp = use_rp(s, K);
     const int rpp = rp ? rp_paired(K) : 0;
     const int hws = (int)((double)s / 2.0);
@@ -1455,9 +1473,19 @@ static int estimate_points(const double *border, int64_t n, int img_size, int n_
         if (r < 2) { if (cost_ns) cost_ns[i] = kFixed; continue; }
         double sweep, winner, cls_factor;
         int cls = kMaxPerCu;
+        if (!small_ok) {
+            if (cost_ns) cost_ns[i] = large_cost(wn);
+            if (per_cu_out) per_cu_out[i] = 1 + SID_PM_CLASS_LARGE;
+            continue;
+        }
         if (rp) {
             static const bool no_band8 = getenv("SID_PM_NO_BAND8") != nullptr;
             const ShapeClass sc = shape_class(rp, rpp, wn, wn, s, K, flags, sid::mfma_band8_supported(s) && !no_band8 && !rpp, false);   // (the flags decide the Hessian's LDS: rp_own_hes)
+            if (sc.lds > sid::max_lds_bytes()) {                               // beyond the LDS of one workgroup: the large-window pipeline
+                if (cost_ns) cost_ns[i] = large_cost(wn);
+                if (per_cu_out) per_cu_out[i] = 1 + SID_PM_CLASS_LARGE;
+                continue;
+            }
             const sid::RpLdsLayout L4 = sid::rp_lds_layout(wn, wn, s, K <= sid::kRpGroup, rp_rows(rpp, 4), 0, sid::rp_tab_pitch(rpp), rp_own_hes(K, flags), sc.gs);
             const int per_cu = std::max(1, sc.cls), band = sc.band;            // (big layouts - class 0 - run one workgroup per CU, full table)
             const int rows = sc.big ? 4 : rp_rows(rpp, band), nb = (r + rows - 1) / rows, tiles = 2 * L4.npair + L4.nsingle;
@@ -1471,6 +1499,11 @@ static int estimate_points(const double *border, int64_t n, int img_size, int n_
             cls = std::max(1, std::min(per_cu, max_per_cu(rp, rpp))) + (sc.gs ? 16 : 0) + (sc.big ? 32 : 0) + (sc.w3_pitch > 1104 ? 64 : 0);   // (+ 64: the second launch of the three-wavefront class)   // (+ 16: the launches that keep sum w'^2 in global memory are launches of their own)
         } else {
             const sid::MfmaLdsLayout L = sid::mfma_lds_layout(wn, wn, s, 4, use_paired(K));
+            if (L.total > sid::max_lds_bytes()) {
+                if (cost_ns) cost_ns[i] = large_cost(wn);
+                if (per_cu_out) per_cu_out[i] = 1 + SID_PM_CLASS_LARGE;
+                continue;
+            }
             const int per_cu = blocks_per_cu(L.total), ntx = (r + 15) / 16;
             sweep = groups * (double)r * ntx * s * (use_paired(K) ? 0.55 : 1.0) * 1.3;    // one template row per MFMA
             winner = (double)((r + 15) / 16) * ntx * (16 + s - 1) * 2.0;
@@ -1496,4 +1529,42 @@ SID_EXPORT int sid_pm_estimate_residency(const double *border, int64_t n, int im
 {
     if (n > 0 && !per_cu) return fail(SID_PM_ERR_ARG, "bad argument");
     return estimate_points(border, n, img_size, n_angles, flags, nullptr, per_cu);
+}
+
+// Estimated kernel time of ONE run over these points (nanoseconds): per launch class the sum of the point costs plus the tail of
+// the launch - with 256 x (workgroups per CU) points in flight the last round is half empty on average; the classes with few
+// slots run the large borders, whose run times differ by up to 1.5x inside one launch, and end less evenly (fitted to the
+// shards tools/shard_sim.py measures: 1.0 / 0.7 / 0.5 / 0.5 rounds for 1 / 2 / 3 / 4 workgroups per CU) - a launch shorter than
+// one round still takes a full one; a SHORT run (side_by_side_rule, the launcher's own) ends with ONE tail, the longest, and
+// SID_DIST_TAIL_BLEND (0.7) of the others; the points of the large-window pipeline run one after the other behind the launches.
+SID_EXPORT int sid_pm_estimate_run_time(const double *border, int64_t n, int img_size, int n_angles, uint32_t flags, double *time_ns)
+{
+    if (!time_ns || n < 0 || (n > 0 && !border)) return fail(SID_PM_ERR_ARG, "bad argument");
+    *time_ns = 0.0;
+    if (n == 0) return SID_PM_OK;
+    std::vector<double> cost((size_t)n);
+    std::vector<int32_t> cls((size_t)n);
+    if (int rc = estimate_points(border, n, img_size, n_angles, flags, cost.data(), cls.data())) return rc;
+    struct Part { double sum = 0, count = 0; };
+    Part parts[256];
+    for (int64_t i = 0; i < n; ++i) { Part &p = parts[cls[(size_t)i] & 255]; p.sum += cost[(size_t)i]; p.count += 1; }
+    static const double kTail[5] = {0.5, 1.0, 0.7, 0.5, 0.5};
+    const char *be = getenv("SID_DIST_TAIL_BLEND");
+    const double blend = be ? atof(be) : 0.7;
+    double large = 0, sum_all = 0, rounds = 0, tail_max = 0, tail_sum = 0, lat_max = 0, seq = 0;
+    size_t nparts = 0;
+    for (int c = 0; c < 256; ++c) {
+        const Part &p = parts[c];
+        if (p.count == 0) continue;
+        if (c & SID_PM_CLASS_LARGE) { large += p.sum; continue; }
+        const int per_cu = std::max(1, c & SID_PM_CLASS_PER_CU);
+        const double latency = 256.0 * per_cu * (p.sum / p.count), tail = kTail[std::min(per_cu, 4)] * latency;
+        ++nparts; sum_all += p.sum; rounds += p.count / (256.0 * per_cu);
+        tail_max = std::max(tail_max, tail); tail_sum += tail; lat_max = std::max(lat_max, latency);
+        seq += std::max(p.sum + tail, latency);
+    }
+    double t = seq;
+    if (side_by_side_rule(nparts, rounds)) t = std::max(sum_all + tail_max + blend * (tail_sum - tail_max), lat_max);
+    *time_ns = t + large;
+    return SID_PM_OK;
 }

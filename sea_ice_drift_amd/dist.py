@@ -26,35 +26,16 @@ def point_cost(border, img_size=34, n_angles=15, flags=1):
     return _capi.estimate_cost(np.asarray(border, dtype=np.float64), img_size, n_angles, flags)
 
 
-# tail of a launch in run times of one of its workgroups, by residency class (workgroups per CU): with 256 x class points in
-# flight the last round is half empty on average; the classes with few slots run the large borders, whose run times differ by
-# up to 1.5x inside one launch, and end less evenly.  Fitted to the shards tools/shard_sim.py measures on the GPU
-# (8 shards of the benchmark grid: 0.5 everywhere left the one-per-CU shard 6.5 % and the mixed one 7.4 % above the others).
-_TAIL_ROUNDS = {1: 1.0, 2: 0.7, 3: 0.5, 4: 0.5}
-_SIDE_TAIL_BLEND = float(os.environ.get('SID_DIST_TAIL_BLEND', '0.7'))   # share of the shorter tails a side-by-side run still pays (fitted: tools/shard_sim.py)
-_SIDE_BY_SIDE_ROUNDS = 16.0        # pm_capi.hip kSideRounds: runs of at most this many rounds of workgroups launch their classes side by side
-
-
-def _shard_times(cost, cls, cuts):
-    """Estimated kernel time of every shard [cuts[r], cuts[r+1]) of the border-ordered points: per launch class the sum of
-    the point costs plus the tail of the launch (``_TAIL_ROUNDS`` x the run time of a workgroup = slots x mean cost); a launch
-    shorter than one round still takes a full one."""
+def _shard_times(border_sorted, cuts, img_size=34, n_angles=15, flags=1):
+    """Estimated kernel time of every shard [cuts[r], cuts[r+1]) of the border-ordered points: the LIBRARY's estimate of one run
+    over the shard's points (include/sid_pm.h ``sid_pm_estimate_run_time``: point costs per launch class, launch tails, the
+    launcher's own rule for side-by-side launches, large-window points) - the rule lives in one place, next to the launcher."""
+    from . import _capi
     t = np.zeros(len(cuts) - 1)
     for r in range(len(cuts) - 1):
         a, b = cuts[r], cuts[r + 1]
-        parts = []
-        for c in np.unique(cls[a:b]):                               # one launch per class (residency | 16 x global sums)
-            sel = cost[a:b][cls[a:b] == c]
-            per_cu = int(c) & 15
-            latency = 256.0 * per_cu * sel.mean()
-            parts.append((sel.sum(), _TAIL_ROUNDS.get(per_cu, 0.5) * latency, latency, sel.size / (256.0 * per_cu)))
-        if len(parts) > 1 and sum(p[3] for p in parts) <= _SIDE_BY_SIDE_ROUNDS:
-            # the launches of a short run go side by side (sid_pm_run, round 5): the next launch fills the CUs the previous one
-            # drains, so the run ends with ONE tail - the longest - instead of one per launch
-            tails = sorted(p[1] for p in parts)
-            t[r] = max(sum(p[0] for p in parts) + tails[-1] + _SIDE_TAIL_BLEND * sum(tails[:-1]), max(p[2] for p in parts))
-        else:
-            t[r] = sum(max(p[0] + p[1], p[2]) for p in parts)
+        if b > a:
+            t[r] = _capi.estimate_run_time(border_sorted[a:b], img_size, n_angles, flags)
     return t
 
 
@@ -70,20 +51,18 @@ def shard_cuts_by_cost(border, world_size, img_size=34, n_angles=15, flags=1):
     Every rank's kernels must finish before the gather can complete, so the step time is the slowest rank's kernel time
     plus the exchange step; shortening rank 0's shard would not hide the exchange (it starts when the LAST rank is done).
     Pure function of its arguments: every rank computes the same cuts."""
-    from . import _capi
     border = np.asarray(border)
     order = np.argsort(-border, kind='stable')
     n = order.size
     if n == 0 or world_size <= 1:
         return order, np.array([0] + [n] * max(world_size, 1), dtype=np.int64), np.zeros(n)
     cost = point_cost(border[order], img_size, n_angles, flags)          # (flags of the run: sid_pm.h SID_PM_HES_NORM = 1 ...)
-    cls = _capi.estimate_residency(border[order], img_size, n_angles, flags)
     cum = np.concatenate([[0.0], np.cumsum(cost)])
     share = np.full(world_size, cum[-1] / world_size)               # cost each shard is to hold
     best_cuts, best = None, np.inf
     for _ in range(24):                                             # move cost from the slow shards to the fast ones
         cuts = _cuts_for_shares(cost, cum, share)
-        t = _shard_times(cost, cls, cuts)
+        t = _shard_times(border[order], cuts, img_size, n_angles, flags)
         if t.max() < best:
             best, best_cuts = t.max(), cuts
         share = np.maximum(share + 0.7 * (t.mean() - t), 0.0)

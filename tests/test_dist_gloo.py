@@ -67,7 +67,7 @@ def test_cost_shards_partition_and_balance():
         cuts = np.concatenate([[0], np.cumsum([len(p) for p in parts])])
         for r, p in enumerate(parts):                                         # shard r = the r-th run of the border order
             np.testing.assert_array_equal(np.sort(order[cuts[r]:cuts[r + 1]]), p)
-        t = _shard_times(point_cost(border[order]), _capi.estimate_residency(border[order]), cuts)
+        t = _shard_times(border[order], cuts)
         assert t.max() / t.min() < 1.02
         cost = [point_cost(border[p]).sum() for p in parts]
         # (at 8 shards the rank with the largest borders runs two launches of few slots - one workgroup per CU, two per CU -
