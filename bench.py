@@ -186,22 +186,14 @@ class GridRun(object):
 
     def rebalance(self, rounds):
         """Measured feedback on the cuts (N > 1): the estimate prices a launch as cost + tail and leaves the slowest of eight
-        shards ~4 % above the mean; here every rank times its own kernels, one all_gather makes the
-        times known everywhere, ``dist.rebalance_cuts`` moves the cuts, and the cuts with the smallest slowest rank are kept.
-        Set-up work, before the warm-up; a fixed number of rounds, the same collectives on every rank."""
-        from sea_ice_drift_amd.dist import per_rank_breakdown, rebalance_cuts
-        import numpy as np
-        history, best = [], (float('inf'), self.cuts)
-        for it in range(rounds + 1):
-            t = per_rank_breakdown([self.kernel_ms()], self.dev)[:, 0]
-            history.append({'points': np.diff(self.cuts).tolist(), 'kernel_ms': [round(float(v), 4) for v in t]})
-            if t.max() < best[0]:
-                best = (float(t.max()), self.cuts)
-            if it < rounds:
-                self.reshard(rebalance_cuts(self.cost, self.cuts, t))
-        if best[1] is not self.cuts:
-            self.reshard(best[1])
-        return {'rounds': rounds, 'kept_slowest_kernel_ms': best[0], 'history': history}
+        shards ~4 % above the mean; ``dist.rebalance_with_feedback`` - a public helper of the library's
+        N-GPU path, not a benchmark-only trick - has every rank time its own kernels, makes the times known everywhere with one
+        all_gather per round (a rank whose kernels failed still takes part, then every rank raises), moves the cuts and keeps
+        the ones with the smallest slowest rank.  Set-up work, before the warm-up."""
+        from sea_ice_drift_amd.dist import rebalance_with_feedback
+        res = rebalance_with_feedback(self.kernel_ms, self.reshard, self.cost, self.cuts, rounds, self.dev)
+        res.pop('cuts')
+        return res
 
     def step(self, ev=None):
         if ev is not None:

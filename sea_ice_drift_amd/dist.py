@@ -113,7 +113,11 @@ def rebalance_cuts(cost, cuts, measured, damping=0.6):
     target = _cuts_for_shares(w, cum, np.full(world, cum[-1] / world))
     new = np.rint(cuts + damping * (target - cuts)).astype(np.int64)
     new[0], new[-1] = 0, cost.size
-    return np.maximum.accumulate(new)                               # (monotone: an empty shard is legal, a negative one is not)
+    new = np.maximum.accumulate(new)
+    if cost.size >= world:                                          # every rank keeps at least one point (an empty shard times as
+        new = np.maximum(new, np.arange(world + 1))                 # ~0 ms and would drag the next round's cuts towards it)
+        new = np.minimum(new, cost.size - (world - np.arange(world + 1)))
+    return new
 
 
 class PackedGatherer(object):
@@ -314,3 +318,37 @@ def per_rank_breakdown(values, device, group=None):
     rows = [torch.empty_like(mine) for _ in range(world)]
     dist.all_gather(rows, mine, group=group)
     return torch.stack(rows).cpu().numpy()
+
+
+
+def rebalance_with_feedback(measure_ms, reshard, cost, cuts, rounds, device, group=None):
+    """Measured feedback on the shard cuts, as a collective-safe loop (used by bench.py --gpus N; any N-GPU caller can).
+
+    ``measure_ms()``  -> this rank's kernel milliseconds with the current cuts (may raise: a refused point, a HIP error);
+    ``reshard(cuts)`` -> make this rank run its shard under ``cuts`` (every rank is called with the same cuts).
+    Every round is ONE all_gather of (time, ok): a rank whose measurement raised still takes part in the collective - with
+    ok = 0 - and then EVERY rank raises, instead of one rank raising while the others block in the all_gather for ever.
+    ``rounds`` rounds of ``rebalance_cuts``; the cuts with the smallest slowest rank are kept.  A pure function of the gathered
+    times on every rank.  Returns dict(cuts, rounds, kept_slowest_kernel_ms, history)."""
+    history, best = [], (float('inf'), cuts)
+    for it in range(rounds + 1):
+        err = None
+        try:
+            mine = float(measure_ms())
+        except Exception as e:                                       # noqa: reported after the collective
+            err, mine = e, float('nan')
+        both = per_rank_breakdown([mine, 0.0 if err is not None else 1.0], device, group)
+        if not (both[:, 1] > 0.5).all():
+            bad = [int(r) for r in np.flatnonzero(both[:, 1] <= 0.5)]
+            raise RuntimeError('rebalance round %d: the kernels of rank(s) %s failed%s' % (it, bad, ': %s' % err if err is not None else ''))
+        t = both[:, 0]
+        history.append({'points': np.diff(cuts).tolist(), 'kernel_ms': [round(float(v), 4) for v in t]})
+        if t.max() < best[0]:
+            best = (float(t.max()), cuts)
+        if it < rounds:
+            cuts = rebalance_cuts(cost, cuts, t)
+            reshard(cuts)
+    if best[1] is not cuts:
+        cuts = best[1]
+        reshard(cuts)
+    return {'cuts': cuts, 'rounds': rounds, 'kept_slowest_kernel_ms': best[0], 'history': history}

@@ -5,6 +5,7 @@ import os
 import socket
 
 import numpy as np
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -138,3 +139,64 @@ def test_eight_rank_gather_roundtrip_with_unequal_shards():
     res = _roundtrip(8, 6007)
     lens = [r[1] for r in sorted(res)]
     assert max(lens) > 1.5 * min(lens)                            # unequal on purpose
+
+
+def _feedback_worker(rank, world, port, fail_rank, q):
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from sea_ice_drift_amd.dist import rebalance_with_feedback, shard_cuts_by_cost
+        border = np.repeat(np.arange(20.0, 51.0), 40)
+        order, cuts, cost = shard_cuts_by_cost(border, world)
+        state = {'cuts': cuts, 'calls': 0}
+
+        def measure():
+            state['calls'] += 1
+            if rank == fail_rank and state['calls'] == 2:
+                raise RuntimeError('a refused point on rank %d' % rank)
+            a, b = state['cuts'][rank], state['cuts'][rank + 1]
+            return float(cost[a:b].sum()) * (1.3 if rank == 0 else 1.0) + 5e4   # rank 0's device is slower than the estimate says
+
+        def reshard(c):
+            state['cuts'] = c
+        try:
+            res = rebalance_with_feedback(measure, reshard, cost, cuts, 3, 'cpu')
+            q.put((rank, 'ok', [h['kernel_ms'] for h in res['history']], np.diff(res['cuts']).tolist()))
+        except RuntimeError as e:
+            q.put((rank, 'raised', str(e), None))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('fail_rank', [-1, 1])
+def test_measured_feedback_is_collective_safe(fail_rank):
+    """``dist.rebalance_with_feedback`` on two gloo ranks: without a failure the slowest rank gets faster and no shard is empty;
+    when ONE rank's measurement raises, EVERY rank raises after the round's all_gather - none is left blocking in it."""
+    world = 2
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_feedback_worker, args=(r, world, port, fail_rank, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    if fail_rank < 0:
+        assert all(r[1] == 'ok' for r in res)
+        hist = res[0][2]
+        assert hist == res[1][2]                                   # the same numbers on every rank
+        assert max(hist[-1]) < max(hist[0]) and min(res[0][3]) >= 1
+    else:
+        assert all(r[1] == 'raised' for r in res), res
+        assert 'rank(s) [1]' in res[0][2] and 'rank(s) [1]' in res[1][2]
+
+
+def test_rebalance_cuts_keep_every_shard_non_empty():
+    cost = np.ones(10)
+    cuts = np.array([0, 3, 6, 10])
+    new = rebalance_cuts(cost, cuts, np.array([1e-9, 1.0, 1.0]), damping=1.0)    # rank 0 measured ~nothing: it would be given everything
+    assert (np.diff(new) >= 1).all() and new[0] == 0 and new[-1] == 10
