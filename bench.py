@@ -78,6 +78,7 @@ def parse_args(argv=None):
                     help='N > 1, strong scaling: rounds of measured feedback on the shard cuts BEFORE the warm-up (every rank times '
                          'its kernels over 3 steps, one all_gather, dist.rebalance_cuts; the cuts with the smallest slowest rank are kept); 0 = the estimated cuts')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-seam', action='store_true', help="skip the seam-inclusive timings (sid_pm_batch host-in / host-out, set_points) reported under 'seam_inclusive'")
     ap.add_argument('--no-also-defaults', action='store_true',
                     help="N = 1, grid mode: skip the second measurement on the reference's DEFAULT configuration (img_size 35, "
                          "angles [-3, 0, 3]; pmlib.py:118,329) that is reported under 'reference_defaults'")
@@ -361,6 +362,48 @@ def parity_block(args, img1, img2, g, n_total, res, res_ij, angles, rot, s, orac
                                   'min_positive_gap': float(gap[(gap > 0) & fin].min()) if ((gap > 0) & fin).any() else None}}
 
 
+def seam_inclusive(args, img1, img2, g, s, angles, rot, local_rank, res, res_ij):
+    """SURVEY.md section 8(d) defines the metric 'from entering the dispatch'; the headline `value` starts with the pair, the point
+    records and the sampling tables resident in HBM (the contract's rule for `value`).  Here is what lies before that, timed on
+    the same workload, host buffers in / host buffers out - reported beside `value`, never as it:
+      sid_pm_batch_ms            the one-shot C call (include/sid_pm.h): create a handle, upload the pair (2 x 100 MB over PCIe from
+                                 pageable memory), set_points (validate, classify, one upload), the kernels, fetch, destroy
+      dispatch_resident_pair_ms  handle and pair resident (what pattern_matching pays per call once its upload is done):
+                                 set_points + run + fetch
+      set_points_ms              set_points alone (host classification of the points + uploads of records and tables)"""
+    import numpy as np
+    from sea_ice_drift_amd import _capi
+    v = [g[k] for k in ('c1', 'r1', 'c2fg', 'r2fg', 'border')]
+    n = len(v[0])
+
+    def med(fn, reps=3):
+        fn()
+        t = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            out = fn()
+            t.append((time.perf_counter() - t0) * 1e3)
+        return float(np.median(t)), out
+    batch_ms, (out, ij) = med(lambda: _capi.pm_batch(img1, img2, *v, s, 0.0, angles, rot=rot))
+    same = bool(np.array_equal(out, res, equal_nan=True) and np.array_equal(ij, res_ij))
+    with _capi.PMContext(local_rank) as ctx:
+        ctx.upload_pair(img1, img2)
+        ctx.sync()
+        sp_ms, _ = med(lambda: ctx.set_points(*v, s, 0.0, angles, rot=rot))
+
+        def dispatch():
+            ctx.set_points(*v, s, 0.0, angles, rot=rot)
+            ctx.run()
+            return ctx.fetch()
+        disp_ms, _ = med(dispatch)
+    return {'sid_pm_batch_ms': batch_ms, 'sid_pm_batch_points_per_s': n / (batch_ms * 1e-3),
+            'dispatch_resident_pair_ms': disp_ms, 'dispatch_resident_pair_points_per_s': n / (disp_ms * 1e-3),
+            'set_points_ms': sp_ms, 'equals_the_resident_results': same,
+            'what': 'host buffers in / host buffers out, median of 3 calls after one untimed call; sid_pm_batch = create + upload of the '
+                    '%d MB pair from pageable memory + set_points + kernels + fetch + destroy (SURVEY.md 8(d): from entering the dispatch); '
+                    'never `value`' % (2 * img1.size // 1000000)}
+
+
 def grid_mode(args, torch, dist, dev, world, rank, local_rank):
     import numpy as np
     from sea_ice_drift_amd import synthetic as syn
@@ -483,6 +526,8 @@ def grid_mode(args, torch, dist, dev, world, rank, local_rank):
     # driver run); its oracle comparison follows after the baselines.
     also_defaults = world == 1 and not args.no_also_defaults and not args.force_collective and args.img_size == 34 and args.angles == 7
     defaults_run = defaults_timed(args, torch, dist, dev, local_rank, t1, t2) if also_defaults else None
+    if world == 1 and not args.force_collective and not args.no_seam:
+        line['seam_inclusive'] = seam_inclusive(args, img1, img2, g, s, angles, rot, local_rank, res, res_ij)
     oracle_run = None
     if not args.no_cpu_baseline:
         line['cpu_baseline'], oracle_run = cpu_baselines(args, img1, img2, g, n_total, angles, rot, s)
@@ -614,9 +659,22 @@ def stream_mode(args, torch, dist, dev, world, rank, local_rank):
                     results[p] = ctx.fetch()
 
     run = Run()
-    elapsed, kern_ms = timed_steps(torch, dist, world, run, args.steps, args.warmup)
+    elapsed, kern_first_ms = timed_steps(torch, dist, world, run, args.steps, args.warmup)
+    # the kernels of ONE pair in steady state: both slots uploaded, nothing for the launches to wait for (the events around
+    # the first pair of a step also hold that pair's wait for its own upload - reported as kernel_ms_first_pair_incl_upload_wait)
+    ctx.sync()
+    torch.cuda.synchronize()
+    ka, kb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ctx.run()
+    ka.record()
+    for _ in range(3):
+        ctx.run()
+    kb.record()
+    kb.synchronize()
+    ctx.check()
+    kern_ms = ka.elapsed_time(kb) / 3.0
     from sea_ice_drift_amd.dist import per_rank_breakdown
-    per_rank = per_rank_breakdown([timed_steps.local_elapsed / args.steps * 1e3, kern_ms, len(mine)], dev) if world > 1 else None
+    per_rank = per_rank_breakdown([timed_steps.local_elapsed / args.steps * 1e3, kern_first_ms, len(mine)], dev) if world > 1 else None
     line = None
     # parity: up to three pairs of this rank against the oracle on a subsample (checker only)
     ok, checked = True, 0
@@ -653,9 +711,10 @@ def stream_mode(args, torch, dist, dev, world, rank, local_rank):
                        'parallelism': 'pairs dealt round-robin to %d GPU(s); no collective on the data path' % world},
             'roofline': {'bound': 'mfma', 'achieved': 2.0 * info['macs'] / (kern_ms * 1e-3) / 1e12, 'peak': MFMA_I8_PEAK_TOPS,
                          'unit': 'TFLOP/s', 'frac': 2.0 * info['macs'] / (kern_ms * 1e-3) / 1e12 / MFMA_I8_PEAK_TOPS,
-                         'traffic': None, 'kernel_ms_per_pair': kern_ms,
-                         'note': 'kernels of the first pair of every step (HIP events on the launch stream); the step time '
-                                 'also holds the 200 MB H2D upload of every pair, overlapped'},
+                         'traffic': None, 'kernel_ms_per_pair': kern_ms, 'kernel_ms_first_pair_incl_upload_wait': kern_first_ms,
+                         'note': 'kernels of one pair in steady state (HIP events on the launch stream around 3 runs on a resident pair after the '
+                                 'timed steps: nothing to wait for); the step time also holds the 200 MB H2D upload of every pair, overlapped - '
+                                 'ms_per_pair above is the streaming rate, bound by the uploads when they take longer than the kernels'},
             'parity_check': {'pairs_checked_per_rank': checked, 'ok': ok},
             'setup_s': {'generate_and_pin_pairs': t_gen},
         }

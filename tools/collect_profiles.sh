@@ -8,8 +8,8 @@ OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 # HBM traffic first: bench.py quotes profiles/traffic.json and checks that it was collected on the library it runs
-rocprofv3 --pmc FETCH_SIZE -d /tmp/pf_$TAG -o pf -- python3 $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-also-defaults --check 0 > /dev/null 2>&1
-rocprofv3 --pmc WRITE_SIZE -d /tmp/pw_$TAG -o pw -- python3 $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-also-defaults --check 0 > /dev/null 2>&1
+rocprofv3 --pmc FETCH_SIZE -d /tmp/pf_$TAG -o pf -- python3 $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-also-defaults --no-seam --check 0 > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE -d /tmp/pw_$TAG -o pw -- python3 $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-also-defaults --no-seam --check 0 > /dev/null 2>&1
 python3 $R/tools/pmc_traffic.py $(find /tmp/pf_$TAG -name "*.db" | head -1) $(find /tmp/pw_$TAG -name "*.db" | head -1) pm_kernel > $OUT/pmc_traffic.json
 python3 - "$OUT/pmc_traffic.json" "$R" > $OUT/traffic.json <<'PY'
 import hashlib, json, sys
@@ -40,12 +40,17 @@ python3 $R/bench.py --mode stream --pairs 16 --steps 2 --warmup 1 --check 32 > $
 python3 $R/bench.py --gpus 2 --steps 5 --warmup 1 --no-cpu-baseline > $OUT/dryrun_2ranks_1gpu.json 2>> $OUT/bench.err
 python3 $R/bench.py --gpus 1 --force-collective --steps 20 --warmup 3 --no-cpu-baseline > $OUT/force_collective_rccl_1gpu.json 2>> $OUT/bench.err
 timeout 300 python3 $R/bench.py --mode ftpm --check 400 > $OUT/ftpm_bench.json 2>> $OUT/bench.err
-rocprofv3 --kernel-trace --stats -d /tmp/kt_$TAG -o kt -- python3 $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-also-defaults --check 0 > /dev/null 2>&1
-python3 $R/tools/rocpd_summary.py $(find /tmp/kt_$TAG -name "*.db" | head -1) > $OUT/kernel_trace_stats.txt
-rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU -d /tmp/p1_$TAG -o p1 -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-also-defaults --check 0 > /dev/null 2>&1
-rocprofv3 --pmc SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_LDS -d /tmp/p2_$TAG -o p2 -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-also-defaults --check 0 > /dev/null 2>&1
-rocprofv3 --pmc SQ_VALU_MFMA_COEXEC_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_CYCLES -d /tmp/p3_$TAG -o p3 -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-also-defaults --check 0 > /dev/null 2>&1
-rocprofv3 --pmc SQC_ICACHE_REQ SQC_ICACHE_MISSES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE -d /tmp/p4_$TAG -o p4 -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-also-defaults --check 0 > /dev/null 2>&1
+# kernel trace over 25 steps, stats over the last 20 (5 warm-up steps: the clocks ramp over the first dispatches), so that the
+# sum of the average launch durations can be held against bench.py's kernel_ms_per_step of the SAME run (printed into the file)
+rocprofv3 --kernel-trace --stats -d /tmp/kt_$TAG -o kt -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-also-defaults --no-seam --check 0 > $OUT/kernel_trace_bench.json 2>/dev/null
+python3 $R/tools/rocpd_summary.py $(find /tmp/kt_$TAG -name "*.db" | head -1) pm_kernel --window 5 20 > $OUT/kernel_trace_stats.txt
+python3 -c "
+import json; d = json.load(open('$OUT/kernel_trace_bench.json'))
+print('# bench.py of the SAME traced run: ms_per_step %.4f, kernel_ms_per_step (HIP events over the 20 timed steps) %.4f' % (d['ms_per_step'], d['roofline']['kernel_ms_per_step']))" >> $OUT/kernel_trace_stats.txt
+rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU -d /tmp/p1_$TAG -o p1 -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-also-defaults --no-seam --check 0 > /dev/null 2>&1
+rocprofv3 --pmc SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_LDS -d /tmp/p2_$TAG -o p2 -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-also-defaults --no-seam --check 0 > /dev/null 2>&1
+rocprofv3 --pmc SQ_VALU_MFMA_COEXEC_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_CYCLES -d /tmp/p3_$TAG -o p3 -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-also-defaults --no-seam --check 0 > /dev/null 2>&1
+rocprofv3 --pmc SQC_ICACHE_REQ SQC_ICACHE_MISSES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE -d /tmp/p4_$TAG -o p4 -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-also-defaults --no-seam --check 0 > /dev/null 2>&1
 for p in p1 p2 p3 p4; do python3 $R/tools/rocpd_summary.py $(find /tmp/${p}_$TAG -name "*.db" | head -1) | sed -n '/PMC per dispatch/,$p' >> $OUT/pmc_counters.txt; done
 timeout 200 python3 $R/tools/e2e_bench.py > $OUT/e2e_pattern_matching.json 2>> $OUT/bench.err
 ls -la $OUT
