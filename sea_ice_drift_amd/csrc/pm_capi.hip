@@ -52,7 +52,7 @@ struct Image {
     int64_t rows = 0, cols = 0, stride = 0;
 };
 
-struct Bucket { int offset, count, lds, band, pitch, occ; uint32_t gs_stride = 0; bool big = false; bool keep = false; };   // keep: the launch keeps the sweep's accumulators (PMArgs::gs_keep_acc) and takes recycled blocks   // gs_stride: largest sum w'^2 block of the launch's points, in u32 entries (gs launches; 0 otherwise)   // occ: wavefronts per SIMD of the kernel build (3; 4: the four-per-CU class of the slot-group layouts); band: output rows per sweep work item of this launch (4 or 8); pitch: compile-time window pitch of the row-pair kernel (0: run-time)
+struct Bucket { int offset, count, lds, band, pitch, occ; uint32_t gs_stride = 0; bool big = false; bool keep = false; bool pooled = false; };   // pooled: the launch takes its blocks of global memory from the free lists (PMArgs::ring)   // keep: the launch keeps the sweep's accumulators (PMArgs::gs_keep_acc) and takes recycled blocks   // gs_stride: largest sum w'^2 block of the launch's points, in u32 entries (gs launches; 0 otherwise)   // occ: wavefronts per SIMD of the kernel build (3; 4: the four-per-CU class of the slot-group layouts); band: output rows per sweep work item of this launch (4 or 8); pitch: compile-time window pitch of the row-pair kernel (0: run-time)
 
 template <typename T>
 struct DevBuf {
@@ -221,6 +221,7 @@ void make_samp2(const std::vector<uint16_t> &tab, int K, int s, std::vector<uint
 // workgroups of four wavefronts a CU takes at the kernels' register budget (3 wavefronts per SIMD): launch classes beyond
 // this differ in nothing.  The row-pair kernel's slot-group layouts (<= 7 angles) have a 128-VGPR build as well, for the
 // borders whose LDS footprint fits four times (SID_PM_NO_OCC4=1: off; A/B runs).
+constexpr bool kRecycleAllDefault = true;    // (round 6: -1.0 % on the 15-angle step, HBM traffic 12.7x -> 10.1x the algorithmic bytes: profiles/r06_ab_recycle_all.txt)
 constexpr int kMaxPerCu = 3;
 constexpr int kW3MaxLds = 40960;   // every window of pitch 104 that fits four times (borders 20 .. 23 at 34 / 35 px; measured per border: tools/r4_w3.sh)
 // four workgroups per CU need the 128-VGPR build of the row-pair kernel (pm_kernel_rp_occ4.hip): the slot-group layouts only.
@@ -462,7 +463,7 @@ int classify_points(sid_pm_ctx *ctx)
     static const bool no_fixed_pitch = getenv("SID_PM_NO_FIXED_PITCH") != nullptr;         // (run-time pitch everywhere: gs instantiations; A/B runs)
     // Everything the launch needs to know about a point follows from the SHAPE of its search window, and a run has a few
     // dozen shapes (one per border): the LDS layouts are evaluated per shape, the points are only binned.
-    struct Shape { int wh, ww, lds, band, cls, nat_pitch, pitch; double work; std::vector<int32_t> idx; bool gs = false, big = false; int w3p = 0; bool keep = false; bool large = false; };
+    struct Shape { int wh, ww, lds, band, cls, nat_pitch, pitch; double work; std::vector<int32_t> idx; bool gs = false, big = false; int w3p = 0; bool keep = false; bool large = false; bool pooled = false; };
     std::vector<Shape> shapes;
     std::vector<int32_t> slot_of((size_t)1 << 16, -1);                // (wh, ww) -> shape, direct-mapped on a hash of the pair
     auto find_shape = [&](int wh, int ww) -> int {
@@ -563,6 +564,14 @@ int classify_points(sid_pm_ctx *ctx)
         }
     }
     for (Shape &sh : shapes) sh.keep = rp && sh.wh > 0 && keep_acc_launch(ctx, sh.gs, sh.big, sh.cls);   // (the launch class is final here)
+    // Recycled blocks (PMArgs::ring): the launches that keep accumulators always (their blocks are 3 - 5x larger); the others that
+    // keep per-placement tables in global memory with SID_PM_RECYCLE_ALL != 0 (SID_PM_NO_RECYCLE=1: a block per launch position everywhere)
+    {
+        const bool recycle = getenv("SID_PM_NO_RECYCLE") == nullptr;
+        const char *ra = getenv("SID_PM_RECYCLE_ALL");
+        const bool recycle_all = ra ? atoi(ra) != 0 : kRecycleAllDefault;
+        for (Shape &sh : shapes) sh.pooled = rp && sh.wh > 0 && sh.gs && !sh.big && recycle && (sh.keep || recycle_all);
+    }
     // XCD-aware launch order.  Workgroup j of a launch runs on XCD j mod 8 and every XCD has its own L2, so
     // within a run of points of equal class and work (= equal border: the order there is the caller's, i.e.
     // spatial for a grid) the run is cut into 8 contiguous chunks and chunk c goes to the XCD of slot
@@ -595,7 +604,7 @@ int classify_points(sid_pm_ctx *ctx)
                                           (rp && first.cls >= 4 && sid::rp_pitch_instantiated(first.band, rpp, first.pitch, 4)) ? 4 : 3});
         ctx->info[5] = (double)first.cls;                             // (class of the bucket being filled)
         Bucket &bk = ctx->buckets.back();
-        bk.big = first.big; bk.keep = first.keep;
+        bk.big = first.big; bk.keep = first.keep; bk.pooled = first.pooled;
         bk.count += (int)src->size();
         bk.lds = std::max(bk.lds, lds_run);
         if (rp && first.gs)                                           // (launches that keep sum w'^2 in global memory: the largest block)
@@ -623,15 +632,14 @@ int classify_points(sid_pm_ctx *ctx)
     std::vector<uint32_t> goff;
     uint64_t gsii_granules = 0;
     if (rp) {
-        // Launches that keep accumulators take their blocks from the per-XCD free lists (PMArgs::ring): kPoolBlocks blocks (512 per
+        // Launches that keep accumulators take their blocks from the per-XCD free lists (PMArgs::ring): kPoolBlocks blocks (1024 per
         // XCD) of the largest such block, whatever the number of points (SID_PM_NO_RECYCLE=1: a block per launch position, as the others)
-        const bool recycle = ctx->gs_keep_acc && getenv("SID_PM_NO_RECYCLE") == nullptr;
         uint32_t stride = 0;
         std::vector<uint32_t> gran_shape(shapes.size(), 0u);
         for (size_t k = 1; k < shapes.size(); ++k) {
             const Shape &sh = shapes[k];
             if (sh.big) gran_shape[k] = (uint32_t)(big_layout(sh.wh, sh.ww, s, K, flags).big_bytes / 256);
-            else if (sh.gs && sh.keep && recycle) stride = std::max(stride, block_entries(ctx, sh.wh, sh.ww, sh.band, true));
+            else if (sh.pooled) stride = std::max(stride, block_entries(ctx, sh.wh, sh.ww, sh.band, sh.keep));
             else if (sh.gs) gran_shape[k] = block_entries(ctx, sh.wh, sh.ww, sh.band, sh.keep) / 64u;
         }
         ctx->pool_stride = stride;
@@ -1007,7 +1015,7 @@ SID_EXPORT int sid_pm_run(sid_pm_ctx *ctx)
         A.rec = ctx->d_rec.p ? ctx->d_rec.p + b.offset : nullptr;
         A.n_launch = b.count;
         A.gs_keep_acc = b.keep ? 1u : 0u;
-        A.ring = (b.keep && ctx->pool_stride) ? ctx->ring.p : nullptr;
+        A.ring = (b.pooled && ctx->pool_stride) ? ctx->ring.p : nullptr;
         const int lds_launch = std::min(b.lds, sid::max_lds_bytes());
         A.lds_bytes = lds_launch;
         // 256 threads per point; 768 when the LDS footprint leaves room for one point per CU only, so that

@@ -66,7 +66,7 @@ struct PMArgs {
     // Round 6: the lists are BITMAPS - kRingWordsPerXcd 64-bit words per XCD, a set bit = a free block - and no operation ever
     // waits for another workgroup: pop = one atomic AND that clears the lowest set bit of the popper's home word (found in a
     // copy read first thing in the kernel; the AND's return value tells whether the bit was still there, and is the fresh copy
-    // for the next try if not), then the XCD's other words, then - all of them empty: four times what an XCD holds resident
+    // for the next try if not), then the XCD's other words, then - all of them empty: eight times what an XCD holds resident
     // would have to be in flight - the point is refused (PMArgs::refused: an error, never a hang); push = one atomic OR without
     // a return value.  Round 5's ticket ring committed a popper to ONE future push: a workgroup that was context-saved (queue
     // eviction) between taking its ticket and reading its entry found the entry overwritten by the pushes of a whole lap when it
@@ -90,8 +90,9 @@ __host__ __device__ inline int round_up(int v, int m) { return (v + m - 1) / m *
 constexpr int kMiscMfmaBytes = 2688;
 constexpr int kTrowPad = 36;         // zero rows around a winner operand block: 16 above, 20 below (the step loop runs in fours)
 constexpr int kQueueCap = 192;       // arg-max candidates waiting for exact evaluation (16 B each)
-constexpr int kRingWordsPerXcd = 8, kRingHomeWords = 4;    // bitmap words per XCD (PMArgs::ring); a workgroup's home word is one of the first kRingHomeWords, by launch position
-constexpr int kPoolBlocks = 8 * kRingWordsPerXcd * 64;     // 512 blocks per XCD: four times what an XCD holds resident
+constexpr int kRingWordsPerXcd = 16, kRingHomeWords = 4;    // bitmap words per XCD (PMArgs::ring); a workgroup's home word is one of the first kRingHomeWords, by launch position
+constexpr int kPoolBlocks = 8 * kRingWordsPerXcd * 64;     // 1024 blocks per XCD: eight times what an XCD holds resident (workgroups that a queue eviction
+                                                           // saved hold theirs while others start: four queues - a run's launches side by side - can strand 4 x 128)
 constexpr int kRingStride = 8;                             // u64 units between words (a cache line each)
 constexpr int kRingU64 = 8 * kRingWordsPerXcd * kRingStride;
 constexpr int kRpQueueWithSi = 128;  // ... and the sums kept for the winner (RpLdsLayout::si_off) leave it at least this

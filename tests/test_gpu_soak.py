@@ -75,10 +75,10 @@ def test_repeated_runs_are_bit_identical(workload, c_oracle, angles, img_size, b
     np.testing.assert_allclose(ref[sel, 4], exp[:, 4], rtol=1e-5, atol=1e-5)
 
 
-@pytest.mark.parametrize('angles,img_size', [(1, 35), (3, 34)])
+@pytest.mark.parametrize('angles,img_size', [(1, 35), (3, 34), (7, 34)])
 def test_recycled_blocks_survive_queue_evictions(angles, img_size, c_oracle, tmp_path):
-    """The launches of at most 7 angles take the blocks of global memory that hold their per-placement sums and accumulators
-    from per-XCD free lists (round 5).  300 repetitions of a 6 400-point run while a host thread provokes evictions of the
+    """Every launch that keeps per-placement tables in global memory takes its blocks from per-XCD free lists (round 5: the
+    launches of at most 7 angles; round 6: all of them - the 15-angle benchmark kernel included - and the lists are bitmaps).  300 repetitions of a 6 400-point run while a host thread provokes evictions of the
     process's GPU queues (tools/eviction_soak.py: wavefronts in flight are saved and restored on OTHER compute units - what broke
     round 4's pool of blocks picked by hardware slot): every repetition bit-identical to the first, the first equal to the
     oracle.  A process of its own, run before every other GPU test (conftest.py), with a hard timeout and one retry.
