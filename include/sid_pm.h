@@ -57,8 +57,12 @@ extern "C" {
 #define SID_PM_HES_SMTH 2u          /* hes_smth=True  (gaussian_filter sigma=1 before Hessian) */
 #define SID_PM_MCC_NORM 4u          /* mcc_norm=True                                           */
 #define SID_PM_ROT_ORDER1 8u        /* rot_order=1 (pmlib.py:89,112-113): templates sampled bilinearly with scipy's arithmetic
-                                     * (float64 taps, uint8 output rounding); default rot_order=0 = nearest neighbour.
-                                     * Orders 2..5 (whole-image spline prefilter) are not implemented.              */
+                                     * (float64 taps, uint8 output rounding); default rot_order=0 = nearest neighbour.   */
+#define SID_PM_ROT_ORDER(n) (((uint32_t)(n) & 7u) << 3)   /* rot_order = n, 0..5, in flag bits 3..5 (SID_PM_ROT_ORDER(1) == SID_PM_ROT_ORDER1).
+                                     * Orders 2..5 are scipy's spline interpolation: the WHOLE image 1 goes through scipy's recursive
+                                     * B-spline prefilter once per pair (float64 coefficients, 8 B per pixel x 2 buffers of device
+                                     * memory, kept with the handle until the pair changes), then every template sample is the
+                                     * tensor product of n + 1 weights per axis - scipy's arithmetic operation for operation.      */
 
 typedef struct sid_pm_ctx sid_pm_ctx;
 

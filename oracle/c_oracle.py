@@ -45,6 +45,10 @@ def lib():
         L.sid_oracle_pm_batch_gap.restype = C.c_int
         L.sid_oracle_pm_batch_gap.argtypes = L.sid_oracle_pm_batch.argtypes + [_f32p]
         L.sid_oracle_max_threads.restype = C.c_int
+        L.sid_oracle_spline_coefficients.restype = C.c_int
+        L.sid_oracle_spline_coefficients.argtypes = [_u8p, C.c_int64, C.c_int64, C.c_int64, C.c_int, _f64p]
+        L.sid_oracle_get_template_spline.restype = C.c_int
+        L.sid_oracle_get_template_spline.argtypes = [_f64p, C.c_int64, C.c_int64, C.c_double, C.c_double, _f64p, C.c_int, C.c_int, _u8p]
         L.sid_oracle_rotate_and_match.restype = C.c_int
         L.sid_oracle_rotate_and_match.argtypes = ([_u8p, C.c_int64, C.c_int64, C.c_int64] * 2 +
                                                   [C.c_double, C.c_double, C.c_int, _f64p, _f64p, C.c_int, C.c_uint, _f64p, _i32p, _f32p, _u8p])
@@ -62,10 +66,24 @@ def _f64(a):
     return a, a.ctypes.data_as(_f64p)
 
 
-def get_template(img, c, r, rot, s, rot_order=0):
+def spline_coefficients(img, order):
+    """scipy's spline_filter(img, order, output=float64) restated (pm_oracle.c sid_oracle_spline_coefficients)."""
+    img, pi = _u8(img)
+    coef = np.empty(img.shape, dtype=np.float64)
+    if lib().sid_oracle_spline_coefficients(pi, img.shape[0], img.shape[1], img.strides[0], int(order), coef.ctypes.data_as(_f64p)):
+        raise ValueError('order 2..5')
+    return coef
+
+
+def get_template(img, c, r, rot, s, rot_order=0, coeffs=None):
     img, pi = _u8(img)
     rot, pr = _f64(rot)
     out = np.empty((s, s), dtype=np.uint8)
+    if rot_order >= 2:
+        coeffs = spline_coefficients(img, rot_order) if coeffs is None else np.ascontiguousarray(coeffs, dtype=np.float64)
+        lib().sid_oracle_get_template_spline(coeffs.ctypes.data_as(_f64p), img.shape[0], img.shape[1], float(c), float(r), pr, int(s),
+                                             int(rot_order), out.ctypes.data_as(_u8p))
+        return out
     (lib().sid_oracle_get_template1 if rot_order == 1 else lib().sid_oracle_get_template)(pi, img.shape[0], img.shape[1], img.strides[0], float(c), float(r),
                                   pr, int(s), out.ctypes.data_as(_u8p))
     return out

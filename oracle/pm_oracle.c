@@ -32,6 +32,7 @@
 #define SID_FLAG_HES_SMTH 2u
 #define SID_FLAG_MCC_NORM 4u
 #define SID_FLAG_ROT_ORDER1 8u   /* rot_order=1 (pmlib.py:89,112-113): bilinear template sampling */
+#define SID_ROT_ORDER(flags) (((flags) >> 3) & 7u)   /* rot_order 0..5 in flag bits 3..5 (include/sid_pm.h) */
 
 /* ------------------------------------------------------------------ a1 */
 /* rot = {cos a, sin a, tcT0, tcT1} with tcT = [tc,tc].dot([[cos,-sin],[sin,cos]])
@@ -98,6 +99,147 @@ int sid_oracle_get_template1(const uint8_t *img, int64_t rows, int64_t cols, int
                 t = t + ((double)img[r1 * stride + c0] * w1r) * w0c;
                 t = t + ((double)img[r1 * stride + c1] * w1r) * w1c;
                 t = t > 0.0 ? t + 0.5 : 0.0;                      /* CASE_INTERP_OUT_UINT of ni_interpolation.c */
+                t = t > 255.0 ? 255.0 : t;
+                v = (uint8_t)t;
+            }
+            out[i * s + j] = v;
+            if (v < vmin) vmin = v;
+        }
+    }
+    return vmin;
+}
+
+/* ------------------------------------------------------------------ a1, rot_order 2..5 */
+/* scipy.ndimage.affine_transform(..., order = 2..5, mode='constant', cval=0, output=uint8, prefilter=True): the WHOLE image through
+ * scipy's recursive B-spline prefilter (ni_splines.c apply_filter: gain, then per pole causal initialisation with the MIRROR
+ * formulas - 'constant' takes those -, causal recursion, anticausal initialisation, anticausal recursion; axis 0 first), then the
+ * tensor product of order + 1 weights per axis (get_spline_interpolation_weights) over the coefficient image.  The NumPy form
+ * (oracle/pm_oracle.py) has the derivation and is pinned against scipy itself; this is the same arithmetic in C. */
+static const double kSplinePoles[6][2] = {{0, 0}, {0, 0}, {-0.171572875253809902396622551581, 0}, {-0.267949192431122706472553658494, 0},
+                                          {-0.361341225900220177092212841325, -0.013725429297339121360331226939},
+                                          {-0.430575347099973791851434783493, -0.043096288203264653822712839920}};
+
+static void spline_filter_line(double *c, int64_t n, int64_t stride, int order)
+{
+    if (n <= 1) return;
+    const int npoles = order / 2;
+    double gain = 1.0;
+    for (int p = 0; p < npoles; ++p) { const double z = kSplinePoles[order][p]; gain *= (1.0 - z) * (1.0 - 1.0 / z); }
+    for (int64_t i = 0; i < n; ++i) c[i * stride] *= gain;
+    for (int p = 0; p < npoles; ++p) {
+        const double z = kSplinePoles[order][p];
+        const double z_n_1 = pow(z, (double)(n - 1));
+        double z_i = z;
+        double c0 = c[0] + z_n_1 * c[(n - 1) * stride];
+        for (int64_t i = 1; i < n - 1; ++i) {
+            if (z_i == 0.0) break;                                /* (the remaining terms are +-0) */
+            c0 += z_i * (c[i * stride] + z_n_1 * c[(n - 1 - i) * stride]);
+            z_i *= z;
+        }
+        c0 /= 1 - z_n_1 * z_n_1;
+        c[0] = c0;
+        for (int64_t i = 1; i < n; ++i) c[i * stride] += z * c[(i - 1) * stride];
+        c[(n - 1) * stride] = (z * c[(n - 2) * stride] + c[(n - 1) * stride]) * z / (z * z - 1);
+        for (int64_t i = n - 2; i >= 0; --i) c[i * stride] = z * (c[(i + 1) * stride] - c[i * stride]);
+    }
+}
+
+/* spline_filter(img, order, output=float64): coef [rows][cols] */
+int sid_oracle_spline_coefficients(const uint8_t *img, int64_t rows, int64_t cols, int64_t stride, int order, double *coef)
+{
+    if (order < 2 || order > 5) return -1;
+    for (int64_t i = 0; i < rows; ++i) for (int64_t j = 0; j < cols; ++j) coef[i * cols + j] = (double)img[i * stride + j];
+#pragma omp parallel for schedule(static)
+    for (int64_t j = 0; j < cols; ++j) spline_filter_line(coef + j, rows, cols, order);      /* axis 0 */
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < rows; ++i) spline_filter_line(coef + i * cols, cols, 1, order);  /* axis 1 */
+    return 0;
+}
+
+static void spline_weights(double x, int order, double *w)
+{
+    x -= floor(order & 1 ? x : x + 0.5);
+    double y = x, z = 1.0 - x, t;
+    switch (order) {
+    case 2:
+        w[1] = 0.75 - x * x;
+        y = 0.5 - x;
+        w[0] = 0.5 * y * y;
+        break;
+    case 3:
+        w[1] = (y * y * (y - 2.0) * 3.0 + 4.0) / 6.0;
+        w[2] = (z * z * (z - 2.0) * 3.0 + 4.0) / 6.0;
+        w[0] = z * z * z / 6.0;
+        break;
+    case 4:
+        t = x * x;
+        w[2] = t * (t * 0.25 - 0.625) + 115.0 / 192.0;
+        y = 1.0 + x;
+        w[1] = y * (y * (y * (5.0 - y) / 6.0 - 1.25) + 5.0 / 24.0) + 55.0 / 96.0;
+        z = 1.0 - x;
+        w[3] = z * (z * (z * (5.0 - z) / 6.0 - 1.25) + 5.0 / 24.0) + 55.0 / 96.0;
+        y = 0.5 - x;
+        t = y * y;
+        w[0] = t * t / 24.0;
+        break;
+    default:
+        t = y * y;
+        w[2] = t * (t * (0.25 - y / 12.0) - 0.5) + 0.55;
+        t = z * z;
+        w[3] = t * (t * (0.25 - z / 12.0) - 0.5) + 0.55;
+        y = x + 1.0;
+        w[1] = y * (y * (y * (y * (y / 24.0 - 0.375) + 1.25) - 1.75) + 0.625) + 0.425;
+        y = 2.0 - x;
+        w[4] = y * (y * (y * (y * (y / 24.0 - 0.375) + 1.25) - 1.75) + 0.625) + 0.425;
+        z = 1.0 - x;
+        t = z * z;
+        w[0] = z * t * t / 120.0;
+        break;
+    }
+    w[order] = 1.0;
+    for (int i = 0; i < order; ++i) w[order] -= w[i];
+}
+
+static inline int64_t spline_mirror(int64_t idx, int64_t len)
+{
+    if (len <= 1) return 0;
+    const int64_t s2 = 2 * len - 2;
+    if (idx < 0) { idx = s2 * (-idx / s2) + idx; return idx <= 1 - len ? idx + s2 : -idx; }
+    if (idx >= len) { idx -= s2 * (idx / s2); if (idx >= len) idx = s2 - idx; }
+    return idx;
+}
+
+/* get_template(..., rot_order = order) from the prefiltered image coef [rows][cols]; returns the minimum sampled value */
+int sid_oracle_get_template_spline(const double *coef, int64_t rows, int64_t cols, double c, double r, const double *rot, int s,
+                                   int order, uint8_t *out)
+{
+    const double cosa = rot[0], sina = rot[1];
+    const double off0 = r - rot[2], off1 = c - rot[3];
+    const double msin = -sina;
+    int vmin = 255;
+    for (int i = 0; i < s; ++i) {
+        for (int j = 0; j < s; ++j) {
+            double rr = 0.0 + (double)i * cosa;
+            rr = rr + (double)j * sina;
+            rr = rr + off0;
+            double cc = 0.0 + (double)i * msin;
+            cc = cc + (double)j * cosa;
+            cc = cc + off1;
+            uint8_t v = 0;
+            if (rr >= 0.0 && rr <= (double)(rows - 1) && cc >= 0.0 && cc <= (double)(cols - 1)) {
+                const int64_t sr = (int64_t)floor(order & 1 ? rr : rr + 0.5) - order / 2, sc = (int64_t)floor(order & 1 ? cc : cc + 0.5) - order / 2;
+                double wr[6], wc[6];
+                spline_weights(rr, order, wr);
+                spline_weights(cc, order, wc);
+                double t = 0.0;
+                for (int a = 0; a <= order; ++a) {
+                    const int64_t ia = spline_mirror(sr + a, rows);
+                    for (int b = 0; b <= order; ++b) {
+                        const int64_t ib = spline_mirror(sc + b, cols);
+                        t += (coef[ia * cols + ib] * wr[a]) * wc[b];
+                    }
+                }
+                t = t > 0.0 ? t + 0.5 : 0.0;
                 t = t > 255.0 ? 255.0 : t;
                 v = (uint8_t)t;
             }
@@ -353,6 +495,7 @@ int sid_oracle_hessian(const float *ccm, int rh, int rw, unsigned flags, float *
 
 /* -------------------------------------------------------- a2, a4, a6 */
 typedef struct {
+    const double *coef;             /* rot_order 2..5: the prefiltered image 1 (owned by the caller of the batch) */
     uint8_t *tmpl, *tmpl_best;
     float *res, *best, *scratch;
     uint32_t *sit;
@@ -396,8 +539,10 @@ static int rotate_and_match_ws(sid_ws *w, const uint8_t *img1, int64_t rows1, in
     float top1 = -INFINITY, top2 = -INFINITY;                   /* two largest values over all angles and placements */
     int best_k = -1; int64_t best_idx = -1;
     for (int k = 0; k < n_angles; ++k) {
-        if (((flags & SID_FLAG_ROT_ORDER1) ? sid_oracle_get_template1 : sid_oracle_get_template)(img1, rows1, cols1, stride1, c1, r1, rot + 4 * k, s, w->tmpl) == 0)
-            return -1;                                          /* pmlib.py:152-154 -> NaN */
+        const int order = (int)SID_ROT_ORDER(flags);
+        const int vmin = order >= 2 ? sid_oracle_get_template_spline(w->coef, rows1, cols1, c1, r1, rot + 4 * k, s, order, w->tmpl)
+                                    : (order == 1 ? sid_oracle_get_template1 : sid_oracle_get_template)(img1, rows1, cols1, stride1, c1, r1, rot + 4 * k, s, w->tmpl);
+        if (vmin == 0) return -1;                               /* pmlib.py:152-154 -> NaN */
         match_template_core(win, wh, ww, wstride, w->tmpl, s, w->res, w->sit, w->si,
                             w->si + (size_t)rh * rw, k > 0);
         int64_t idx = 0; float mx = w->res[0];
@@ -465,8 +610,14 @@ int sid_oracle_rotate_and_match(const uint8_t *img1, int64_t rows1, int64_t cols
                                 unsigned flags, double *out5, int32_t *ij3, float *ccm, uint8_t *tmpl)
 {
     const int s = img_size;
-    if (n_angles < 1 || s < 2 || rows2 - s + 1 < 2 || cols2 - s + 1 < 2 || !rot) return -1;
+    if (n_angles < 1 || s < 2 || rows2 - s + 1 < 2 || cols2 - s + 1 < 2 || !rot || SID_ROT_ORDER(flags) > 5) return -1;
     sid_ws w; memset(&w, 0, sizeof(w));
+    double *coef = NULL;
+    if (SID_ROT_ORDER(flags) >= 2) {
+        coef = (double *)malloc(sizeof(double) * (size_t)rows1 * (size_t)cols1);
+        if (!coef || sid_oracle_spline_coefficients(img1, rows1, cols1, stride1, (int)SID_ROT_ORDER(flags), coef)) { free(coef); return -1; }
+        w.coef = coef;
+    }
     double ddrc[2]; float rr, hh; int iyx[2];
     for (int k = 0; k < 5; ++k) out5[k] = NAN;
     if (ij3) { ij3[0] = ij3[1] = ij3[2] = -1; }
@@ -479,6 +630,7 @@ int sid_oracle_rotate_and_match(const uint8_t *img1, int64_t rows1, int64_t cols
         if (tmpl) memcpy(tmpl, w.tmpl_best, (size_t)s * s);
     }
     ws_free(&w);
+    free(coef);
     return best_k >= 0 ? 0 : 1;
 }
 
@@ -525,8 +677,13 @@ int sid_oracle_pm_batch_gap(const uint8_t *img1, int64_t rows1, int64_t cols1, i
                             const double *angles, const double *rot_in, int n_angles, unsigned flags,
                             int nthreads, double *out, int32_t *out_ij, float *gap)
 {
-    if (n_angles < 1 || img_size < 2 || n < 0) return -1;
+    if (n_angles < 1 || img_size < 2 || n < 0 || SID_ROT_ORDER(flags) > 5) return -1;
     double *rot = make_rot(angles, n_angles, alpha0, img_size, rot_in);
+    double *coef = NULL;
+    if (SID_ROT_ORDER(flags) >= 2 && n > 0) {                       /* the whole image 1 through the spline prefilter, once per batch */
+        coef = (double *)malloc(sizeof(double) * (size_t)rows1 * (size_t)cols1);
+        if (!coef || sid_oracle_spline_coefficients(img1, rows1, cols1, stride1, (int)SID_ROT_ORDER(flags), coef)) { free(coef); free(rot); return -1; }
+    }
 #ifdef _OPENMP
     if (nthreads < 1) nthreads = omp_get_max_threads();
 #else
@@ -535,6 +692,7 @@ int sid_oracle_pm_batch_gap(const uint8_t *img1, int64_t rows1, int64_t cols1, i
 #pragma omp parallel num_threads(nthreads)
     {
         sid_ws w; memset(&w, 0, sizeof(w));
+        w.coef = coef;
 #pragma omp for schedule(dynamic, 4)
         for (int64_t i = 0; i < n; ++i)
             use_mcc_ws(&w, img1, rows1, cols1, stride1, img2, rows2, cols2, stride2,
@@ -543,6 +701,7 @@ int sid_oracle_pm_batch_gap(const uint8_t *img1, int64_t rows1, int64_t cols1, i
         ws_free(&w);
     }
     free(rot);
+    free(coef);
     return 0;
 }
 

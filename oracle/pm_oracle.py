@@ -65,6 +65,15 @@ FLAG_MCC_NORM = 4
 FLAG_ROT_ORDER1 = 8          # rot_order=1 (pmlib.py:89): templates sampled bilinearly
 
 
+def flag_rot_order(order):
+    """rot_order 0..5 as flag bits 3..5 (include/sid_pm.h SID_PM_ROT_ORDER): order 1 = FLAG_ROT_ORDER1."""
+    return (int(order) & 7) << 3
+
+
+def rot_order_of(flags):
+    return (int(flags) >> 3) & 7
+
+
 # --------------------------------------------------------------------------- a1
 def rotation_terms(angle_deg, img_size):
     """(cos a, sin a, tcT0, tcT1) exactly as pmlib.py:105-110 builds them.
@@ -141,6 +150,147 @@ def get_template_order1(img, c, r, a, s):
     t = t + (v[r0, c1] * w0r) * w1c
     t = t + (v[r1, c0] * w1r) * w0c
     t = t + (v[r1, c1] * w1r) * w1c
+    t = np.where(t > 0, t + 0.5, 0.0)
+    t = np.minimum(t, 255.0)
+    return np.where(inside, t, 0.0).astype(np.uint8)
+
+
+# ----------------------------------------------------------------- a1, rot_order 2..5
+# scipy.ndimage.affine_transform(img, ..., order=n, mode='constant', cval=0, output=uint8, prefilter=True) for n = 2..5
+# (pmlib.py:112-113 with rot_order=n): the WHOLE image goes through scipy's recursive B-spline prefilter first
+# (spline_filter(input, order, output=float64, mode='constant'): per axis, axis 0 first; 'constant' takes the MIRROR boundary
+# formulas of ni_splines.c), then every sample is the tensor product of order + 1 spline weights per axis over the coefficient
+# image.  Restated here operation for operation; pinned against scipy itself - coefficients and weights bit for bit (probed
+# through spline_filter1d and map_coordinates(prefilter=False) on impulses: tests/test_oracle_golden.py) - and against the
+# reference's get_template(rot_order=n) (fixture G1c).
+SPLINE_POLES = {2: (-0.171572875253809902396622551581,),
+                3: (-0.267949192431122706472553658494,),
+                4: (-0.361341225900220177092212841325, -0.013725429297339121360331226939),
+                5: (-0.430575347099973791851434783493, -0.043096288203264653822712839920)}
+
+
+def spline_filter_lines(c, order):
+    """scipy's apply_filter (ni_splines.c) along axis 0 of a float64 array, every column a line: gain, then per pole the causal
+    initialisation (mirror), the causal recursion, the anticausal initialisation, the anticausal recursion."""
+    import math
+    c = np.array(c, dtype=np.float64)
+    n = c.shape[0]
+    if n <= 1:
+        return c
+    gain = 1.0
+    for z in SPLINE_POLES[order]:
+        gain *= (1.0 - z) * (1.0 - 1.0 / z)
+    c *= gain
+    for z in SPLINE_POLES[order]:
+        z_n_1 = math.pow(z, n - 1)
+        z_i = z
+        c0 = c[0] + z_n_1 * c[n - 1]
+        for i in range(1, n - 1):
+            if z_i == 0.0:                                        # (the remaining terms are +-0: they change nothing)
+                break
+            c0 = c0 + z_i * (c[i] + z_n_1 * c[n - 1 - i])
+            z_i *= z
+        c0 = c0 / (1 - z_n_1 * z_n_1)
+        c[0] = c0
+        for i in range(1, n):
+            c[i] += z * c[i - 1]
+        c[n - 1] = (z * c[n - 2] + c[n - 1]) * z / (z * z - 1)
+        for i in range(n - 2, -1, -1):
+            c[i] = z * (c[i + 1] - c[i])
+    return c
+
+
+def spline_coefficients(img, order):
+    """spline_filter(img, order, output=float64) of a 2-D image: axis 0, then axis 1."""
+    c = spline_filter_lines(np.asarray(img, dtype=np.float64), order)
+    return np.ascontiguousarray(spline_filter_lines(c.T, order).T)
+
+
+def spline_weights(x, order):
+    """get_spline_interpolation_weights (ni_splines.c) for an array of coordinates: list of order + 1 weight arrays."""
+    x = np.asarray(x, dtype=np.float64)
+    x = x - np.floor(x if order & 1 else x + 0.5)
+    w = [None] * (order + 1)
+    y = x
+    z = 1.0 - x
+    if order == 2:
+        w[1] = 0.75 - x * x
+        y = 0.5 - x
+        w[0] = 0.5 * y * y
+    elif order == 3:
+        w[1] = (y * y * (y - 2.0) * 3.0 + 4.0) / 6.0
+        w[2] = (z * z * (z - 2.0) * 3.0 + 4.0) / 6.0
+        w[0] = z * z * z / 6.0
+    elif order == 4:
+        t = x * x
+        w[2] = t * (t * 0.25 - 0.625) + 115.0 / 192.0
+        y = 1.0 + x
+        w[1] = y * (y * (y * (5.0 - y) / 6.0 - 1.25) + 5.0 / 24.0) + 55.0 / 96.0
+        z = 1.0 - x
+        w[3] = z * (z * (z * (5.0 - z) / 6.0 - 1.25) + 5.0 / 24.0) + 55.0 / 96.0
+        y = 0.5 - x
+        t = y * y
+        w[0] = t * t / 24.0
+    elif order == 5:
+        t = y * y
+        w[2] = t * (t * (0.25 - y / 12.0) - 0.5) + 0.55
+        t = z * z
+        w[3] = t * (t * (0.25 - z / 12.0) - 0.5) + 0.55
+        y = x + 1.0
+        w[1] = y * (y * (y * (y * (y / 24.0 - 0.375) + 1.25) - 1.75) + 0.625) + 0.425
+        z2 = 2.0 - x
+        w[4] = z2 * (z2 * (z2 * (z2 * (z2 / 24.0 - 0.375) + 1.25) - 1.75) + 0.625) + 0.425
+        z = 1.0 - x
+        t = z * z
+        w[0] = z * t * t / 120.0
+    else:
+        raise ValueError('order 2..5')
+    last = np.ones_like(x)
+    for i in range(order):
+        last = last - w[i]
+    w[order] = last
+    return w
+
+
+def get_template_spline(img, c, r, a, s, order, coeffs=None):
+    """get_template(img, c, r, a, s, rot_order=order) for order 2..5 (pmlib.py:89-115).  ``coeffs``: the prefiltered image
+    (spline_coefficients(img, order)) when the caller has it already."""
+    if coeffs is None:
+        coeffs = spline_coefficients(img, order)
+    cosa, sina, tct0, tct1 = rotation_terms(a, s)
+    off0 = np.float64(r) - tct0
+    off1 = np.float64(c) - tct1
+    ii = np.arange(s, dtype=np.float64)[:, None]
+    jj = np.arange(s, dtype=np.float64)[None, :]
+    rr = ((0.0 + ii * cosa) + jj * sina) + off0
+    cc = ((0.0 + ii * (-sina)) + jj * cosa) + off1
+    rows, cols = img.shape
+    inside = (rr >= 0) & (rr <= rows - 1) & (cc >= 0) & (cc <= cols - 1)
+    rr = np.where(inside, rr, 0.0)
+    cc = np.where(inside, cc, 0.0)
+    if order & 1:
+        sr, sc = np.floor(rr).astype(np.int64) - order // 2, np.floor(cc).astype(np.int64) - order // 2
+    else:
+        sr, sc = np.floor(rr + 0.5).astype(np.int64) - order // 2, np.floor(cc + 0.5).astype(np.int64) - order // 2
+    wr, wc = spline_weights(rr, order), spline_weights(cc, order)
+
+    def mirror(i, n):                                               # scipy's edge mapping of a tap index (NI_GeometricTransform)
+        if n <= 1:
+            return np.zeros_like(i)
+        s2 = 2 * n - 2
+        neg = i < 0
+        j = np.where(neg, s2 * (-i // s2) + i, i)
+        j = np.where(neg, np.where(j <= 1 - n, j + s2, -j), j)
+        big = ~neg & (i >= n)
+        k = np.where(big, i - s2 * (i // s2), j)
+        k = np.where(big & (k >= n), s2 - k, k)
+        return k
+    t = np.zeros((s, s), dtype=np.float64)
+    for ta in range(order + 1):
+        ia = mirror(sr + ta, rows)
+        for tb in range(order + 1):
+            ib = mirror(sc + tb, cols)
+            t = t + (coeffs[ia, ib] * wr[ta]) * wc[tb]
     t = np.where(t > 0, t + 0.5, 0.0)
     t = np.minimum(t, 255.0)
     return np.where(inside, t, 0.0).astype(np.uint8)
@@ -255,14 +405,17 @@ def get_hessian(ccm, hes_norm=True, hes_smth=False):
 
 # ----------------------------------------------------------------------- a2,a4,a6
 def rotate_and_match(img1, c1, r1, img_size, image2, alpha0, angles=(-3, 0, 3),
-                     mcc_norm=False, hes_norm=True, hes_smth=False, full=False, rot_order=0):
+                     mcc_norm=False, hes_norm=True, hes_smth=False, full=False, rot_order=0, coeffs=None):
     """pmlib.py:117-174 (rot_order: 0 or 1, forwarded to get_template as pmlib.py:151 does).  Returns (dc, dr, best_a, best_r, best_h) and, with
     full=True, also (best_ij, best_angle_index, best_result, best_template)."""
     nan = np.nan
     best_r = -np.inf
     best = None
     for k, angle in enumerate(angles):
-        template = (get_template_order1 if rot_order == 1 else get_template)(img1, c1, r1, angle - alpha0, img_size)
+        if rot_order >= 2:                                         # (coeffs: spline_coefficients(img1, rot_order), when the caller has them)
+            template = get_template_spline(img1, c1, r1, angle - alpha0, img_size, rot_order, coeffs=coeffs)
+        else:
+            template = (get_template_order1 if rot_order == 1 else get_template)(img1, c1, r1, angle - alpha0, img_size)
         if template.min() == 0:                                   # pmlib.py:152-154
             if full:
                 return (nan, nan, nan, nan, nan), ((-1, -1), -1, None, None)
@@ -316,9 +469,10 @@ def pm_batch(img1, img2, c1, r1, c2fg, r2fg, border, img_size, alpha0, angles,
     n = len(c1)
     out = np.full((n, 5), np.nan)
     ij = np.full((n, 3), -1, dtype=np.int32)
+    order = rot_order_of(flags)
     kw = dict(angles=list(angles), hes_norm=bool(flags & FLAG_HES_NORM),
               hes_smth=bool(flags & FLAG_HES_SMTH), mcc_norm=bool(flags & FLAG_MCC_NORM),
-              rot_order=1 if (flags & FLAG_ROT_ORDER1) else 0)
+              rot_order=order, coeffs=spline_coefficients(img1, order) if order >= 2 else None)
     for i in range(n):
         res, (bij, bk, _, _) = use_mcc(c1[i], r1[i], c2fg[i], r2fg[i], border[i], img1, img2,
                                        img_size, alpha0, full=True, **kw)

@@ -258,11 +258,15 @@ def _rot_arg(rot, angles, alpha0, img_size):
     return rot
 
 
+def rot_order_flag(order):
+    """rot_order 0..5 as flag bits 3..5 (include/sid_pm.h SID_PM_ROT_ORDER); order 1 = ROT_ORDER1."""
+    return (int(order) & 7) << 3
+
+
 def flags_from_kwargs(hes_norm=True, hes_smth=False, mcc_norm=False, rot_order=0):
-    if rot_order not in (0, 1):
-        raise NotImplementedError('rot_order=%r' % (rot_order,))
-    return ((HES_NORM if hes_norm else 0) | (HES_SMTH if hes_smth else 0) | (MCC_NORM if mcc_norm else 0) |
-            (ROT_ORDER1 if rot_order == 1 else 0))
+    if isinstance(rot_order, bool) or rot_order not in (0, 1, 2, 3, 4, 5):
+        raise ValueError('rot_order=%r: spline orders 0..5 (scipy.ndimage.affine_transform)' % (rot_order,))
+    return ((HES_NORM if hes_norm else 0) | (HES_SMTH if hes_smth else 0) | (MCC_NORM if mcc_norm else 0) | rot_order_flag(rot_order))
 
 
 def pm_batch(img1, img2, c1, r1, c2fg, r2fg, border, img_size, alpha0, angles, rot=None, flags=HES_NORM):

@@ -125,6 +125,12 @@ struct sid_pm_ctx {
     DevBuf<int32_t> d_nan_idx;          // ... and, when NO other kernel of the run exists (template side above 64), the points without a valid window
     int n_nan_idx = 0;
     sid::LwWorkspace lw;
+    // rot_order 2..5: image 1 through scipy's spline prefilter (coef[1]; coef[0] = scratch), valid for (pair_serial, order); and the
+    // templates of the resident points sampled from it (pre), valid for (pair_serial, points_serial)
+    DevBuf<double> coef[2];
+    uint64_t pair_serial = 1, points_serial = 1, coef_pair = 0, pre_pair = 0, pre_points = 0;
+    int coef_order = 0;
+    DevBuf<uint8_t> pre;
     DevBuf<double> lw_small;            // rotate_and_match as a call of its own: angles, rotation terms, the five results
     int64_t n = 0;
     int img_size = 0, n_angles = 0;
@@ -358,7 +364,8 @@ int check_sweep(int img_size, const double *angles, int n_angles, uint32_t flags
     if (n_angles > sid::kMaxAngles) return fail(SID_PM_ERR_UNSUPPORTED, "more than %d angles", sid::kMaxAngles);
     if (img_size < 2 || img_size > sid::kLargeMaxSide)
         return fail(SID_PM_ERR_UNSUPPORTED, "img_size=%d: the kernels support 2..%d", img_size, sid::kLargeMaxSide);
-    if (flags & ~(SID_PM_HES_NORM | SID_PM_HES_SMTH | SID_PM_MCC_NORM | SID_PM_ROT_ORDER1)) return fail(SID_PM_ERR_ARG, "unknown flag bits");
+    if (flags & ~(SID_PM_HES_NORM | SID_PM_HES_SMTH | SID_PM_MCC_NORM | SID_PM_ROT_ORDER(7))) return fail(SID_PM_ERR_ARG, "unknown flag bits");
+    if (((flags >> 3) & 7u) > 5u) return fail(SID_PM_ERR_UNSUPPORTED, "rot_order %u: scipy's spline orders are 0..5", (flags >> 3) & 7u);
     return SID_PM_OK;
 }
 
@@ -702,6 +709,50 @@ int classify_points(sid_pm_ctx *ctx)
     return SID_PM_OK;
 }
 
+// rot_order 2..5 (pmlib.py:112-113): image 1 of the current pair through scipy's whole-image spline prefilter, once per pair and
+// order (8 B per pixel x 2 buffers, kept with the handle); enqueued on the handle's stream behind the upload of the pair
+int ensure_coef(sid_pm_ctx *ctx, int order)
+{
+    if (order < 2) return SID_PM_OK;
+    if (ctx->coef_pair == ctx->pair_serial && ctx->coef_order == order && ctx->coef[1].p) return SID_PM_OK;
+    const size_t px = (size_t)ctx->cur[0].rows * (size_t)ctx->cur[0].cols;
+    if (ctx->cur[0].rows < 2 && ctx->cur[0].cols < 2) return fail(SID_PM_ERR_UNSUPPORTED, "rot_order %d on a 1 x 1 image", order);
+    {
+        size_t free_b = 0, total_b = 0;
+        const size_t need = (ctx->coef[0].cap < px ? px * 8 : 0) + (ctx->coef[1].cap < px ? px * 8 : 0);
+        if (need && hipMemGetInfo(&free_b, &total_b) == hipSuccess && need > free_b)
+            return fail(SID_PM_ERR_NOMEM, "rot_order %d: the spline coefficients of image 1 need %.1f GB of device memory, %.1f GB are free", order, (double)need * 1e-9, (double)free_b * 1e-9);
+    }
+    if (int rc = ctx->coef[0].reserve(px)) return rc;
+    if (int rc = ctx->coef[1].reserve(px)) return rc;
+    if (ctx->cur_slot >= 0 && ctx->ready_rec[ctx->cur_slot]) HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->slot_ready[ctx->cur_slot], 0));
+    const int e = sid::lw_spline_prefilter(ctx->cur[0].ptr, ctx->cur[0].rows, ctx->cur[0].cols, ctx->cur[0].stride, order, ctx->coef[0].p, ctx->coef[1].p, ctx->stream);
+    if (e) return fail(SID_PM_ERR_HIP, "spline prefilter: %s", hipGetErrorString((hipError_t)e));
+    ctx->coef_pair = ctx->pair_serial; ctx->coef_order = order;
+    ctx->pre_pair = 0;                                                // (templates sampled from the old coefficients are stale)
+    return SID_PM_OK;
+}
+
+// ... and the K templates of every resident point sampled from them (the one-workgroup-per-point kernels load these: PMArgs::pre)
+int ensure_presampled(sid_pm_ctx *ctx, int order)
+{
+    if (order < 2 || ctx->n == 0) return SID_PM_OK;
+    if (ctx->pre_pair == ctx->pair_serial && ctx->pre_points == ctx->points_serial && ctx->pre.p) return SID_PM_OK;
+    const size_t bytes = (size_t)ctx->n * (size_t)ctx->n_angles * (size_t)ctx->img_size * (size_t)ctx->img_size;
+    {
+        size_t free_b = 0, total_b = 0;
+        if (bytes > ctx->pre.cap && hipMemGetInfo(&free_b, &total_b) == hipSuccess && bytes > free_b)
+            return fail(SID_PM_ERR_NOMEM, "rot_order %d: the pre-sampled templates of %lld points need %.1f GB of device memory, %.1f GB are free (smaller batches)",
+                        order, (long long)ctx->n, (double)bytes * 1e-9, (double)free_b * 1e-9);
+    }
+    if (int rc = ctx->pre.reserve(bytes)) return rc;
+    const int e = sid::lw_presample(ctx->coef[1].p, ctx->cur[0].rows, ctx->cur[0].cols, ctx->d_vec, ctx->d_vec + ctx->n, ctx->n, ctx->d_rot, ctx->n_angles,
+                                    ctx->img_size, order, ctx->pre.p, ctx->stream);
+    if (e) return fail(SID_PM_ERR_HIP, "template pre-sampling: %s", hipGetErrorString((hipError_t)e));
+    ctx->pre_pair = ctx->pair_serial; ctx->pre_points = ctx->points_serial;
+    return SID_PM_OK;
+}
+
 // The points of the resident set that are beyond the one-point kernels, one after the other through the large-window pipeline
 // (pm_large.hip): a stream of launches, nothing read back; results straight into the rows of the run's result arrays.
 int run_large_points(sid_pm_ctx *ctx, const sid::PMArgs &A)
@@ -722,6 +773,7 @@ int run_large_points(sid_pm_ctx *ctx, const sid::PMArgs &A)
         c.c1 = ctx->h_c1[(size_t)i]; c.r1 = ctx->h_r1[(size_t)i];
         c.s = ctx->img_size; c.K = ctx->n_angles; c.flags = ctx->flags;
         c.d_rot = ctx->d_rot; c.d_angles = ctx->d_angles;
+        c.d_coef = ((ctx->flags >> 3) & 7u) >= 2u ? ctx->coef[1].p : nullptr;
         c.add_c = c2; c.add_r = r2;
         memcpy(c.gauss_w, A.gauss_w, sizeof c.gauss_w);
         c.out5 = A.out + 5 * (size_t)i; c.ij3 = A.out_ij ? A.out_ij + 3 * (size_t)i : nullptr;
@@ -815,7 +867,7 @@ SID_EXPORT void sid_pm_destroy(sid_pm_ctx *ctx)
     if (ctx->fork_ev) (void)hipEventDestroy(ctx->fork_ev);
     for (auto &pair : ctx->own) for (auto &b : pair) b.release();
     ctx->arena.release();
-    sid::lw_workspace_release(ctx->lw); ctx->d_nan_idx.release(); ctx->lw_small.release();
+    sid::lw_workspace_release(ctx->lw); ctx->d_nan_idx.release(); ctx->lw_small.release(); ctx->coef[0].release(); ctx->coef[1].release(); ctx->pre.release();
     ctx->out.release(); ctx->out_ij.release(); ctx->dbg_err.release(); ctx->gsii.release(); ctx->d_goff.release(); ctx->d_rec.release(); ctx->ring.release(); ctx->pool.release();
     if (ctx->h_refused) (void)hipHostFree(ctx->h_refused);
     delete ctx;
@@ -856,6 +908,7 @@ SID_EXPORT int sid_pm_upload_pair(sid_pm_ctx *ctx, int slot,
     }
     HIP_TRY(hipEventRecord(ctx->slot_ready[slot], ctx->copy_stream));
     ctx->ready_rec[slot] = true;
+    ++ctx->pair_serial;
     // first pair, refresh of the selected slot, or a borrowed binding is current (an upload replaces it: the
     // caller who streams through both slots switches with select_pair)
     if (!ctx->have_pair || ctx->cur_slot == slot || ctx->cur_slot < 0) {
@@ -871,6 +924,7 @@ SID_EXPORT int sid_pm_select_pair(sid_pm_ctx *ctx, int slot)
     if (slot < 0 || slot > 1 || !ctx->slot_img[slot][0].ptr) return fail(SID_PM_ERR_STATE, "slot %d holds no pair", slot);
     ctx->cur[0] = ctx->slot_img[slot][0]; ctx->cur[1] = ctx->slot_img[slot][1];
     ctx->have_pair = true; ctx->cur_slot = slot;
+    ++ctx->pair_serial;
     return SID_PM_OK;
 }
 
@@ -883,6 +937,7 @@ SID_EXPORT int sid_pm_bind_pair(sid_pm_ctx *ctx,
     if (int rc = check_images(d[0], d[1])) return rc;
     ctx->cur[0] = d[0]; ctx->cur[1] = d[1];
     ctx->have_pair = true; ctx->cur_slot = -1;
+    ++ctx->pair_serial;
     return SID_PM_OK;
 }
 
@@ -905,7 +960,7 @@ SID_EXPORT int sid_pm_set_points(sid_pm_ctx *ctx, const double *c1, const double
     std::vector<uint16_t> sampv;
     int nflag = 0;
     // (rot_order = 1: no offset table - every template sample is interpolated in float64 by the general sampler)
-    if (!getenv("SID_PM_NO_SAMP_TABLE") && !(flags & SID_PM_ROT_ORDER1) && sid::mfma_img_size_supported(s)) nflag = make_samp(rotv, K, s, sampv);
+    if (!getenv("SID_PM_NO_SAMP_TABLE") && ((flags >> 3) & 7u) == 0u && sid::mfma_img_size_supported(s)) nflag = make_samp(rotv, K, s, sampv);
     std::vector<uint32_t> samp2v;
     // (measured +2 % on the 15-angle step - fifteen table loads per angle instead of five, a uniform branch per chunk - although
     // it executes a third fewer VALU instructions in the template phase: built on request only, SID_PM_SAMP2=1)
@@ -942,6 +997,7 @@ SID_EXPORT int sid_pm_set_points(sid_pm_ctx *ctx, const double *c1, const double
     ctx->user_out = nullptr; ctx->user_ij = nullptr;
     ctx->n = n; ctx->img_size = s; ctx->n_angles = K; ctx->flags = flags; ctx->rp = use_rp(s, K); ctx->rp_paired = ctx->rp ? rp_paired(K) : 0;
     ctx->have_points = false;
+    ++ctx->points_serial;
     if (int rc = classify_points(ctx)) return rc;
     ctx->have_points = true;
     return SID_PM_OK;
@@ -971,6 +1027,12 @@ SID_EXPORT int sid_pm_run(sid_pm_ctx *ctx)
     fill_args(ctx, A);
     if (ctx->cur_slot >= 0 && ctx->ready_rec[ctx->cur_slot])
         HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->slot_ready[ctx->cur_slot], 0));
+    {   // rot_order 2..5: spline coefficients of image 1 (once per pair), templates of the points sampled from them (once per pair and point set)
+        const int order = (int)((ctx->flags >> 3) & 7u);
+        if (int rc = ensure_coef(ctx, order)) return rc;
+        if (!ctx->buckets.empty()) { if (int rc = ensure_presampled(ctx, order)) return rc; }
+        A.pre = (order >= 2 && !ctx->buckets.empty()) ? ctx->pre.p : nullptr;
+    }
     // Launches side by side for SHORT runs.  A full grid is dozens of rounds of workgroups per launch and its launches run one
     // after the other (side by side they measured 1-6 % slower: a CU that took a workgroup of a large-window class is lost to
     // several small ones, rounds 2-4).  A rank's shard of an 8-GPU run is two or three launches of one to seven rounds each,
@@ -1206,6 +1268,8 @@ SID_EXPORT int sid_pm_rotate_and_match(sid_pm_ctx *ctx, double c1, double r1, in
     c.img2 = ctx->cur[1].ptr; c.stride2 = ctx->cur[1].stride;
     c.win_r0 = win_row0; c.win_c0 = win_col0; c.wh = (int)win_rows; c.ww = (int)win_cols;
     c.c1 = c1; c.r1 = r1; c.s = s; c.K = K; c.flags = flags;
+    if (int rc = ensure_coef(ctx, (int)((flags >> 3) & 7u))) return rc;
+    c.d_coef = ((flags >> 3) & 7u) >= 2u ? ctx->coef[1].p : nullptr;
     c.d_angles = ctx->lw_small.p; c.d_rot = ctx->lw_small.p + K;
     c.add_c = 0.0; c.add_r = 0.0;
     gauss_taps(c.gauss_w);
@@ -1233,7 +1297,7 @@ SID_EXPORT int sid_pm_get_template(int device, const uint8_t *img, int64_t rows,
 {
     if (!img || !rot4 || !out || rows < 1 || cols < 1 || stride < cols) return fail(SID_PM_ERR_ARG, "bad argument");
     if (img_size < 1 || img_size > 4096) return fail(SID_PM_ERR_UNSUPPORTED, "img_size=%d", img_size);
-    if (rot_order != 0 && rot_order != 1) return fail(SID_PM_ERR_UNSUPPORTED, "rot_order=%d: 0 (nearest) and 1 (bilinear) are implemented", rot_order);
+    if (rot_order < 0 || rot_order > 5) return fail(SID_PM_ERR_UNSUPPORTED, "rot_order=%d: scipy's spline orders are 0..5", rot_order);
     if (!(fabs(c) < 1e15 && fabs(r) < 1e15)) return fail(SID_PM_ERR_ARG, "non-finite centre");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return fail(SID_PM_ERR_NODEVICE, "no such device");
@@ -1241,21 +1305,27 @@ SID_EXPORT int sid_pm_get_template(int device, const uint8_t *img, int64_t rows,
     const int s = img_size;
     // only the part of the image the samples can touch travels to the device: the samples lie within hypot(s, s) + |tcT| of (r, c)
     const double reach = 1.5 * (double)s + fabs(rot4[2]) + fabs(rot4[3]) + 4.0;
-    const int64_t row0 = std::max<int64_t>(0, (int64_t)floor(r - reach)), row1 = std::min<int64_t>(rows, (int64_t)ceil(r + reach) + 1);
-    const int64_t col0 = std::max<int64_t>(0, (int64_t)floor(c - reach)), col1 = std::min<int64_t>(cols, (int64_t)ceil(c + reach) + 1);
+    // (orders 2..5: scipy prefilters the WHOLE image - pmlib.py:112-113 - so the whole image travels)
+    const bool whole = rot_order >= 2;
+    const int64_t row0 = whole ? 0 : std::max<int64_t>(0, (int64_t)floor(r - reach)), row1 = whole ? rows : std::min<int64_t>(rows, (int64_t)ceil(r + reach) + 1);
+    const int64_t col0 = whole ? 0 : std::max<int64_t>(0, (int64_t)floor(c - reach)), col1 = whole ? cols : std::min<int64_t>(cols, (int64_t)ceil(c + reach) + 1);
     DevBuf<uint8_t> dimg, dout;
-    DevBuf<double> drot;
+    DevBuf<double> drot, dcoef0, dcoef1;
     int rc = SID_PM_OK;
     const int64_t nr = std::max<int64_t>(row1 - row0, 0), nc = std::max<int64_t>(col1 - col0, 0);
-    if ((rc = dimg.reserve((size_t)std::max<int64_t>(nr * nc, 1))) || (rc = dout.reserve((size_t)s * s)) || (rc = drot.reserve(4))) { dimg.release(); dout.release(); drot.release(); return rc; }
+    if ((rc = dimg.reserve((size_t)std::max<int64_t>(nr * nc, 1))) || (rc = dout.reserve((size_t)s * s)) || (rc = drot.reserve(4)) ||
+        (whole && ((rc = dcoef0.reserve((size_t)(rows * cols))) || (rc = dcoef1.reserve((size_t)(rows * cols)))))) {
+        dimg.release(); dout.release(); drot.release(); dcoef0.release(); dcoef1.release(); return rc;
+    }
     hipError_t e = hipSuccess;
     if (nr > 0 && nc > 0) e = hipMemcpy2D(dimg.p, (size_t)nc, img + row0 * stride + col0, (size_t)stride, (size_t)nc, (size_t)nr, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(drot.p, rot4, sizeof(double) * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess && whole) e = (hipError_t)sid::lw_spline_prefilter(dimg.p, rows, cols, nc, rot_order, dcoef0.p, dcoef1.p, nullptr);
     // (a template wholly outside the image samples nothing: every coordinate fails the bounds test and yields 0)
-    if (e == hipSuccess) e = (hipError_t)sid::lw_get_template(dimg.p, nc > 0 ? nc : 1, row0, col0, nr, nc, rows, cols, c, r, drot.p, s, rot_order, dout.p, nullptr);
+    if (e == hipSuccess) e = (hipError_t)sid::lw_get_template(dimg.p, nc > 0 ? nc : 1, row0, col0, nr, nc, rows, cols, c, r, drot.p, s, rot_order, dout.p, nullptr, whole ? dcoef1.p : nullptr);
     if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
     if (e == hipSuccess) e = hipMemcpy(out, dout.p, (size_t)s * s, hipMemcpyDeviceToHost);
-    dimg.release(); dout.release(); drot.release();
+    dimg.release(); dout.release(); drot.release(); dcoef0.release(); dcoef1.release();
     if (e != hipSuccess) return fail(SID_PM_ERR_HIP, "get_template: %s", hipGetErrorString(e));
     return SID_PM_OK;
 }
@@ -1317,14 +1387,15 @@ SID_EXPORT int sid_pm_debug_point(sid_pm_ctx *ctx, double c1, double r1, double 
     std::vector<uint16_t> sampv;
     int nflag = 0;
     // (rot_order = 1: no offset table - every template sample is interpolated in float64 by the general sampler)
-    if (!getenv("SID_PM_NO_SAMP_TABLE") && !(flags & SID_PM_ROT_ORDER1)) nflag = make_samp(rotv, K, s, sampv);
+    if (!getenv("SID_PM_NO_SAMP_TABLE") && ((flags >> 3) & 7u) == 0u) nflag = make_samp(rotv, K, s, sampv);
     DevBuf<float> dccm, dhes;
+    DevBuf<uint8_t> dpre;                                              // rot_order 2..5: this point's templates, sampled from the spline coefficients
     DevBuf<long long> dcyc;
     DevBuf<uint32_t> dgs;                                              // row-pair kernel: this point's sum w'^2 block + its offset (0)
     DevBuf<sid::PointRec> drec;                                        // ... and its record
     int rc = SID_PM_OK;
     auto cleanup = [&]() { dv.release(); dang.release(); drot.release(); dout.release(); dord.release(); dgs.release(); drec.release();
-                           dij.release(); dshape.release(); dt.release(); dccm.release(); dhes.release(); dcyc.release(); dsamp.release(); };
+                           dij.release(); dshape.release(); dt.release(); dccm.release(); dhes.release(); dcyc.release(); dsamp.release(); dpre.release(); };
     const size_t tcount = (size_t)K * s * s;
     if ((rc = dv.reserve(5)) || (rc = dang.reserve((size_t)K)) || (rc = drot.reserve(4 * (size_t)K)) ||
         (rc = dout.reserve(5)) || (rc = dord.reserve(1)) || (rc = dij.reserve(3)) || (rc = dshape.reserve(2)) ||
@@ -1364,6 +1435,13 @@ SID_EXPORT int sid_pm_debug_point(sid_pm_ctx *ctx, double c1, double r1, double 
         gauss_taps(A.gauss_w);
         A.samp = sampv.empty() ? nullptr : dsamp.p; A.samp_nflag = nflag;
         A.lds_bytes = lds;
+        const int order = (int)((flags >> 3) & 7u);
+        if (order >= 2) {
+            if (int rc2 = ensure_coef(ctx, order)) { cleanup(); return rc2; }
+            if (int rc2 = dpre.reserve(tcount)) { cleanup(); return rc2; }
+            step((hipError_t)sid::lw_presample(ctx->coef[1].p, ctx->cur[0].rows, ctx->cur[0].cols, dv.p, dv.p + 1, 1, drot.p, K, s, order, dpre.p, ctx->stream));
+            A.pre = dpre.p;
+        }
         A.gsii = dgs.p + 64; A.gsii_off = dgs.p; A.rec = drec.p;
         A.gs_keep_acc = keep_acc_policy(rp, rpp, K) ? 1u : 0u;
         step((hipError_t)(rp ? sid::launch_pm_rp(A, lds, 256, 4, rpp, 0, 3, ctx->stream)

@@ -37,6 +37,7 @@ struct PMArgs {
     // entries) keep their four offsets.  Per angle kSamp2Words u32: [n_run, n_gather, -, -][kSamp2Cap run records]
     // [kSamp2Cap x uint2 gather offsets][kSamp2Cap x u16 unit numbers i * nq + jq].
     const uint32_t *samp2;
+    const uint8_t *pre;                             // rot_order 2..5: the templates of every point [n_total][K][s][s], sampled from the spline coefficients of image 1 (lw_presample); null otherwise
     double gauss_w[5];                              // hes_smth: normalised sigma-1 Gaussian taps w[0] (|k| = 4) .. w[4] (centre), host-computed
     double *out;                                    // [n_total][5]
     int32_t *out_ij;                                // [n_total][3]

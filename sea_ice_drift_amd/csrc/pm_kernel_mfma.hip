@@ -114,6 +114,8 @@ struct Geo {
     long long r0, c0;                // window origin on image 2
     double c1, r1, nd;
     unsigned long long big;          // row-pair kernel, big layouts (rp_lds_layout): the point's block of global memory
+    unsigned long long pre;          // rot_order 2..5: this point's K templates in global memory [K][s][s], sampled from the spline coefficients
+                                     // of image 1 by lw_presample (pm_large.hip); lin is then 2 and sample_exact loads them (0: none)
 };
 // per-placement table at `off`: LDS, or - big layouts of the row-pair kernel - the point's block of global memory
 template <bool BIG, typename T>
@@ -682,7 +684,7 @@ __device__ __noinline__ void ph_patch(const uint8_t *img1, long long rows1, long
 // whenever the rounding or the image-bounds decision could depend on the last bits (|doubt| < kGuard,
 // float error < 2.5e-5) the sample is flagged and redone afterwards with scipy's double arithmetic.
 struct SampleGeom {
-    const uint8_t *patch; int ppitch, pr0, pc0, s, ngrp, ig, j; bool act, inside, lin;
+    const uint8_t *patch; const uint8_t *pre; int ppitch, pr0, pc0, s, ngrp, ig, j; bool act, inside, lin;
     float lo_r, hi_r, lo_c, hi_c;
     double c1, r1, rmax1, cmax1;
 };
@@ -702,12 +704,15 @@ __device__ __forceinline__ SampleGeom sample_geom(const Geo &G, int s, long long
     g.lo_c = (float)(-G.pc0); g.hi_c = (float)(cols1 - 1 - G.pc0);
     g.c1 = G.c1; g.r1 = G.r1; g.rmax1 = (double)(rows1 - 1); g.cmax1 = (double)(cols1 - 1);
     g.lin = G.lin != 0;
+    g.pre = reinterpret_cast<const uint8_t *>(G.pre);
     return g;
 }
 
 // exact coordinates of sample (i, j) -> pixel value (0 outside image 1)
-__device__ __forceinline__ int sample_exact(const SampleGeom &g, const double *rot4, int i, int j)
+// ka = index of the angle in the run's list (needed for pre-sampled templates only: rot_order 2..5)
+__device__ __forceinline__ int sample_exact(const SampleGeom &g, const double *rot4, int i, int j, int ka)
 {
+    if (g.pre) return g.pre[((size_t)ka * g.s + i) * g.s + j];         // sampled from the spline coefficients by lw_presample
     const double cosa = rot4[0], sina = rot4[1];
     const double off0 = g.r1 - rot4[2], off1 = g.c1 - rot4[3];
     double rr = 0.0 + (double)i * cosa;                                // NI_GeometricTransform order (matrix = transform.T)
@@ -872,7 +877,7 @@ __device__ __noinline__ void ph_tpl_general(int a0, int Kg, long long rows1, lon
                     for (int u = 0; u < kRowsPerThread; ++u) {
                         if ((dbits >> u) & 1u) {
                             const int i = g.ig + (k0 + u) * g.ngrp;
-                            const int v = sample_exact(g, m->rot[aa], i, g.j);
+                            const int v = sample_exact(g, m->rot[aa], i, g.j, a0 + aa);
                             sawzero |= (v == 0) ? 1 : 0;
                             afrag[wbase + (k0 + u) * wstep + 16 * aa] = (uint8_t)(v ^ 0x80);
                             atomicAdd(&m->isT[aa], v - 128); atomicAdd(&m->isTT[aa], (v - 128) * (v - 128));
@@ -969,7 +974,7 @@ __device__ __noinline__ void ph_tpl_fix(const uint16_t *samp, int a0, int Kg, lo
         const int ag = winner_ka < 0 ? a0 + a_lo + a : winner_ka;      // angle index in the table
         if (j >= s || !(samp[(size_t)ag * s * sp + rem] & 0x8000u)) continue;
         const double *rot4 = winner_ka < 0 ? m->rot[a] : m->rot[0];
-        const int v = sample_exact(g, rot4, i, j);
+        const int v = sample_exact(g, rot4, i, j, -1);                  // (table path: never with pre-sampled templates)
         if (winner_ka < 0) {
             (smem + G.u_off)[G.arow0 + i * arow + (j >> 4) * G.gpitch + a * 16 + (j & 15)] = (uint8_t)(v ^ 0x80);
             atomicAdd(&m->isT[a], v - 128); atomicAdd(&m->isTT[a], (v - 128) * (v - 128));
@@ -1309,7 +1314,7 @@ __device__ __noinline__ void ph_winner_stage(const double *rot4, const uint16_t 
             const u32 db = sample_fast5<false>(g, m->rot[0], true, k0, st, stt, sz,
                                                [&](int, int i, int v, bool take) { put(i, g.j, v, take); });
             for (int u = 0; u < kRowsPerThread; ++u)
-                if ((db >> u) & 1u) { const int i = g.ig + (k0 + u) * g.ngrp; put(i, g.j, sample_exact(g, m->rot[0], i, g.j)); }
+                if ((db >> u) & 1u) { const int i = g.ig + (k0 + u) * g.ngrp; put(i, g.j, sample_exact(g, m->rot[0], i, g.j, ka)); }
         }
     }
 }
@@ -1866,7 +1871,7 @@ __global__ __launch_bounds__(BAND == 8 ? 512 : kMaxBlockM, BAND == 8 ? 2 : kOccM
         G->win_magic = 0xffffffffu / (u32)(L.wpitch >> 2) + 1u; G->patch_magic = 0xffffffffu / (u32)(L.ppitch >> 2) + 1u;
         G->rw_magic = 0xffffffffu / (u32)rw + 1u;
         G->r0 = r0; G->c0 = c0; G->c1 = c1; G->r1 = r1; G->nd = (double)(s * s);
-        G->hist_off = 0; G->lin = (int)((A.flags >> 3) & 1u);
+        G->hist_off = 0; G->lin = (int)((A.flags >> 3) & 7u); G->pre = A.pre ? (unsigned long long)(A.pre + (size_t)pt * K * s * s) : 0ull;
         m->zero_flag = 0; m->gmax_key = 0x007fffffu /* f2key(-inf) */; m->qcount = 0;
         for (int k = 0; k < 5; ++k) m->gw[k] = A.gauss_w[k];
     }

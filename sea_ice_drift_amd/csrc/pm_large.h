@@ -23,6 +23,7 @@ size_t lw_scratch_bytes(int wh, int ww, int s, int K, uint32_t flags);
 // index (device-visible, 3 int32; may be null); NaN x 5 / -1 when a template touches a zero pixel (pmlib.py:152-154).
 struct LargeCall {
     const uint8_t *img1; int64_t rows1, cols1, stride1;
+    const double *d_coef = nullptr;                        // rot_order 2..5 (flags bits 3..5): image 1 through lw_spline_prefilter, [rows1][cols1]
     const uint8_t *img2; int64_t stride2;                  // image 2 (the window must lie inside it: the caller checks)
     int64_t win_r0, win_c0; int wh, ww;
     double c1, r1;
@@ -44,8 +45,15 @@ int lw_write_nan(const int32_t *d_idx, int n, double *out, int32_t *out_ij, void
 
 // get_template (pmlib.py:89-115) as a call of its own: one template of side s sampled from `d_img` - the rows [row0, row0 + nrows)
 // and columns [col0, col0 + ncols) of an image of rows x cols pixels (only that part needs to be on the device) - to d_out [s][s].
+// order 2..5: d_coef = the WHOLE image through lw_spline_prefilter (then d_img is not read).
 int lw_get_template(const uint8_t *d_img, int64_t stride, int64_t row0, int64_t col0, int64_t nrows, int64_t ncols, int64_t rows, int64_t cols,
-                    double c, double r, const double *d_rot4, int s, int order, uint8_t *d_out, void *stream);
+                    double c, double r, const double *d_rot4, int s, int order, uint8_t *d_out, void *stream, const double *d_coef = nullptr);
+// scipy.ndimage.spline_filter(img, order, output=float64, mode='constant') of a device uint8 image (pmlib.py:112-113 with rot_order =
+// 2..5: affine_transform prefilters the WHOLE image): result in buf1 [rows][cols]; buf0 = scratch of the same size.
+int lw_spline_prefilter(const uint8_t *d_img, int64_t rows, int64_t cols, int64_t stride, int order, double *buf0, double *buf1, void *stream);
+// the K templates of n points (centres d_c1 / d_r1) sampled from the prefiltered image into d_pre [n][K][s][s]
+int lw_presample(const double *d_coef, int64_t rows, int64_t cols, const double *d_c1, const double *d_r1, int64_t n, const double *d_rot, int K, int s,
+                 int order, uint8_t *d_pre, void *stream);
 // get_hessian (pmlib.py:36-59) of a float32 matrix on the device: d_hes [rh][rw] = the (normalised) Hessian magnitudes.
 int lw_get_hessian(const float *d_ccm, int rh, int rw, uint32_t flags, const double gauss_w[5], float *d_hes, LwWorkspace &W, void *stream);
 

@@ -54,6 +54,7 @@ struct LwState {
 
 struct LwParams {
     const uint8_t *img1; long long rows1, cols1, stride1, row0, col0;   // image 1 (row0 / col0: origin of the part that is on the device)
+    const double *coef;                                                 // rot_order 2..5: image 1 through scipy's spline prefilter, [rows1][cols1] float64
     const uint8_t *win; long long wstride;                             // first pixel of the window on image 2
     int wh, ww, rh, rw, s, K;
     u32 flags;
@@ -112,18 +113,152 @@ __device__ __forceinline__ int lw_sample(const uint8_t *img, long long stride, l
     return img[(ri - row0) * stride + (ci - col0)];
 }
 
+// ---- rot_order 2..5 (pmlib.py:112-113: scipy's affine_transform with order = n): spline weights and taps over the prefiltered
+// image (oracle: sid_oracle_get_template_spline; weights and coefficients pinned against scipy itself, fixture G1c against the
+// reference's get_template) ----
+__device__ __forceinline__ void lw_spline_weights(double x, int order, double *w)
+{
+    x -= floor((order & 1) ? x : x + 0.5);
+    double y = x, z = 1.0 - x, t;
+    switch (order) {
+    case 2:
+        w[1] = 0.75 - x * x;
+        y = 0.5 - x;
+        w[0] = 0.5 * y * y;
+        break;
+    case 3:
+        w[1] = (y * y * (y - 2.0) * 3.0 + 4.0) / 6.0;
+        w[2] = (z * z * (z - 2.0) * 3.0 + 4.0) / 6.0;
+        w[0] = z * z * z / 6.0;
+        break;
+    case 4:
+        t = x * x;
+        w[2] = t * (t * 0.25 - 0.625) + 115.0 / 192.0;
+        y = 1.0 + x;
+        w[1] = y * (y * (y * (5.0 - y) / 6.0 - 1.25) + 5.0 / 24.0) + 55.0 / 96.0;
+        z = 1.0 - x;
+        w[3] = z * (z * (z * (5.0 - z) / 6.0 - 1.25) + 5.0 / 24.0) + 55.0 / 96.0;
+        y = 0.5 - x;
+        t = y * y;
+        w[0] = t * t / 24.0;
+        break;
+    default:
+        t = y * y;
+        w[2] = t * (t * (0.25 - y / 12.0) - 0.5) + 0.55;
+        t = z * z;
+        w[3] = t * (t * (0.25 - z / 12.0) - 0.5) + 0.55;
+        y = x + 1.0;
+        w[1] = y * (y * (y * (y * (y / 24.0 - 0.375) + 1.25) - 1.75) + 0.625) + 0.425;
+        y = 2.0 - x;
+        w[4] = y * (y * (y * (y * (y / 24.0 - 0.375) + 1.25) - 1.75) + 0.625) + 0.425;
+        z = 1.0 - x;
+        t = z * z;
+        w[0] = z * t * t / 120.0;
+        break;
+    }
+    double last = 1.0;
+    for (int i = 0; i < order; ++i) last -= w[i];
+    w[order] = last;
+}
+
+__device__ __forceinline__ long long lw_spline_mirror(long long idx, long long len)
+{
+    if (len <= 1) return 0;
+    const long long s2 = 2 * len - 2;
+    if (idx < 0) { idx = s2 * (-idx / s2) + idx; return idx <= 1 - len ? idx + s2 : -idx; }
+    if (idx >= len) { idx -= s2 * (idx / s2); if (idx >= len) idx = s2 - idx; }
+    return idx;
+}
+
+__device__ __forceinline__ int lw_sample_spline(const double *coef, long long rows, long long cols, double c, double r, const double *rot4,
+                                                int i, int j, int order)
+{
+    const double cosa = rot4[0], sina = rot4[1];
+    const double off0 = r - rot4[2], off1 = c - rot4[3];
+    double rr = 0.0 + (double)i * cosa;
+    rr = rr + (double)j * sina;
+    rr = rr + off0;
+    double cc = 0.0 + (double)i * (-sina);
+    cc = cc + (double)j * cosa;
+    cc = cc + off1;
+    if (!(rr >= 0.0 && rr <= (double)(rows - 1) && cc >= 0.0 && cc <= (double)(cols - 1))) return 0;
+    const long long sr = (long long)floor((order & 1) ? rr : rr + 0.5) - order / 2, sc = (long long)floor((order & 1) ? cc : cc + 0.5) - order / 2;
+    double wr[6], wc[6];
+    lw_spline_weights(rr, order, wr);
+    lw_spline_weights(cc, order, wc);
+    double t = 0.0;
+    for (int a = 0; a <= order; ++a) {
+        const double *row = coef + lw_spline_mirror(sr + a, rows) * cols;
+        for (int b = 0; b <= order; ++b) t += (row[lw_spline_mirror(sc + b, cols)] * wr[a]) * wc[b];
+    }
+    t = t > 0.0 ? t + 0.5 : 0.0;
+    t = t > 255.0 ? 255.0 : t;
+    return (int)t;
+}
+
+// scipy's spline prefilter (ni_splines.c apply_filter), one pole, one direction per launch, one LINE per thread (the recursion
+// is sequential along a line; the lines - 10^4 of them - are the parallelism).  Element k of line L: base[L * line_stride +
+// k * elem_stride].  CAUSAL: c[k] = (src[k] * gain) + z c[k-1] after the mirror initialisation of c[0]; ANTICAUSAL:
+// c[k] = z (c[k+1] - src[k]) after the initialisation of c[n-1].  src and dst are different buffers (ping-pong), so that the
+// loads of a block of eight elements are issued together ahead of the dependent chain.  Every operation is scipy's, in
+// scipy's order (-ffp-contract=off); pow(z, n - 1) comes from the host's libm, as scipy's does.
+template <typename TSrc, bool CAUSAL>
+__global__ __launch_bounds__(64) void lw_spline_pass_kernel(const TSrc *__restrict__ src, double *__restrict__ dst, long long nlines, long long n,
+                                                            long long s_line, long long s_elem, long long d_line, long long d_elem,
+                                                            double z, double z_n_1, double gain)
+{
+    const long long L = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (L >= nlines) return;
+    const TSrc *sp = src + L * s_line;
+    double *dp = dst + L * d_line;
+    auto ld = [&](long long k) { return (double)sp[k * s_elem] * gain; };   // (gain = 1 after the first pass of a line: x * 1.0 is x)
+    if (CAUSAL) {
+        double z_i = z;
+        double c0 = ld(0) + z_n_1 * ld(n - 1);
+        for (long long i = 1; i < n - 1; ++i) {
+            if (z_i == 0.0) break;                                    // (the remaining terms are +-0)
+            c0 += z_i * (ld(i) + (z_n_1 != 0.0 ? z_n_1 * ld(n - 1 - i) : 0.0));
+            z_i *= z;
+        }
+        c0 /= 1 - z_n_1 * z_n_1;
+        dp[0] = c0;
+        double prev = c0;
+        for (long long i = 1; i < n; i += 8) {
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = i + u < n ? ld(i + u) : 0.0;
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (i + u < n) { prev = v[u] + z * prev; dp[(i + u) * d_elem] = prev; }
+        }
+    } else {
+        double nxt = (z * ld(n - 2) + ld(n - 1)) * z / (z * z - 1);
+        dp[(n - 1) * d_elem] = nxt;
+        for (long long i = n - 2; i >= 0; i -= 8) {
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = i - u >= 0 ? ld(i - u) : 0.0;
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (i - u >= 0) { nxt = z * (nxt - v[u]); dp[(i - u) * d_elem] = nxt; }
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void lw_templates_kernel(const LwParams P)
 {
     __shared__ long long red[256][2];
     __shared__ int redmin[256];
     const int k = blockIdx.x, tid = threadIdx.x, s = P.s;
-    const bool lin = (P.flags & 8u) != 0u;
+    const int order = (int)((P.flags >> 3) & 7u);                    // rot_order 0..5 (include/sid_pm.h SID_PM_ROT_ORDER)
+    const bool lin = order == 1;
     uint8_t *T = P.tmpl + (size_t)k * s * s;
     long long st = 0, stt = 0;
     int vmin = 255;
     for (int idx = tid; idx < s * s; idx += 256) {
         const int i = idx / s, j = idx - i * s;
-        const int v = lw_sample(P.img1, P.stride1, P.row0, P.col0, P.rows1, P.cols1, P.c1, P.r1, P.rot + 4 * k, i, j, lin);
+        const int v = order >= 2 ? lw_sample_spline(P.coef, P.rows1, P.cols1, P.c1, P.r1, P.rot + 4 * k, i, j, order)
+                                 : lw_sample(P.img1, P.stride1, P.row0, P.col0, P.rows1, P.cols1, P.c1, P.r1, P.rot + 4 * k, i, j, lin);
         T[idx] = (uint8_t)v;
         const long long tp = v - 128;
         st += tp; stt += tp * tp;
@@ -618,7 +753,8 @@ int lw_run(const LargeCall &c, LwWorkspace &W, void *stream)
         return -1;
     LwParams P;
     memset(&P, 0, sizeof P);
-    P.img1 = c.img1; P.rows1 = c.rows1; P.cols1 = c.cols1; P.stride1 = c.stride1; P.row0 = 0; P.col0 = 0;
+    P.img1 = c.img1; P.rows1 = c.rows1; P.cols1 = c.cols1; P.stride1 = c.stride1; P.row0 = 0; P.col0 = 0; P.coef = c.d_coef;
+    if (((c.flags >> 3) & 7u) > 5u || (((c.flags >> 3) & 7u) >= 2u && !c.d_coef)) return (int)hipErrorInvalidValue;
     P.win = c.img2 + c.win_r0 * c.stride2 + c.win_c0; P.wstride = c.stride2;
     P.wh = c.wh; P.ww = c.ww; P.rh = rh; P.rw = rw; P.s = s; P.K = K; P.flags = c.flags;
     P.c1 = c.c1; P.r1 = c.r1; P.rot = c.d_rot; P.angles = c.d_angles; P.add_c = c.add_c; P.add_r = c.add_r;
@@ -670,6 +806,79 @@ const float *lw_ncc_matrix(const LwWorkspace &W, int wh, int ww, int s, int k)
 
 const uint8_t *lw_template(const LwWorkspace &W, int s, int k) { return static_cast<const uint8_t *>(W.buf[B_TMPL]) + (size_t)k * s * s; }
 
+namespace {
+// rot_order 2..5 in the batch path: the K templates of every point of a run, sampled from the prefiltered image 1 into global
+// memory [n][K][s][s]; the one-workgroup-per-point kernels then LOAD their templates (sample_exact with Geo::pre) instead of
+// sampling - the float64 coefficient patch of a point would not fit their LDS.  One workgroup per (point, angle).
+__global__ __launch_bounds__(256) void lw_presample_kernel(const double *coef, long long rows, long long cols, const double *c1v, const double *r1v,
+                                                           const double *rot, int K, int s, int order, uint8_t *pre)
+{
+    const long long pt = blockIdx.x / K;
+    const int k = blockIdx.x - (int)(pt * K);
+    const double c1 = c1v[pt], r1 = r1v[pt];
+    uint8_t *T = pre + ((size_t)pt * K + k) * (size_t)s * s;
+    for (int idx = threadIdx.x; idx < s * s; idx += 256) {
+        const int i = idx / s, j = idx - i * s;
+        T[idx] = (uint8_t)lw_sample_spline(coef, rows, cols, c1, r1, rot + 4 * k, i, j, order);
+    }
+}
+const double kPoles[6][2] = {{0, 0}, {0, 0}, {-0.171572875253809902396622551581, 0}, {-0.267949192431122706472553658494, 0},
+                             {-0.361341225900220177092212841325, -0.013725429297339121360331226939},
+                             {-0.430575347099973791851434783493, -0.043096288203264653822712839920}};
+}  // namespace
+
+int lw_spline_prefilter(const uint8_t *d_img, int64_t rows, int64_t cols, int64_t stride, int order, double *buf0, double *buf1, void *stream)
+{
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (order < 2 || order > 5 || rows < 1 || cols < 1) return (int)hipErrorInvalidValue;
+    const int npoles = order / 2;
+    double gain = 1.0;
+    for (int p = 0; p < npoles; ++p) { const double z = kPoles[order][p]; gain *= (1.0 - z) * (1.0 - 1.0 / z); }
+    // axis 0 (lines = columns: element stride = a row), then axis 1 (lines = rows); scipy skips an axis of length 1
+    const double *cur = nullptr;                                       // null: the uint8 image is the source
+    auto pass = [&](bool causal, long long nlines, long long n, long long s_line, long long s_elem, long long d_line, long long d_elem,
+                    double z, double g, double *dst) {
+        const double z_n_1 = pow(z, (double)(n - 1));
+        const unsigned nb = (unsigned)((nlines + 63) / 64);
+        if (!cur) {
+            if (causal) hipLaunchKernelGGL((lw_spline_pass_kernel<uint8_t, true>), dim3(nb), dim3(64), 0, st, d_img, dst, nlines, n, s_line, s_elem, d_line, d_elem, z, z_n_1, g);
+            else hipLaunchKernelGGL((lw_spline_pass_kernel<uint8_t, false>), dim3(nb), dim3(64), 0, st, d_img, dst, nlines, n, s_line, s_elem, d_line, d_elem, z, z_n_1, g);
+        } else {
+            if (causal) hipLaunchKernelGGL((lw_spline_pass_kernel<double, true>), dim3(nb), dim3(64), 0, st, cur, dst, nlines, n, s_line, s_elem, d_line, d_elem, z, z_n_1, g);
+            else hipLaunchKernelGGL((lw_spline_pass_kernel<double, false>), dim3(nb), dim3(64), 0, st, cur, dst, nlines, n, s_line, s_elem, d_line, d_elem, z, z_n_1, g);
+        }
+        cur = dst;
+    };
+    bool first = true;
+    for (int axis = 0; axis < 2; ++axis) {
+        const long long n = axis == 0 ? rows : cols, nlines = axis == 0 ? cols : rows;
+        if (n <= 1) continue;
+        for (int p = 0; p < npoles; ++p) {
+            const double z = kPoles[order][p];
+            // causal: cur (or the image) -> buf0; anticausal: buf0 -> buf1
+            const long long sl = cur ? (axis == 0 ? 1 : cols) : (axis == 0 ? 1 : stride), se = cur ? (axis == 0 ? cols : 1) : (axis == 0 ? stride : 1);
+            const long long dl = axis == 0 ? 1 : cols, de = axis == 0 ? cols : 1;
+            pass(true, nlines, n, sl, se, dl, de, z, (p == 0) ? gain : 1.0, buf0);      // (apply_filter multiplies the line by the gain first, on every axis)
+            pass(false, nlines, n, dl, de, dl, de, z, 1.0, buf1);
+            first = false;
+        }
+    }
+    if (first) {                                                       // a 1 x 1 image: the coefficients are the pixels
+        return (int)hipErrorInvalidValue;
+    }
+    return (int)hipGetLastError();
+}
+
+int lw_presample(const double *d_coef, int64_t rows, int64_t cols, const double *d_c1, const double *d_r1, int64_t n, const double *d_rot, int K, int s,
+                 int order, uint8_t *d_pre, void *stream)
+{
+    if (n <= 0) return 0;
+    if ((int64_t)n * K > 0x7fffffffll) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(lw_presample_kernel, dim3((unsigned)(n * K)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), d_coef, (long long)rows, (long long)cols,
+                       d_c1, d_r1, d_rot, K, s, order, d_pre);
+    return (int)hipGetLastError();
+}
+
 int lw_write_nan(const int32_t *d_idx, int n, double *out, int32_t *out_ij, void *stream)
 {
     if (n <= 0) return 0;
@@ -678,14 +887,14 @@ int lw_write_nan(const int32_t *d_idx, int n, double *out, int32_t *out_ij, void
 }
 
 int lw_get_template(const uint8_t *d_img, int64_t stride, int64_t row0, int64_t col0, int64_t nrows, int64_t ncols, int64_t rows, int64_t cols,
-                    double c, double r, const double *d_rot4, int s, int order, uint8_t *d_out, void *stream)
+                    double c, double r, const double *d_rot4, int s, int order, uint8_t *d_out, void *stream, const double *d_coef)
 {
     (void)nrows; (void)ncols;
-    if (s < 1 || s > 4096) return (int)hipErrorInvalidValue;
+    if (s < 1 || s > 4096 || order < 0 || order > 5 || (order >= 2 && !d_coef)) return (int)hipErrorInvalidValue;
     LwParams P;
     memset(&P, 0, sizeof P);
     P.img1 = d_img; P.rows1 = rows; P.cols1 = cols; P.stride1 = stride; P.row0 = row0; P.col0 = col0;
-    P.s = s; P.K = 1; P.flags = order == 1 ? 8u : 0u; P.c1 = c; P.r1 = r; P.rot = d_rot4; P.tmpl = d_out;
+    P.s = s; P.K = 1; P.flags = (uint32_t)order << 3; P.c1 = c; P.r1 = r; P.rot = d_rot4; P.tmpl = d_out; P.coef = d_coef;
     hipLaunchKernelGGL(lw_templates_kernel, dim3(1), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), P);
     return (int)hipGetLastError();
 }

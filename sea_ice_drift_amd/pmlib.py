@@ -12,7 +12,7 @@ The structure is  prelude (host, NumPy)  ->  dispatch (GPU)  ->  postlude (host,
 * the dispatch replaces the ``multiprocessing.Pool.map`` of pmlib.py:436-448 with the HIP
   kernel behind the C ABI (``_capi``).  ``threads`` is accepted for signature compatibility
   and ignored.  There is no CPU fallback: without the HIP library / a gfx950 device this
-  raises.  Options the kernels do not implement (``rot_order`` above 1, an ``mtype`` other
+  raises.  Options the kernels do not implement (an ``mtype`` other
   than TM_CCOEFF_NORMED, a user ``template_matcher``, ``img_size`` outside 2..255) raise
   ``NotImplementedError``;
 * ``pm_postlude``  turns the (N,5) result block into the seven output grids as
@@ -191,13 +191,13 @@ def _sweep_options(kwargs):
     if mtype is not None and (isinstance(mtype, bool) or mtype != TM_CCOEFF_NORMED):
         raise NotImplementedError('mtype=%r: the device matcher implements cv2.TM_CCOEFF_NORMED (%d) only (pmlib.py:119,156)'
                                   % (mtype, TM_CCOEFF_NORMED))
-    # rot_order (pmlib.py:89,112-113): scipy's spline order of the template rotation.  0 (nearest, the default) and 1
-    # (bilinear, scipy's double arithmetic and uint8 rounding) run on the device; orders 2..5 filter the WHOLE image 1 with
-    # scipy's recursive B-spline prefilter before sampling - a different algorithm over 10^8 pixels, not implemented.
+    # rot_order (pmlib.py:89,112-113): scipy's spline order of the template rotation, 0..5, all on the device: 0 (nearest, the
+    # default), 1 (bilinear), 2..5 (the WHOLE image 1 through scipy's recursive B-spline prefilter once per pair, then n + 1
+    # weights per axis per sample) - scipy's float64 arithmetic and uint8 rounding, operation for operation.  Anything else is
+    # what scipy itself refuses ('spline order not supported').
     rot_order = kwargs.get('rot_order', 0)
-    if isinstance(rot_order, bool) or rot_order not in (0, 1):
-        raise NotImplementedError('rot_order=%r: templates are sampled nearest-neighbour (0) or bilinear (1); orders 2..5 need '
-                                  "scipy's whole-image spline prefilter" % (rot_order,))
+    if isinstance(rot_order, bool) or rot_order not in (0, 1, 2, 3, 4, 5):
+        raise RuntimeError('rot_order=%r: spline order not supported (scipy.ndimage.affine_transform takes 0..5)' % (rot_order,))
     angles = list(kwargs.get('angles', [-3, 0, 3]))
     flags = _capi.flags_from_kwargs(hes_norm=kwargs.get('hes_norm', True), hes_smth=kwargs.get('hes_smth', False),
                                     mcc_norm=kwargs.get('mcc_norm', False), rot_order=int(rot_order))
@@ -279,9 +279,8 @@ def pm_dispatch(img1, img2, c1, r1, c2fg, r2fg, border, img_size, alpha0, device
 def get_template(img, c, r, a, s, rot_order=0, **kwargs):
     """Rotated and shifted square template: same signature and return as the reference's get_template (pmlib.py:89-115) -
     the (s, s) uint8 array scipy's affine_transform would give for ``rot_order`` 0 or 1, sampled on the GPU."""
-    if isinstance(rot_order, bool) or rot_order not in (0, 1):
-        raise NotImplementedError("rot_order=%r: templates are sampled nearest-neighbour (0) or bilinear (1); orders 2..5 need "
-                                  "scipy's whole-image spline prefilter" % (rot_order,))
+    if isinstance(rot_order, bool) or rot_order not in (0, 1, 2, 3, 4, 5):
+        raise RuntimeError('rot_order=%r: spline order not supported (scipy.ndimage.affine_transform takes 0..5)' % (rot_order,))
     return _capi.get_template(img, c, r, rotation_terms(a, s), s, rot_order=int(rot_order), device=int(kwargs.get('device', 0)))
 
 

@@ -12,6 +12,9 @@ them, with a sha256) and the outputs the reference's functions returned:
                      template_matcher=<restated TM_CCOEFF_NORMED> injected through the
                      reference's own plug point (cv2 is absent: parity unpinned at that call)
   g3b_use_mcc_order1.npz  pmlib.use_mcc(rot_order=1) on G3's pair and points
+  g1c_templates_spline.npz  pmlib.get_template(rot_order = 2..5): scipy's whole-image spline prefilter + order-n interpolation
+                     (pmlib.py:89-115) on a smooth image and on G1's noise image, incl. templates cut by the image border
+  g3d_use_mcc_spline.npz  pmlib.use_mcc(rot_order = 2, 3, 5) on G3's pair and points
   g3c_large_rotations.npz  pmlib.use_mcc on G3's pair and points with scene rotations alpha0 of 30, 90 and -137.5 degrees
                      (pmlib.py:79-87,151: the sampling angle is angle - alpha0), rot_order 0 and 1, sizes 34 / 35
   g8_rotate_and_match.npz  pmlib.rotate_and_match called directly (pmlib.py:117-174) - the shape of the reference's own test
@@ -118,6 +121,40 @@ def make_g3b(pmlib):
     np.savez_compressed(os.path.join(HERE, 'g3b_use_mcc_order1.npz'), **d)
 
 
+def g1c_image():
+    """A smooth positive image (the spline orders overshoot on noise and hit 0 = the reference's NaN rule)."""
+    return syn.make_pair(400, 400, seed=111)[0]
+
+
+G1C_CASES = [(200, 150, 0, 34), (200.3, 150.7, 7.5, 35), (123.5, 321.5, -9, 34), (50.49999, 60.5, 45, 35), (210, 220, 90, 34),
+             (300.25, 100.75, -137.5, 35), (5, 5, 10, 34), (390.5, 17.25, -6, 35), (399, 399, 0, 35), (0, 0, 0, 34), (200, 200, 3, 64)]
+
+
+def make_g1c(pmlib):
+    d = dict(img_sha=syn.sha256(g1c_image()), noise_sha=syn.sha256(g1_image()), cases=np.array(G1C_CASES, dtype=np.float64))
+    for name, img in (('smooth', g1c_image()), ('noise', g1_image())):
+        for order in (2, 3, 4, 5):
+            for k, (c, r, a, s) in enumerate(G1C_CASES):
+                d['%s_o%d_%d' % (name, order, k)] = pmlib.get_template(img, c, r, a, s, rot_order=order)
+    np.savez_compressed(os.path.join(HERE, 'g1c_templates_spline.npz'), **d)
+
+
+def make_g3d(pmlib):
+    """use_mcc(..., rot_order = 2 / 3 / 5) on G3's pair and points (restated matcher injected as in G3)."""
+    img1, img2 = g3_pair()
+    c1, r1, c2fg, r2fg, border = g3_points()
+    d = dict(pair_sha=syn.sha256(img1, img2))
+    for s, alpha0, order, k in G3D_CASES:
+        angles = G3_ANGLE_SETS[k]
+        res = np.array([pmlib.use_mcc(c1[i], r1[i], c2fg[i], r2fg[i], border[i], img1, img2, s, alpha0,
+                                      angles=angles, rot_order=order, template_matcher=c_oracle.match_template)
+                        for i in range(len(c1))], dtype=np.float64)
+        d['out_s%d_o%d_k%d' % (s, order, k)] = res
+        d['alpha0_s%d_o%d_k%d' % (s, order, k)] = alpha0
+    np.savez_compressed(os.path.join(HERE, 'g3d_use_mcc_spline.npz'), **d)
+
+
+G3D_CASES = ((34, 0.0, 3, 0), (35, -3.85, 3, 2), (34, 30.0, 2, 1), (35, 0.0, 5, 0), (34, -3.85, 4, 0))   # s, alpha0, rot_order, angle set
 G3C_ALPHA0 = [30.0, 90.0, -137.5]
 G3C_ANGLE_SETS = [[-3, 0, 3], list(range(-7, 8))]
 
@@ -435,7 +472,7 @@ def make_g7():
 
 
 def main():
-    which = sys.argv[1:] or ['g1', 'g1b', 'g2', 'g3', 'g3b', 'g3c', 'g4', 'g5', 'g6', 'g7', 'g8']
+    which = sys.argv[1:] or ['g1', 'g1b', 'g1c', 'g2', 'g3', 'g3b', 'g3c', 'g3d', 'g4', 'g5', 'g6', 'g7', 'g8']
     if 'g7' in which:
         t = time.time()
         make_g7()
@@ -446,7 +483,7 @@ def main():
         make_g6(reflib)
         print('g6 done in %.1f s' % (time.time() - t))
     c_oracle.build()
-    for name, fn in (('g1', make_g1), ('g1b', make_g1b), ('g2', make_g2), ('g3', make_g3), ('g3b', make_g3b), ('g3c', make_g3c), ('g4', make_g4), ('g8', make_g8)):
+    for name, fn in (('g1', make_g1), ('g1b', make_g1b), ('g1c', make_g1c), ('g3d', make_g3d), ('g2', make_g2), ('g3', make_g3), ('g3b', make_g3b), ('g3c', make_g3c), ('g4', make_g4), ('g8', make_g8)):
         if name in which:
             t = time.time()
             fn(pmlib)

@@ -103,8 +103,8 @@ def test_rotation_table_matches_reference_formula():
 def test_unsupported_options_raise_instead_of_falling_back():
     img = np.ones((200, 200), dtype=np.uint8)
     args = ([100.0], [100.0], [100.0], [100.0], [20.0], 34, 0.0)
-    for order in (2, 3, 5, -1, True):                # scipy spline orders above 1 prefilter the whole image: not implemented
-        with pytest.raises(NotImplementedError):
+    for order in (6, -1, True):                      # scipy's spline orders are 0..5 (all on the device since round 6); scipy raises RuntimeError
+        with pytest.raises(RuntimeError):
             my.pm_dispatch(img, img, *args, rot_order=order)
     with pytest.raises(NotImplementedError):
         my.pm_dispatch(img, img, *args, template_matcher=lambda *a: None)
@@ -114,9 +114,9 @@ def test_unsupported_options_raise_instead_of_falling_back():
         with pytest.raises(NotImplementedError):
             my.pm_dispatch(img, img, *args, mtype=mtype)
     assert my.TM_CCOEFF_NORMED == 5
-    for ok in ({}, {'mtype': None}, {'mtype': 5}, {'rot_order': 0}, {'rot_order': 1}, {'mtype': 5, 'rot_order': 1}):
+    for ok in ({}, {'mtype': None}, {'mtype': 5}, {'rot_order': 0}, {'rot_order': 1}, {'mtype': 5, 'rot_order': 1}, {'rot_order': 3}, {'rot_order': 5}):
         angles, flags = my._sweep_options(dict(ok))
-        assert angles == [-3, 0, 3] and flags == (1 | (8 if ok.get('rot_order') == 1 else 0))
+        assert angles == [-3, 0, 3] and flags == (1 | (ok.get('rot_order', 0) << 3))
 
 
 def test_api_surface():

@@ -210,3 +210,54 @@ def test_g3c_large_rotations(c_oracle, s):
                 if k == 0 and ai == 2:
                     got_n, _ = po.pm_batch(img1, img2, *v, s, alpha0, angles, flags=flags)
                     np.testing.assert_array_equal(got_n, exp)
+
+
+# ---------------------------------------------------------------- G1c / G3d rot_order 2..5 (scipy's spline interpolation)
+@pytest.mark.parametrize('order', [2, 3, 4, 5])
+def test_spline_restatement_is_scipys_own_arithmetic(c_oracle, order):
+    """The prefilter against scipy.ndimage.spline_filter and the interpolation weights against scipy's own, read out through
+    map_coordinates(prefilter=False) on impulse images - bit for bit, NumPy and C forms."""
+    import math
+    from scipy import ndimage as nd
+    rng = np.random.default_rng(50 + order)
+    for shape in ((2, 3), (5, 17), (64, 31), (300, 280)):
+        img = rng.integers(0, 256, shape, dtype=np.uint8)
+        ref = nd.spline_filter(img, order, output=np.float64, mode='constant')
+        np.testing.assert_array_equal(po.spline_coefficients(img, order), ref)
+        np.testing.assert_array_equal(c_oracle.spline_coefficients(img, order), ref)
+    xs = np.concatenate([rng.uniform(8, 30, 500), [10.0, 10.5, 11.25]])
+    w = po.spline_weights(xs, order)
+    for x, wx in zip(xs, np.array(w).T):
+        base = math.floor(x) - order // 2 if order & 1 else math.floor(x + 0.5) - order // 2
+        for t in range(order + 1):
+            imp = np.zeros(41)
+            imp[base + t] = 1.0
+            assert nd.map_coordinates(imp, [[x]], order=order, prefilter=False, mode='constant')[0] == wx[t]
+
+
+@pytest.mark.parametrize('order', [2, 3, 4, 5])
+def test_g1c_templates_spline_numpy_and_c(c_oracle, order):
+    g = load('g1c_templates_spline.npz')
+    for name, img in (('smooth', mg.g1c_image()), ('noise', mg.g1_image())):
+        assert syn.sha256(img) == str(g['img_sha' if name == 'smooth' else 'noise_sha'])
+        cf = po.spline_coefficients(img, order)
+        for k, (c, r, a, s) in enumerate(mg.G1C_CASES):
+            exp = g['%s_o%d_%d' % (name, order, k)]
+            np.testing.assert_array_equal(po.get_template_spline(img, c, r, a, int(s), order, coeffs=cf), exp)
+            np.testing.assert_array_equal(c_oracle.get_template(img, c, r, po.rotation_terms(a, int(s)), int(s), rot_order=order, coeffs=cf), exp)
+
+
+@pytest.mark.parametrize('case', mg.G3D_CASES)
+def test_g3d_use_mcc_spline(c_oracle, case):
+    s, alpha0, order, k = case
+    g = load('g3d_use_mcc_spline.npz')
+    g3 = load('g3_use_mcc.npz')
+    img1, img2 = mg.g3_pair()
+    v = [g3[x] for x in ('c1', 'r1', 'c2fg', 'r2fg', 'border')]
+    angles = mg.G3_ANGLE_SETS[k]
+    exp = g['out_s%d_o%d_k%d' % (s, order, k)]
+    got, ij = c_oracle.pm_batch(img1, img2, *v, s, alpha0, angles, rot=rot_for(angles, alpha0, s), flags=1 | po.flag_rot_order(order), nthreads=4)
+    np.testing.assert_array_equal(got, exp)
+    if k == 0 and order == 3:
+        got_n, _ = po.pm_batch(img1, img2, *v, s, alpha0, angles, flags=1 | po.flag_rot_order(order))
+        np.testing.assert_array_equal(got_n, exp)
