@@ -404,6 +404,23 @@ def seam_inclusive(args, img1, img2, g, s, angles, rot, local_rank, res, res_ij)
                     'never `value`' % (2 * img1.size // 1000000)}
 
 
+def rank_devices(torch, dist, dev):
+    """One record per rank of the process group - host, device index, name, architecture, compute units (256 = 8 XCDs x 32), uuid,
+    PCI address - gathered with all_gather_object at set-up: evidence in the bench line of how many GPUs the collective really spans."""
+    p = torch.cuda.get_device_properties(dev)
+    mine = {'rank': dist.get_rank() if dist.is_initialized() else 0, 'host': socket.gethostname(), 'device_index': int(dev.index or 0),
+            'name': p.name, 'arch': getattr(p, 'gcnArchName', None), 'compute_units': int(p.multi_processor_count),
+            'xcds': int(p.multi_processor_count) // 32 if int(p.multi_processor_count) % 32 == 0 else None,
+            'uuid': str(getattr(p, 'uuid', '')) or None,
+            'pci_bus_id': ('%04x:%02x:%02x' % (getattr(p, 'pci_domain_id', 0), p.pci_bus_id, getattr(p, 'pci_device_id', 0))) if hasattr(p, 'pci_bus_id') else None,
+            'hbm_gb': round(p.total_memory / 1e9, 1)}
+    if not (dist.is_available() and dist.is_initialized()):
+        return [mine]
+    rows = [None] * dist.get_world_size()
+    dist.all_gather_object(rows, mine)
+    return rows
+
+
 def grid_mode(args, torch, dist, dev, world, rank, local_rank):
     import numpy as np
     from sea_ice_drift_amd import synthetic as syn
@@ -437,6 +454,7 @@ def grid_mode(args, torch, dist, dev, world, rank, local_rank):
     from sea_ice_drift_amd.dist import per_rank_breakdown
     per_rank = per_rank_breakdown([kern_ms, exchange['gather_ms'], exchange['unpermute_ms'], exchange['d2h_ms'], len(run.idx),
                                    run.info['launches']], dev) if (world > 1 or args.force_collective) else None
+    devices_seen = rank_devices(torch, dist, dev) if (world > 1 or args.force_collective) else None
     run.poisoned_step()                                    # untimed; the parity check below reads this step's output
     res, res_ij = run.results() if rank == 0 else (None, None)
     n_total, info, g = run.n_total, run.info, run.g
@@ -517,6 +535,11 @@ def grid_mode(args, torch, dist, dev, world, rank, local_rank):
                                                  if getattr(run.gather, 'device_unpermute', False) else 'index_select x2 + one copy to the host'),
                                      'collectives': 'broadcast x2 (pair), all_reduce(MAX) + gather (indices) at set-up, one gather of '
                                                     'the packed block per step',
+                                     # what the process group itself reports: the ranks it holds and the device each one runs on
+                                     # (distinct uuids / PCI addresses = N GPUs; equal ones = a dry run of N ranks sharing a GPU)
+                                     'world_size_seen_by_the_process_group': dist.get_world_size() if dist.is_initialized() else 1,
+                                     'devices': devices_seen,
+                                     'distinct_devices': len({(d.get('uuid'), d.get('pci_bus_id'), d.get('host')) for d in devices_seen}) if devices_seen else None,
                                      'per_rank': {'kernel_ms': [float(v) for v in kcol], 'gather_ms': [float(v) for v in per_rank[:, 1]],
                                                   'points': [int(v) for v in per_rank[:, 4]], 'launches': [int(v) for v in per_rank[:, 5]]},
                                      'slowest_rank': int(kcol.argmax()), 'slowest_kernel_ms': float(kcol.max()),
