@@ -229,7 +229,7 @@ void make_samp2(const std::vector<uint16_t> &tab, int K, int s, std::vector<uint
 // borders whose LDS footprint fits four times (SID_PM_NO_OCC4=1: off; A/B runs).
 constexpr bool kRecycleAllDefault = true;    // (round 6: -1.0 % on the 15-angle step, HBM traffic 12.7x -> 10.1x the algorithmic bytes: profiles/r06_ab_recycle_all.txt)
 constexpr int kMaxPerCu = 3;
-constexpr int kW3MaxLds = 40960;   // every window of pitch 104 that fits four times (borders 20 .. 23 at 34 / 35 px; measured per border: tools/r4_w3.sh)
+constexpr int kW3MaxLds = 40960;   // every window of pitch 104 that fits four times (borders 20 .. 23 at 34 / 35 px; measured per border: tools/archive/r4_w3.sh)
 // four workgroups per CU need the 128-VGPR build of the row-pair kernel (pm_kernel_rp_occ4.hip): the slot-group layouts only.
 // (Round 4 measured it for the full operand table as well - with sum w'^2 in global memory borders 20-26 fit four per CU:
 // border 20 +1.6 %, border 26 +5 % against three per CU with the sums in LDS; not shipped.)  SID_PM_NO_OCC4=1: never (A/B runs)
@@ -443,7 +443,7 @@ ShapeClass shape_class(bool rp, int rpp, int wh, int ww, int s, int K, uint32_t 
     }
     if (force_gs || getenv("SID_PM_ALWAYS_GS") != nullptr) return g;
     // slot groups: since their gs launches keep sum w' for the winner as well, the gs form is ahead at every border (3 / 7 angles,
-    // mixed: -0.9 %; borders 25 / 26: -0.8 %; tools/r4_env_ab.sh) - unless the round-3 classes were asked for (SID_PM_NO_W3)
+    // mixed: -0.9 %; borders 25 / 26: -0.8 %; tools/archive/r4_env_ab.sh) - unless the round-3 classes were asked for (SID_PM_NO_W3)
     if (rpp > 0 && w3_max_lds() > 0 && getenv("SID_PM_NO_GS") == nullptr && getenv("SID_PM_NO_GSI") == nullptr) return g;
     const ShapeClass l = eval(false);
     if (l.band == 8 || l.nat_pitch > 112 || l.lds > sid::max_lds_bytes()) return g;   // (no instantiation without gs)
@@ -1547,7 +1547,7 @@ static int estimate_points(const double *border, int64_t n, int img_size, int n_
     struct Fit { double sweep, winner, pos, fixed, two, one, gs, four; };
     static const Fit kFit[3] = {{3.4646e-3, 2.2848e-2, 7.6082e-3, 29.955, 1.1228, 1.2800, 1.06500, 0.88700},
                                 {3.9853e-3, 1.7996e-2, 7.6297e-3, 25.686, 1.2348, 1.3287, 0.99236, 0.91000},
-                                {2.5923e-3, 1.8513e-2, 6.4734e-3, 24.173, 1.2518, 1.3574, 1.00890, 0.86000}};   // (last column: the three-wavefront class, refitted to tools/r4_w3.sh / r4_w3p.sh)
+                                {2.5923e-3, 1.8513e-2, 6.4734e-3, 24.173, 1.2518, 1.3574, 1.00890, 0.86000}};   // (last column: the three-wavefront class, refitted to tools/archive/r4_w3.sh / r4_w3p.sh)
     const Fit &F = kFit[rpp];
     constexpr double kBigFactor = 1.25;   // every per-placement table through L2 / HBM (measured at borders 70 .. 100: tools/border_cost.py)
     const double kSweep = F.sweep, kWinner = F.winner, kPos = F.pos, kFixed = F.fixed, kTwoPerCu = F.two, kOnePerCu = F.one, kFourPerCu = F.four;
