@@ -129,12 +129,14 @@ int sid_pm_bind_pair(sid_pm_ctx *ctx,
 /* Host vectors of the n points + the sweep parameters.  Validates, orders the points by
  * search-window size (largest first, for load balance), groups them by LDS footprint and
  * uploads them; the points stay resident until the next call.
- * Device scratch reserved here (grow-only, freed by sid_pm_destroy): 48 B + 52 B per point for records and results, and a
- * block of global memory for every point whose launch keeps per-placement tables there - 8 B per placement of the search
- * window (14 KB at border 20, 83 KB at border 50; template sides 34 / 35 only), every table of the point beyond border 68
- * (0.6 MB at border 111); points whose launch keeps its sums in LDS get none.  Angle sets of at most 3 angles (and of at most
- * 7 in the smallest windows) take their blocks - 16 / 32 B per placement more - from 2048 recycled ones instead, whatever n.
- * SID_PM_ERR_NOMEM with the numbers when the device cannot hold it. */
+ * Device scratch reserved here (grow-only, freed by sid_pm_destroy): 48 B + 52 B per point for records and results; for the
+ * launches that keep per-placement tables in global memory (template sides 34 / 35) 8192 RECYCLED blocks of the largest such
+ * table, whatever n - 8 B per placement of the search window (14 KB at border 20, 83 KB at border 50), 16 / 32 B per placement
+ * more for angle sets of at most 3 / 7 angles (they keep the sweep's accumulators as well): 0.7 - 2 GB; beyond border 68 a block
+ * of its own per point for every table of the point (0.6 MB at border 111).  Points whose launch keeps its sums in LDS get none;
+ * points beyond one workgroup's LDS (SID_PM_CLASS_LARGE) share the scratch of the large-window pipeline (sid_pm_rotate_and_match).
+ * rot_order 2..5: + 16 B per pixel of image 1 (spline coefficients, at the first run on a pair) + n x n_angles x img_size^2 B
+ * (pre-sampled templates).  SID_PM_ERR_NOMEM with the numbers when the device cannot hold it. */
 int sid_pm_set_points(sid_pm_ctx *ctx, const double *c1, const double *r1, const double *c2fg,
                       const double *r2fg, const double *border, int64_t n, int img_size,
                       double alpha0, const double *angles, const double *rot, int n_angles,

@@ -93,9 +93,12 @@ def test_unsupported_sizes_and_flags_are_errors(pm_ctx):
     assert e.value.code == -4
     with pytest.raises(_capi.SidPmError):
         pm_ctx.set_points(*one, 34, 0.0, [])
-    with pytest.raises(_capi.SidPmError) as e:                     # unknown flag bit (8 = SID_PM_ROT_ORDER1 is one now)
-        pm_ctx.set_points(*one, 34, 0.0, [0.0], flags=16)
+    with pytest.raises(_capi.SidPmError) as e:                     # unknown flag bit (bits 3..5 = SID_PM_ROT_ORDER(n))
+        pm_ctx.set_points(*one, 34, 0.0, [0.0], flags=64)
     assert e.value.code == -1
+    with pytest.raises(_capi.SidPmError) as e:                     # rot_order 6: scipy has orders 0..5
+        pm_ctx.set_points(*one, 34, 0.0, [0.0], flags=1 | (6 << 3))
+    assert e.value.code == -4
     # a border too large for the LDS of one workgroup is no longer an error: the large-window pipeline takes the point
     pm_ctx.set_points([150.0], [150.0], [150.0], [150.0], [112.0], 34, 0.0, [0.0])
     pm_ctx.run()

@@ -12,7 +12,7 @@ while [ $# -gt 0 ]; do
     /opt/rocm/bin/hipcc $FLAGS $defs -c -o $O/ab/${name}_occ4.o pm_kernel_rp_occ4.hip &
     /opt/rocm/bin/hipcc $FLAGS $defs -c -o $O/ab/${name}_capi.o pm_capi.hip &
     wait
-    /opt/rocm/bin/hipcc $FLAGS -shared -o $AB/lib_${name}.so $O/ab/${name}_mfma.o $O/ab/${name}_occ4.o $O/ab/${name}_capi.o $O/ft_match.o $O/stage.o $O/orb.o $O/first_guess.o
+    /opt/rocm/bin/hipcc $FLAGS -shared -o $AB/lib_${name}.so $O/ab/${name}_mfma.o $O/ab/${name}_occ4.o $O/ab/${name}_capi.o $O/pm_large.o $O/ft_match.o $O/stage.o $O/orb.o $O/first_guess.o
     echo "built $AB/lib_${name}.so" ) &
   # two variants at a time (8 cores, ~3 compilers each)
   if [ $(jobs -r | wc -l) -ge 2 ]; then wait -n; fi
