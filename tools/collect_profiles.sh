@@ -26,7 +26,7 @@ print(json.dumps({
  'launches_per_step': launches, 'fetch_bytes_per_step_raw': fetch / 2.0, 'fetch_correction': 2.0, 'fetch_bytes_per_step': fetch,
  'write_bytes_per_step': write, 'hbm_bytes_per_step': fetch + write, 'hbm_bytes_per_launch': (fetch + write) / max(launches, 1),
  'source': 'rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `python3 bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-also-defaults --check 0` (%d dispatches = 6 steps: warm-up, 4 timed, 1 for the parity check), summed with tools/pmc_traffic.py (tools/collect_profiles.sh)' % disp,
- 'note': 'fetch: search windows, image-1 patches, the sampling table, and the per-placement sums (sum w^2, sum w) that the ~35 000 points of the gs launches - the three-wavefront class and borders 28 .. 50 - keep in their exclusive block of global memory and read back once or twice (from L2 when it still holds them, else HBM); write: those sums, 8 B per placement, written once per step and point (every launch position has a block of its own: nothing is recycled in the 15-angle launches, so all of it reaches HBM) + register spills; the results go to pinned host memory; algorithmic bytes = both images once (0.2 GB per step)'}, indent=1))
+ 'note': 'fetch: search windows, image-1 patches, the sampling table, and the per-placement sums (sum w^2, sum w) that the ~35 000 points of the gs launches - the three-wavefront class and borders 28 .. 50 - keep in a block of global memory and read back once or twice (from L2 when it still holds them); write: those sums, 8 B per placement, written once per step and point + register spills.  Since round 6 the blocks of EVERY such launch are recycled through per-XCD free lists (8192 blocks cycle instead of 40 000 write-once ones): the read-backs mostly hit L2 / the Infinity Cache (fetch 1.65 -> 1.14 GB per step), the writes still leave L2 (WRITE_SIZE counts them on their way to the memory side, 0.93 -> 0.91 GB); the results go to pinned host memory; algorithmic bytes = both images once (0.2 GB per step)'}, indent=1))
 PY
 cp $OUT/traffic.json $R/profiles/traffic.json
 python3 $R/bench.py --steps 20 --warmup 3 > $OUT/bench.json 2> $OUT/bench.err
