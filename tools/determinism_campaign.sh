@@ -60,5 +60,15 @@ run 10000 1000 --angles 1 --img-size 35
 SID_PM_NO_RECYCLE=1 run 4000 1000 --angles 1 --img-size 35
 SID_PM_KEEP_ACC=0 run 4000 1000 --angles 1 --img-size 35
 SID_PM_SAMP2=1 run 4000 300 --angles 7
+# round 6: bitmap free lists, for EVERY launch that keeps tables in global memory (the 15- and 7-angle kernels too); round 5's
+# split for comparison; the large-window pipeline (every point through it)
+run 4000 3000 --angles 7
+run 4000 3000 --angles 7 --border 20
+run 4000 2000 --angles 3
+run 10000 300 --angles 7
+run 4000 10000 --angles 1 --img-size 35
+SID_PM_RECYCLE_ALL=0 run 4000 1000 --angles 7
+SID_PM_ALL_LARGE=1 run 1000 30 --angles 1
+SID_PM_ALL_LARGE=1 run 1000 20 --angles 7 --img-size 35
 echo "library md5 $(md5sum $R/sea_ice_drift_amd/libsid_pm.so | cut -d' ' -f1)" >> $OUT
 cat $OUT
