@@ -3,7 +3,8 @@
 On gfx950 `v_pk_fma_f32 ... op_sel:[0,1,0]` - the form hipcc's SLP vectoriser produced in the template sampler - loses the
 product term in lanes 48..63 while another wavefront of the SIMD issues MFMAs (tools/ubench/pk_waw.hip, measured in
 profiles/r02_packed_fp32_op_sel_hazard.txt).  The build therefore switches the SLP vectoriser off and this test greps the
-generated ISA of every source.  Cross-compiles on the CPU box (no GPU needed), about a minute."""
+ISA of every BUILT object (the gfx950 code objects are disassembled: what ships; `make isa-check-src` recompiles every source to
+assembly instead).  Builds on the CPU box (no GPU needed), seconds once the library is built."""
 import os
 import shutil
 import subprocess
