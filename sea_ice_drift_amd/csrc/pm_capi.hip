@@ -498,7 +498,7 @@ int classify_points(sid_pm_ctx *ctx)
     for (int64_t i = 0; i < n; ++i) {
         int wh = 0, ww = 0;
         if (!window_dims(c2fg[i], r2fg[i], border[i], s, rows2, cols2, wh, ww)) { shapes[0].idx.push_back((int32_t)i); continue; }
-        if (wh - s + 1 >= 65536 * 16 || ww - s + 1 >= 65536 * 64) return fail(SID_PM_ERR_UNSUPPORTED, "point %lld: search window %dx%d too large", (long long)i, wh, ww);
+        if (wh > 65535 || ww > 4000000) return fail(SID_PM_ERR_UNSUPPORTED, "point %lld: search window %dx%d too large (65535 rows: a launch dimension of the large-window pipeline)", (long long)i, wh, ww);
         int k = find_shape(wh, ww);
         if (k < 0) {
             Shape sh{wh, ww, 0, 4, 0, 0, 0, 0.0, {}};
@@ -1249,8 +1249,8 @@ SID_EXPORT int sid_pm_rotate_and_match(sid_pm_ctx *ctx, double c1, double r1, in
     // cv2.matchTemplate needs a window at least as large as the template, np.gradient two values along each axis (pmlib.py:156, :51)
     if (win_rows - s + 1 < 2 || win_cols - s + 1 < 2)
         return fail(SID_PM_ERR_ARG, "window %lldx%lld: fewer than two placements of a %d px template along an axis", (long long)win_rows, (long long)win_cols, s);
-    if (win_rows > 0x7fffffff || win_cols > 0x7fffffff || win_rows - s + 1 >= 65536 * 16 || win_cols - s + 1 >= 65536ll * 64)
-        return fail(SID_PM_ERR_UNSUPPORTED, "window too large");
+    if (win_rows > 65535 || win_cols > 4000000)
+        return fail(SID_PM_ERR_UNSUPPORTED, "window %lldx%lld too large (at most 65535 rows: a launch dimension of the large-window pipeline)", (long long)win_rows, (long long)win_cols);
     const int64_t np = (win_rows - s + 1) * (win_cols - s + 1);
     if (np >= 0xffffffffll) return fail(SID_PM_ERR_UNSUPPORTED, "more than 2^32 placements");
     if (ccm && ccm_cap < np) return fail(SID_PM_ERR_ARG, "ccm capacity %lld < %lld placements", (long long)ccm_cap, (long long)np);

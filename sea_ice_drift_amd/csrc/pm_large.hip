@@ -742,7 +742,7 @@ int lw_run(const LargeCall &c, LwWorkspace &W, void *stream)
 {
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const int s = c.s, K = c.K, rh = c.wh - s + 1, rw = c.ww - s + 1;
-    if (s < 2 || s > kLargeMaxSide || K < 1 || K > kMaxAngles || rh < 2 || rw < 2) return (int)hipErrorInvalidValue;
+    if (s < 2 || s > kLargeMaxSide || K < 1 || K > kMaxAngles || rh < 2 || rw < 2 || c.wh > 65535) return (int)hipErrorInvalidValue;   // (wh: a launch dimension of lw_rowsums)
     const size_t np = (size_t)rh * rw;
     if (np >= 0xffffffffull) return (int)hipErrorInvalidValue;
     const size_t nblk = (np + 255) / 256;
