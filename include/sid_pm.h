@@ -204,7 +204,8 @@ int sid_pm_estimate_cost(const double *border, int64_t n, int img_size, int n_an
 #define SID_PM_CLASS_BIG    32
 #define SID_PM_CLASS_W3B    64
 #define SID_PM_CLASS_LARGE  128  /* beyond one workgroup's LDS (border > 111 px at 34 / 35 px, template side > 64): the point runs the
-                                  * large-window pipeline, one point at a time behind the launches of the others            */
+                                  * large-window pipeline, in batches of up to 64 such points behind the launches of the others
+                                  * (sid_pm_run then waits for the stream once before it enqueues them)                     */
 int sid_pm_estimate_residency(const double *border, int64_t n, int img_size, int n_angles, uint32_t flags, int32_t *launch_class);
 
 /* Estimated kernel time (nanoseconds) of ONE sid_pm_run over points with these borders: the point costs per launch class, the

@@ -761,6 +761,9 @@ int run_large_points(sid_pm_ctx *ctx, const sid::PMArgs &A)
         const int e = sid::lw_write_nan(ctx->d_nan_idx.p, ctx->n_nan_idx, A.out, A.out_ij, ctx->stream);
         if (e) return fail(SID_PM_ERR_HIP, "large-window pipeline: %s", hipGetErrorString((hipError_t)e));
     }
+    std::vector<sid::LargeCall> calls;
+    calls.reserve(ctx->large_idx.size());
+    size_t worst = 0;
     for (const int32_t i : ctx->large_idx) {
         int wh = 0, ww = 0;
         const double c2 = ctx->h_c2fg[(size_t)i], r2 = ctx->h_r2fg[(size_t)i], b = ctx->h_border[(size_t)i];
@@ -777,9 +780,13 @@ int run_large_points(sid_pm_ctx *ctx, const sid::PMArgs &A)
         c.add_c = c2; c.add_r = r2;
         memcpy(c.gauss_w, A.gauss_w, sizeof c.gauss_w);
         c.out5 = A.out + 5 * (size_t)i; c.ij3 = A.out_ij ? A.out_ij + 3 * (size_t)i : nullptr;
-        const int e = sid::lw_run(c, ctx->lw, ctx->stream);
-        if (e == -1) return fail(SID_PM_ERR_NOMEM, "point %d: the large-window pipeline needs %.2f GB of device scratch for its %dx%d window (%d angles)",
-                                 (int)i, (double)sid::lw_scratch_bytes(wh, ww, c.s, c.K, c.flags) * 1e-9, wh, ww, c.K);
+        worst = std::max(worst, sid::lw_scratch_bytes(wh, ww, c.s, c.K, c.flags));
+        calls.push_back(c);
+    }
+    if (!calls.empty()) {
+        const int e = sid::lw_run_batch(calls.data(), (int)calls.size(), ctx->lw, ctx->stream);
+        if (e == -1) return fail(SID_PM_ERR_NOMEM, "the large-window pipeline could not allocate its device scratch (%.2f GB for the largest of %zu points, batches of up to 3 GB)",
+                                 (double)worst * 1e-9, calls.size());
         if (e) return fail(SID_PM_ERR_HIP, "large-window pipeline: %s", hipGetErrorString((hipError_t)e));
     }
     return SID_PM_OK;
@@ -1529,13 +1536,14 @@ static int estimate_points(const double *border, int64_t n, int img_size, int n_
     const int s = img_size, K = n_angles;
     if (s < 2 || s > sid::kLargeMaxSide || K < 1) return fail(SID_PM_ERR_UNSUPPORTED, "img_size / angle count not supported");
     const bool small_ok = sid::mfma_img_size_supported(s);
-    // a point of the large-window pipeline (pm_large.hip: one point at a time, tiled over the device): ~20 launches of fixed
-    // cost, the matrix instructions of lw_corr, the box sums (profiles/r06_large_window_bench.jsonl: 0.17 / 0.19 / 0.24 ms at
-    // borders 112 / 160 / 250 with 15 angles, 0.27 ms at 100 px; within 30 %)
+    // a point of the large-window pipeline (pm_large.hip: batches of up to 64 points, each tiled over the device): the matrix
+    // instructions of lw_corr and the per-placement passes, fitted to profiles/r06_large_window_bench_batched.jsonl (11 / 19 / 46 us
+    // at borders 112 / 160 / 250 with 15 angles, 9 us at 100 px, 6 us at 65 px: within 40 %); the ~25 launches of a batch
+    // (0.15 ms) are priced per batch by sid_pm_estimate_run_time
     auto large_cost = [&](int wn) {
         const double r = (double)(wn - s + 1);
         const double tiles = ceil(r / 64.0) * ceil(r / 16.0) * (double)((K + 15) / 16);
-        return 150000.0 + 10.0 * tiles * (double)(s + 3) * (double)((s + 63) / 64) + 8.0 * (double)s * (double)s;
+        return 3000.0 + 4.5 * tiles * (double)(s + 3) * (double)((s + 63) / 64);
     };
     const bool rp = use_rp(s, K);
     const int rpp = rp ? rp_paired(K) : 0;
@@ -1642,7 +1650,7 @@ SID_EXPORT int sid_pm_estimate_run_time(const double *border, int64_t n, int img
     for (int c = 0; c < 256; ++c) {
         const Part &p = parts[c];
         if (p.count == 0) continue;
-        if (c & SID_PM_CLASS_LARGE) { large += p.sum; continue; }
+        if (c & SID_PM_CLASS_LARGE) { large += p.sum + 150000.0 * ceil(p.count / 64.0); continue; }   // (+ the launches of every batch of 64)
         const int per_cu = std::max(1, c & SID_PM_CLASS_PER_CU);
         const double latency = 256.0 * per_cu * (p.sum / p.count), tail = kTail[std::min(per_cu, 4)] * latency;
         ++nparts; sum_all += p.sum; rounds += p.count / (256.0 * per_cu);

@@ -10,8 +10,8 @@ constexpr int kLargeMaxSide = 255;
 
 // Device scratch of the pipeline, owned by a handle (grow-only; freed by lw_workspace_release).
 struct LwWorkspace {
-    void *buf[12] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    size_t cap[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    void *buf[16] = {};
+    size_t cap[16] = {};
 };
 void lw_workspace_release(LwWorkspace &W);
 // bytes of device scratch one call with these dimensions needs (for the out-of-memory message)
@@ -36,6 +36,9 @@ struct LargeCall {
 };
 // returns a hipError_t as int (0 = success); -1: scratch allocation failed
 int lw_run(const LargeCall &c, LwWorkspace &W, void *stream);
+// n calls of one run (same template side, angles and flags; any windows) in batches of up to 64 points: one launch per phase
+// and batch, the point a launch dimension.  Waits for the stream once at entry (the scratch of an earlier run is reused).
+int lw_run_batch(const LargeCall *calls, int n, LwWorkspace &W, void *stream);
 // After lw_run on the same workspace has completed: device pointers of the NCC matrix [rh][rw] (float32) and the template
 // [s][s] (uint8) of angle k (the matrices of ALL candidate angles stay in the workspace until the next lw_run).
 const float *lw_ncc_matrix(const LwWorkspace &W, int wh, int ww, int s, int k);

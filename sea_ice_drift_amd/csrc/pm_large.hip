@@ -17,8 +17,10 @@
 //   lw_hessian     exact median by radix select over the global matrix (lw_hist / lw_hist_scan), std from float64 sums
 //   lw_finish      displacement (pmlib.py:168-169), mcc_norm (:171-172), the five results
 //
-// Nothing is read back by the host between the kernels: the state of the point (LwState) lives in device memory, so a run of
-// large points is a stream of launches.  HBM-bound except lw_corr; sized for 288 GB (K x placements x 4 B of NCC values).
+// Nothing is read back by the host between the kernels: the state of a point (LwState) lives in device memory, so a run of
+// large points is a stream of launches - and the points of a run go through it in BATCHES: every kernel takes an array of
+// per-point parameters and one launch dimension is the point (lw_run_batch; a launch per phase and batch instead of ~25 per
+// point, whose fixed cost - 0.15 ms - was most of a point's time).  HBM-bound except lw_corr; sized for 288 GB (K x placements x 4 B of NCC values).
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <string.h>
@@ -69,6 +71,19 @@ struct LwParams {
     double *partial;
     double *out5; int32_t *ij3;
 };
+
+// source / destination matrices of the get_hessian kernels, by name (the pointers are per point): the NCC matrix of the winning
+// angle, the two smoothing buffers, the Hessian magnitudes
+enum { M_NCC = 0, M_TMPA = 1, M_TMPB = 2, M_HES = 3 };
+__device__ __forceinline__ float *lw_matrix(const LwParams &P, int sel)
+{
+    switch (sel) {
+    case M_NCC: return P.ncc + (size_t)P.st->kbest * ((size_t)P.rh * P.rw);
+    case M_TMPA: return P.tmpa;
+    case M_TMPB: return P.tmpb;
+    default: return P.hes;
+    }
+}
 
 __device__ __forceinline__ u32 f2key(float f) { u32 b = __float_as_uint(f); return (b & 0x80000000u) ? ~b : (b | 0x80000000u); }
 __device__ __forceinline__ float key2f(u32 k) { u32 b = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k; return __uint_as_float(b); }
@@ -245,8 +260,9 @@ __global__ __launch_bounds__(64) void lw_spline_pass_kernel(const TSrc *__restri
     }
 }
 
-__global__ __launch_bounds__(256) void lw_templates_kernel(const LwParams P)
+__global__ __launch_bounds__(256) void lw_templates_kernel(const LwParams *Pv)
 {
+    const LwParams &P = Pv[blockIdx.y];
     __shared__ long long red[256][2];
     __shared__ int redmin[256];
     const int k = blockIdx.x, tid = threadIdx.x, s = P.s;
@@ -305,10 +321,11 @@ __global__ __launch_bounds__(256) void lw_templates_kernel(const LwParams P)
 // ---------------------------------------------------------------------------------------------- box sums
 // running sums along the window rows: hs1[rho][x] = sum_{j < s} w'[rho][x + j], hs2 likewise of w'^2.  A thread owns four
 // consecutive x of one row: one full sum, three slides.
-__global__ __launch_bounds__(256) void lw_rowsums_kernel(const LwParams P)
+__global__ __launch_bounds__(256) void lw_rowsums_kernel(const LwParams *Pv)
 {
+    const LwParams &P = Pv[blockIdx.z];
     const int rho = blockIdx.y, x0 = (blockIdx.x * 256 + threadIdx.x) * 4;
-    if (x0 >= P.rw) return;
+    if (x0 >= P.rw || rho >= P.wh) return;
     const uint8_t *row = P.win + (long long)rho * P.wstride;
     int a = 0; u32 b = 0;
     for (int j = 0; j < P.s; ++j) { const int v = (int)row[x0 + j] - 128; a += v; b += (u32)(v * v); }
@@ -322,10 +339,11 @@ __global__ __launch_bounds__(256) void lw_rowsums_kernel(const LwParams P)
 }
 
 // ... then down the columns: si[y][x] = sum_{i < s} hs1[y + i][x].  A thread owns 32 consecutive y of one column (coalesced in x).
-__global__ __launch_bounds__(256) void lw_colsums_kernel(const LwParams P)
+__global__ __launch_bounds__(256) void lw_colsums_kernel(const LwParams *Pv)
 {
+    const LwParams &P = Pv[blockIdx.z];
     const int x = blockIdx.x * 256 + threadIdx.x, y0 = blockIdx.y * 32;
-    if (x >= P.rw) return;
+    if (x >= P.rw || y0 >= P.rh) return;
     const size_t rw = (size_t)P.rw;
     int a = 0; u32 b = 0;
     for (int i = 0; i < P.s; ++i) { a += P.hs1[(size_t)(y0 + i) * rw + x]; b += P.hs2[(size_t)(y0 + i) * rw + x]; }
@@ -353,12 +371,14 @@ __device__ __forceinline__ float lw_ncc(int acc, double swd, double dI, double r
 
 __host__ __device__ inline int lw_pitch(int s) { return kTW + 64 * ((s + 63) >> 6); }
 
-__global__ __launch_bounds__(256) void lw_corr_kernel(const LwParams P)
+__global__ __launch_bounds__(256) void lw_corr_kernel(const LwParams *Pv, int ngroups)
 {
+    const LwParams &P = Pv[blockIdx.z / ngroups];
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int s = P.s, nJB = (s + 63) >> 6, pitch = lw_pitch(s), rowsT = kTH + s - 1;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, n = lane & 15, kg = lane >> 4;
-    const int x0 = blockIdx.x * kTW, y0 = blockIdx.y * kTH, grp = blockIdx.z;
+    const int x0 = blockIdx.x * kTW, y0 = blockIdx.y * kTH, grp = blockIdx.z % ngroups;
+    if (x0 >= P.rw || y0 >= P.rh) return;                            // (the grid is sized for the largest window of the batch)
     // window tile -> LDS as re-centred int8; outside the window: 0 (those products belong to placements that are not stored)
     for (int e = tid; e < rowsT * (pitch >> 2); e += 256) {
         const int tr = e / (pitch >> 2), tc = (e - tr * (pitch >> 2)) << 2;
@@ -455,8 +475,9 @@ __global__ __launch_bounds__(256) void lw_corr_kernel(const LwParams P)
 }
 
 // ---------------------------------------------------------------------------------------------- angle pick
-__global__ void lw_pick_kernel(const LwParams P)
+__global__ void lw_pick_kernel(const LwParams *Pv)
 {
+    const LwParams &P = Pv[blockIdx.x];
     if (threadIdx.x != 0) return;
     LwState *S = P.st;
     const u32 n = (u32)((size_t)P.rh * P.rw);
@@ -492,11 +513,13 @@ __device__ __forceinline__ int lw_reflect(int q, int n)
     return q;
 }
 
-__global__ __launch_bounds__(256) void lw_smooth_kernel(const LwParams P, const float *base, size_t kstride, float *dst, int pass)
+__global__ __launch_bounds__(256) void lw_smooth_kernel(const LwParams *Pv, int src_sel, int dst_sel, int pass)
 {
+    const LwParams &P = Pv[blockIdx.y];
     const size_t np = (size_t)P.rh * P.rw, e = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (e >= np || !P.st->valid) return;
-    const float *src = base + (size_t)P.st->kbest * kstride;
+    const float *src = lw_matrix(P, src_sel);
+    float *dst = lw_matrix(P, dst_sel);
     const int y = (int)(e / P.rw), x = (int)(e - (size_t)y * P.rw);
     const int p = pass == 0 ? y : x, n = pass == 0 ? P.rh : P.rw;
     double acc = (double)src[e] * P.gw[4];
@@ -537,12 +560,16 @@ __device__ __forceinline__ void lw_block_sums(double a, double b, double *partia
 }
 
 // np.gradient twice along each axis, np.hypot (pmlib.py:51-55) - float32 arithmetic as NumPy's; hypotf as glibc evaluates it
-__global__ __launch_bounds__(256) void lw_hessian_kernel(const LwParams P, const float *base, size_t kstride, float *hes, double *partial)
+__global__ __launch_bounds__(256) void lw_hessian_kernel(const LwParams *Pv, int src_sel)
 {
+    const LwParams &P = Pv[blockIdx.y];
     const size_t np = (size_t)P.rh * P.rw, e = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if ((size_t)blockIdx.x * 256 >= np) return;                      // (block-uniform: the grid is sized for the largest matrix of the batch)
+    float *hes = P.hes;
+    double *partial = P.partial;
     double a = 0.0, b = 0.0;
     if (e < np && P.st->valid) {
-        const float *src = base + (size_t)P.st->kbest * kstride;
+        const float *src = lw_matrix(P, src_sel);
         const int y = (int)(e / P.rw), x = (int)(e - (size_t)y * P.rw);
         const float d2x = lw_grad2(src + (size_t)y * P.rw, 1, x, P.rw);
         const float d2y = lw_grad2(src + x, (size_t)P.rw, y, P.rh);
@@ -553,20 +580,26 @@ __global__ __launch_bounds__(256) void lw_hessian_kernel(const LwParams P, const
     lw_block_sums(a, b, partial);
 }
 
-__global__ __launch_bounds__(256) void lw_sums_kernel(const LwParams P, const float *base, size_t kstride, double *partial)
+__global__ __launch_bounds__(256) void lw_sums_kernel(const LwParams *Pv, int src_sel)
 {
+    const LwParams &P = Pv[blockIdx.y];
     const size_t np = (size_t)P.rh * P.rw, e = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if ((size_t)blockIdx.x * 256 >= np) return;
+    double *partial = P.partial;
     double a = 0.0, b = 0.0;
     if (e < np && P.st->valid) {
-        const float v = (base + (size_t)P.st->kbest * kstride)[e];
+        const float v = lw_matrix(P, src_sel)[e];
         a = (double)v; b = (double)v * (double)v;
     }
     lw_block_sums(a, b, partial);
 }
 
 // second level: the partials of nblk blocks in a fixed order -> st->sums[which]
-__global__ __launch_bounds__(256) void lw_sums_final_kernel(const LwParams P, const double *partial, int nblk, int which)
+__global__ __launch_bounds__(256) void lw_sums_final_kernel(const LwParams *Pv, int which)
 {
+    const LwParams &P = Pv[blockIdx.x];
+    const double *partial = P.partial;
+    const int nblk = (int)(((size_t)P.rh * P.rw + 255) / 256);
     __shared__ double red[256][2];
     const int tid = threadIdx.x;
     double a = 0.0, b = 0.0;
@@ -582,14 +615,15 @@ __global__ __launch_bounds__(256) void lw_sums_final_kernel(const LwParams P, co
 
 // exact order statistics by radix select, 8 bits per pass over the global matrix: histogram of the next byte among the
 // elements that match the prefix found so far, for both wanted ranks at once
-__global__ __launch_bounds__(256) void lw_hist_kernel(const LwParams P, const float *base, size_t kstride, int pass, int which)
+__global__ __launch_bounds__(256) void lw_hist_kernel(const LwParams *Pv, int src_sel, int pass, int which)
 {
+    const LwParams &P = Pv[blockIdx.y];
     __shared__ u32 h[2][256];
     const int tid = threadIdx.x;
     h[0][tid] = 0u; h[1][tid] = 0u;
     __syncthreads();
     if (P.st->valid) {
-        const float *src = base + (size_t)P.st->kbest * kstride;
+        const float *src = lw_matrix(P, src_sel);
         const size_t np = (size_t)P.rh * P.rw;
         const u32 p0 = P.st->sel_prefix[which][0], p1 = P.st->sel_prefix[which][1];
         const int hi = 32 - 8 * pass, lo = 24 - 8 * pass;
@@ -605,9 +639,9 @@ __global__ __launch_bounds__(256) void lw_hist_kernel(const LwParams P, const fl
     if (h[1][tid]) atomicAdd(&P.st->hist[which][1][tid], h[1][tid]);
 }
 
-__global__ void lw_hist_scan_kernel(const LwParams P, int pass, int which)
+__global__ void lw_hist_scan_kernel(const LwParams *Pv, int pass, int which)
 {
-    LwState *S = P.st;
+    LwState *S = Pv[blockIdx.x].st;
     const int b = threadIdx.x;
     if (b < 2 && S->valid) {
         u32 cum = 0, rank = S->sel_rank[which][b];
@@ -632,8 +666,9 @@ __device__ __forceinline__ void lw_med_std(const LwState *S, int which, size_t n
     sd = sqrtf((float)var);
 }
 
-__global__ void lw_finish_kernel(const LwParams P)
+__global__ void lw_finish_kernel(const LwParams *Pv)
 {
+    const LwParams &P = Pv[blockIdx.x];
     if (threadIdx.x != 0) return;
     const LwState *S = P.st;
     if (!S->valid) return;
@@ -649,8 +684,10 @@ __global__ void lw_finish_kernel(const LwParams P)
 }
 
 // get_hessian as a call of its own: the whole matrix normalised
-__global__ __launch_bounds__(256) void lw_normalise_kernel(const LwParams P, float *hes)
+__global__ __launch_bounds__(256) void lw_normalise_kernel(const LwParams *Pv)
 {
+    const LwParams &P = Pv[blockIdx.y];
+    float *hes = P.hes;
     const size_t np = (size_t)P.rh * P.rw, e = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (e >= np) return;
     float med, sd;
@@ -658,8 +695,9 @@ __global__ __launch_bounds__(256) void lw_normalise_kernel(const LwParams P, flo
     hes[e] = (hes[e] - med) / sd;
 }
 
-__global__ void lw_state_init_kernel(const LwParams P)
+__global__ void lw_state_init_kernel(const LwParams *Pv)
 {
+    const LwParams &P = Pv[blockIdx.x];
     if (threadIdx.x != 0) return;
     LwState *S = P.st;
     const u32 n = (u32)((size_t)P.rh * P.rw);
@@ -682,7 +720,9 @@ __global__ void lw_nan_kernel(const int32_t *idx, int n, double *out, int32_t *o
 }
 
 // ---------------------------------------------------------------------------------------------- host
-enum { B_STATE = 0, B_TMPL, B_OPA, B_HS1, B_HS2, B_SI, B_SII, B_NCC, B_HES, B_TMPA, B_TMPB, B_PART };
+enum { B_STATE = 0, B_TMPL, B_OPA, B_HS1, B_HS2, B_SI, B_SII, B_NCC, B_HES, B_TMPA, B_TMPB, B_PART, B_PARAMS };
+constexpr int kLwBatch = 64;                       // points per batch of launches (one launch dimension)
+constexpr size_t kLwBatchBytes = (size_t)3 << 30;  // ... as long as their scratch stays below this
 
 int reserve(LwWorkspace &W, int i, size_t bytes)
 {
@@ -695,6 +735,7 @@ int reserve(LwWorkspace &W, int i, size_t bytes)
 }
 
 size_t opa_bytes(int s, int K) { return (size_t)((K + 15) / 16) * (size_t)(s + 6) * (size_t)((s + 63) >> 6) * 1024; }
+size_t up256(size_t v) { return (v + 255) / 256 * 256; }
 
 hipError_t allow_lds(int bytes)
 {
@@ -711,93 +752,157 @@ hipError_t allow_lds(int bytes)
     return e;
 }
 
-// median + sums of one matrix: four histogram passes (two ranks at once) -> st->sel_prefix[which]
-void launch_select(const LwParams &P, const float *base, size_t kstride, int which, hipStream_t st)
+// median of one matrix per point of the batch: four histogram passes (two ranks at once) -> st->sel_prefix[which]
+void launch_select(const LwParams *Pv, int G, size_t np_max, int src_sel, int which, hipStream_t st)
 {
-    const size_t np = (size_t)P.rh * P.rw;
-    const unsigned nb = (unsigned)std::min<size_t>((np + 255) / 256, 2048);
+    const unsigned nb = (unsigned)std::min<size_t>((np_max + 255) / 256, 2048);
     for (int pass = 0; pass < 4; ++pass) {
-        hipLaunchKernelGGL(lw_hist_kernel, dim3(nb), dim3(256), 0, st, P, base, kstride, pass, which);
-        hipLaunchKernelGGL(lw_hist_scan_kernel, dim3(1), dim3(64), 0, st, P, pass, which);
+        hipLaunchKernelGGL(lw_hist_kernel, dim3(nb, (unsigned)G), dim3(256), 0, st, Pv, src_sel, pass, which);
+        hipLaunchKernelGGL(lw_hist_scan_kernel, dim3((unsigned)G), dim3(64), 0, st, Pv, pass, which);
     }
 }
+
+// per-point scratch of a call, bytes per buffer (256-byte granules)
+struct Need { size_t tmpl, opa, hs, s4, ncc, part; };
+Need need_of(const LargeCall &c)
+{
+    const size_t rh = (size_t)(c.wh - c.s + 1), rw = (size_t)(c.ww - c.s + 1), np = rh * rw;
+    return Need{up256((size_t)c.K * c.s * c.s), up256(opa_bytes(c.s, c.K)), up256((size_t)c.wh * rw * 4), up256(np * 4), up256((size_t)c.K * np * 4),
+                up256(((np + 255) / 256) * 16)};
+}
+size_t total_of(const Need &n, uint32_t flags) { return n.tmpl + n.opa + 2 * n.hs + 3 * n.s4 + n.ncc + n.part + ((flags & 2u) ? 2 * n.s4 : 0); }
 
 }  // namespace
 
 void lw_workspace_release(LwWorkspace &W)
 {
-    for (int i = 0; i < 12; ++i) { if (W.buf[i]) (void)hipFree(W.buf[i]); W.buf[i] = nullptr; W.cap[i] = 0; }
+    for (int i = 0; i < 16; ++i) { if (W.buf[i]) (void)hipFree(W.buf[i]); W.buf[i] = nullptr; W.cap[i] = 0; }
 }
 
 size_t lw_scratch_bytes(int wh, int ww, int s, int K, uint32_t flags)
 {
-    const size_t rh = (size_t)(wh - s + 1), rw = (size_t)(ww - s + 1), np = rh * rw;
-    size_t b = sizeof(LwState) + (size_t)K * s * s + opa_bytes(s, K) + (size_t)wh * rw * 8 + np * 8 + (size_t)K * np * 4 + np * 4;
-    if (flags & 2u) b += np * 8;
-    b += ((np + 255) / 256) * 32;
-    return b;
+    LargeCall c;
+    c.wh = wh; c.ww = ww; c.s = s; c.K = K;
+    return sizeof(LwState) + total_of(need_of(c), flags);
 }
 
-int lw_run(const LargeCall &c, LwWorkspace &W, void *stream)
+// The calls of one run (same template side, angles and flags; any windows), in batches of up to kLwBatch points: one launch per
+// phase and batch, the point = a launch dimension.
+int lw_run_batch(const LargeCall *calls, int n, LwWorkspace &W, void *stream)
 {
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    const int s = c.s, K = c.K, rh = c.wh - s + 1, rw = c.ww - s + 1;
-    if (s < 2 || s > kLargeMaxSide || K < 1 || K > kMaxAngles || rh < 2 || rw < 2 || c.wh > 65535) return (int)hipErrorInvalidValue;   // (wh: a launch dimension of lw_rowsums)
-    const size_t np = (size_t)rh * rw;
-    if (np >= 0xffffffffull) return (int)hipErrorInvalidValue;
-    const size_t nblk = (np + 255) / 256;
-    if (reserve(W, B_STATE, sizeof(LwState)) || reserve(W, B_TMPL, (size_t)K * s * s) || reserve(W, B_OPA, opa_bytes(s, K)) ||
-        reserve(W, B_HS1, (size_t)c.wh * rw * 4) || reserve(W, B_HS2, (size_t)c.wh * rw * 4) || reserve(W, B_SI, np * 4) ||
-        reserve(W, B_SII, np * 4) || reserve(W, B_NCC, (size_t)K * np * 4) || reserve(W, B_HES, np * 4) ||
-        ((c.flags & 2u) && (reserve(W, B_TMPA, np * 4) || reserve(W, B_TMPB, np * 4))) || reserve(W, B_PART, nblk * 32))
-        return -1;
-    LwParams P;
-    memset(&P, 0, sizeof P);
-    P.img1 = c.img1; P.rows1 = c.rows1; P.cols1 = c.cols1; P.stride1 = c.stride1; P.row0 = 0; P.col0 = 0; P.coef = c.d_coef;
-    if (((c.flags >> 3) & 7u) > 5u || (((c.flags >> 3) & 7u) >= 2u && !c.d_coef)) return (int)hipErrorInvalidValue;
-    P.win = c.img2 + c.win_r0 * c.stride2 + c.win_c0; P.wstride = c.stride2;
-    P.wh = c.wh; P.ww = c.ww; P.rh = rh; P.rw = rw; P.s = s; P.K = K; P.flags = c.flags;
-    P.c1 = c.c1; P.r1 = c.r1; P.rot = c.d_rot; P.angles = c.d_angles; P.add_c = c.add_c; P.add_r = c.add_r;
-    for (int q = 0; q < 5; ++q) P.gw[q] = c.gauss_w[q];
-    P.st = static_cast<LwState *>(W.buf[B_STATE]);
-    P.tmpl = static_cast<uint8_t *>(W.buf[B_TMPL]); P.opA = static_cast<uint8_t *>(W.buf[B_OPA]);
-    P.hs1 = static_cast<int32_t *>(W.buf[B_HS1]); P.hs2 = static_cast<u32 *>(W.buf[B_HS2]);
-    P.si = static_cast<int32_t *>(W.buf[B_SI]); P.sii = static_cast<u32 *>(W.buf[B_SII]);
-    P.ncc = static_cast<float *>(W.buf[B_NCC]); P.hes = static_cast<float *>(W.buf[B_HES]);
-    P.tmpa = static_cast<float *>(W.buf[B_TMPA]); P.tmpb = static_cast<float *>(W.buf[B_TMPB]);
-    P.partial = static_cast<double *>(W.buf[B_PART]);
-    P.out5 = c.out5; P.ij3 = c.ij3;
-    hipError_t e = allow_lds(0);
+    if (n <= 0) return 0;
+    const int s = calls[0].s, K = calls[0].K;
+    const uint32_t flags = calls[0].flags;
+    const int order = (int)((flags >> 3) & 7u);
+    if (s < 2 || s > kLargeMaxSide || K < 1 || K > kMaxAngles || order > 5) return (int)hipErrorInvalidValue;
+    for (int i = 0; i < n; ++i) {
+        const LargeCall &c = calls[i];
+        const int rh = c.wh - s + 1, rw = c.ww - s + 1;
+        if (c.s != s || c.K != K || c.flags != flags || rh < 2 || rw < 2 || c.wh > 65535 || (size_t)rh * rw >= 0xffffffffull ||
+            (order >= 2 && !c.d_coef)) return (int)hipErrorInvalidValue;   // (wh: a launch dimension of lw_rowsums)
+    }
+    // chunks, the scratch of the largest one, and every point's parameters with chunk-local scratch offsets
+    std::vector<int> chunk_end;
+    Need big{0, 0, 0, 0, 0, 0};
+    size_t big_hs = 0, big_s4 = 0, big_ncc = 0, big_part = 0;
+    std::vector<size_t> off_hs((size_t)n), off_s4((size_t)n), off_ncc((size_t)n), off_part((size_t)n);
+    {
+        size_t bytes = 0, o_hs = 0, o_s4 = 0, o_ncc = 0, o_part = 0;
+        int first = 0;
+        for (int i = 0; i < n; ++i) {
+            const Need nd = need_of(calls[i]);
+            const size_t t = total_of(nd, flags);
+            if (i > first && (i - first >= kLwBatch || bytes + t > kLwBatchBytes)) {
+                chunk_end.push_back(i); first = i; bytes = 0; o_hs = o_s4 = o_ncc = o_part = 0;
+            }
+            off_hs[(size_t)i] = o_hs; off_s4[(size_t)i] = o_s4; off_ncc[(size_t)i] = o_ncc; off_part[(size_t)i] = o_part;
+            o_hs += nd.hs; o_s4 += nd.s4; o_ncc += nd.ncc; o_part += nd.part; bytes += t;
+            big_hs = std::max(big_hs, o_hs); big_s4 = std::max(big_s4, o_s4); big_ncc = std::max(big_ncc, o_ncc); big_part = std::max(big_part, o_part);
+            big.tmpl = nd.tmpl; big.opa = nd.opa;
+        }
+        chunk_end.push_back(n);
+    }
+    const int gmax = std::min(n, kLwBatch);
+    // nothing of an earlier run on this stream may still read what is (re)allocated or overwritten below
+    hipError_t e = hipStreamSynchronize(st);
     if (e != hipSuccess) return (int)e;
-    if ((e = hipMemsetAsync(P.st, 0, sizeof(LwState), st)) != hipSuccess) return (int)e;
-    if ((e = hipMemsetAsync(P.opA, 0, opa_bytes(s, K), st)) != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(lw_templates_kernel, dim3((unsigned)K), dim3(256), 0, st, P);
-    hipLaunchKernelGGL(lw_rowsums_kernel, dim3((unsigned)((rw + 1023) / 1024), (unsigned)c.wh), dim3(256), 0, st, P);
-    hipLaunchKernelGGL(lw_colsums_kernel, dim3((unsigned)((rw + 255) / 256), (unsigned)((rh + 31) / 32)), dim3(256), 0, st, P);
-    const int lds = (kTH + s - 1) * lw_pitch(s);
-    hipLaunchKernelGGL(lw_corr_kernel, dim3((unsigned)((rw + kTW - 1) / kTW), (unsigned)((rh + kTH - 1) / kTH), (unsigned)((K + 15) / 16)),
-                       dim3(256), (size_t)lds, st, P);
-    hipLaunchKernelGGL(lw_pick_kernel, dim3(1), dim3(64), 0, st, P);
-    const float *hsrc = P.ncc;
-    size_t hstride = np;
-    if (c.flags & 2u) {
-        hipLaunchKernelGGL(lw_smooth_kernel, dim3((unsigned)nblk), dim3(256), 0, st, P, (const float *)P.ncc, np, P.tmpa, 0);
-        hipLaunchKernelGGL(lw_smooth_kernel, dim3((unsigned)nblk), dim3(256), 0, st, P, (const float *)P.tmpa, (size_t)0, P.tmpb, 1);
-        hsrc = P.tmpb; hstride = 0;
+    if (reserve(W, B_STATE, sizeof(LwState) * (size_t)kLwBatch) || reserve(W, B_TMPL, big.tmpl * gmax) || reserve(W, B_OPA, big.opa * gmax) ||
+        reserve(W, B_HS1, big_hs) || reserve(W, B_HS2, big_hs) || reserve(W, B_SI, big_s4) || reserve(W, B_SII, big_s4) || reserve(W, B_NCC, big_ncc) ||
+        reserve(W, B_HES, big_s4) || ((flags & 2u) && (reserve(W, B_TMPA, big_s4) || reserve(W, B_TMPB, big_s4))) || reserve(W, B_PART, big_part) ||
+        reserve(W, B_PARAMS, sizeof(LwParams) * (size_t)n))
+        return -1;
+    std::vector<LwParams> hp((size_t)n);
+    {
+        int first = 0, ci = 0;
+        for (int i = 0; i < n; ++i) {
+            if (i == chunk_end[(size_t)ci]) { first = i; ++ci; }
+            const LargeCall &c = calls[i];
+            const int g = i - first;
+            LwParams &P = hp[(size_t)i];
+            memset(&P, 0, sizeof P);
+            P.img1 = c.img1; P.rows1 = c.rows1; P.cols1 = c.cols1; P.stride1 = c.stride1; P.row0 = 0; P.col0 = 0; P.coef = c.d_coef;
+            P.win = c.img2 + c.win_r0 * c.stride2 + c.win_c0; P.wstride = c.stride2;
+            P.wh = c.wh; P.ww = c.ww; P.rh = c.wh - s + 1; P.rw = c.ww - s + 1; P.s = s; P.K = K; P.flags = flags;
+            P.c1 = c.c1; P.r1 = c.r1; P.rot = c.d_rot; P.angles = c.d_angles; P.add_c = c.add_c; P.add_r = c.add_r;
+            for (int q = 0; q < 5; ++q) P.gw[q] = c.gauss_w[q];
+            auto at = [&](int b, size_t off) { return static_cast<uint8_t *>(W.buf[b]) + off; };
+            P.st = static_cast<LwState *>(W.buf[B_STATE]) + g;
+            P.tmpl = at(B_TMPL, big.tmpl * g); P.opA = at(B_OPA, big.opa * g);
+            P.hs1 = reinterpret_cast<int32_t *>(at(B_HS1, off_hs[(size_t)i])); P.hs2 = reinterpret_cast<u32 *>(at(B_HS2, off_hs[(size_t)i]));
+            P.si = reinterpret_cast<int32_t *>(at(B_SI, off_s4[(size_t)i])); P.sii = reinterpret_cast<u32 *>(at(B_SII, off_s4[(size_t)i]));
+            P.ncc = reinterpret_cast<float *>(at(B_NCC, off_ncc[(size_t)i])); P.hes = reinterpret_cast<float *>(at(B_HES, off_s4[(size_t)i]));
+            if (flags & 2u) { P.tmpa = reinterpret_cast<float *>(at(B_TMPA, off_s4[(size_t)i])); P.tmpb = reinterpret_cast<float *>(at(B_TMPB, off_s4[(size_t)i])); }
+            P.partial = reinterpret_cast<double *>(at(B_PART, off_part[(size_t)i]));
+            P.out5 = c.out5; P.ij3 = c.ij3;
+        }
     }
-    hipLaunchKernelGGL(lw_hessian_kernel, dim3((unsigned)nblk), dim3(256), 0, st, P, hsrc, hstride, P.hes, P.partial);
-    if (c.flags & 1u) {
-        hipLaunchKernelGGL(lw_sums_final_kernel, dim3(1), dim3(256), 0, st, P, (const double *)P.partial, (int)nblk, 0);
-        launch_select(P, P.hes, 0, 0, st);
+    if ((e = hipMemcpy(W.buf[B_PARAMS], hp.data(), sizeof(LwParams) * (size_t)n, hipMemcpyHostToDevice)) != hipSuccess) return (int)e;
+    if ((e = allow_lds(0)) != hipSuccess) return (int)e;
+    const LwParams *dparams = static_cast<const LwParams *>(W.buf[B_PARAMS]);
+    const int ngroups = (K + 15) / 16, lds = (kTH + s - 1) * lw_pitch(s);
+    int first = 0;
+    for (const int end : chunk_end) {
+        const int G = end - first;
+        const LwParams *Pv = dparams + first;
+        int wh_max = 0, rh_max = 0, rw_max = 0;
+        size_t np_max = 0;
+        for (int i = first; i < end; ++i) {
+            wh_max = std::max(wh_max, hp[(size_t)i].wh); rh_max = std::max(rh_max, hp[(size_t)i].rh); rw_max = std::max(rw_max, hp[(size_t)i].rw);
+            np_max = std::max(np_max, (size_t)hp[(size_t)i].rh * hp[(size_t)i].rw);
+        }
+        const unsigned nblk = (unsigned)((np_max + 255) / 256);
+        if ((e = hipMemsetAsync(W.buf[B_STATE], 0, sizeof(LwState) * (size_t)G, st)) != hipSuccess) return (int)e;
+        if ((e = hipMemsetAsync(W.buf[B_OPA], 0, big.opa * (size_t)G, st)) != hipSuccess) return (int)e;
+        hipLaunchKernelGGL(lw_templates_kernel, dim3((unsigned)K, (unsigned)G), dim3(256), 0, st, Pv);
+        hipLaunchKernelGGL(lw_rowsums_kernel, dim3((unsigned)((rw_max + 1023) / 1024), (unsigned)wh_max, (unsigned)G), dim3(256), 0, st, Pv);
+        hipLaunchKernelGGL(lw_colsums_kernel, dim3((unsigned)((rw_max + 255) / 256), (unsigned)((rh_max + 31) / 32), (unsigned)G), dim3(256), 0, st, Pv);
+        hipLaunchKernelGGL(lw_corr_kernel, dim3((unsigned)((rw_max + kTW - 1) / kTW), (unsigned)((rh_max + kTH - 1) / kTH), (unsigned)(ngroups * G)),
+                           dim3(256), (size_t)lds, st, Pv, ngroups);
+        hipLaunchKernelGGL(lw_pick_kernel, dim3((unsigned)G), dim3(64), 0, st, Pv);
+        int hsrc = M_NCC;
+        if (flags & 2u) {
+            hipLaunchKernelGGL(lw_smooth_kernel, dim3(nblk, (unsigned)G), dim3(256), 0, st, Pv, (int)M_NCC, (int)M_TMPA, 0);
+            hipLaunchKernelGGL(lw_smooth_kernel, dim3(nblk, (unsigned)G), dim3(256), 0, st, Pv, (int)M_TMPA, (int)M_TMPB, 1);
+            hsrc = M_TMPB;
+        }
+        hipLaunchKernelGGL(lw_hessian_kernel, dim3(nblk, (unsigned)G), dim3(256), 0, st, Pv, hsrc);
+        if (flags & 1u) {
+            hipLaunchKernelGGL(lw_sums_final_kernel, dim3((unsigned)G), dim3(256), 0, st, Pv, 0);
+            launch_select(Pv, G, np_max, M_HES, 0, st);
+        }
+        if (flags & 4u) {
+            hipLaunchKernelGGL(lw_sums_kernel, dim3(nblk, (unsigned)G), dim3(256), 0, st, Pv, (int)M_NCC);
+            hipLaunchKernelGGL(lw_sums_final_kernel, dim3((unsigned)G), dim3(256), 0, st, Pv, 1);
+            launch_select(Pv, G, np_max, M_NCC, 1, st);
+        }
+        hipLaunchKernelGGL(lw_finish_kernel, dim3((unsigned)G), dim3(64), 0, st, Pv);
+        first = end;
     }
-    if (c.flags & 4u) {
-        hipLaunchKernelGGL(lw_sums_kernel, dim3((unsigned)nblk), dim3(256), 0, st, P, (const float *)P.ncc, np, P.partial);
-        hipLaunchKernelGGL(lw_sums_final_kernel, dim3(1), dim3(256), 0, st, P, (const double *)P.partial, (int)nblk, 1);
-        launch_select(P, P.ncc, np, 1, st);
-    }
-    hipLaunchKernelGGL(lw_finish_kernel, dim3(1), dim3(64), 0, st, P);
     return (int)hipGetLastError();
 }
+
+int lw_run(const LargeCall &c, LwWorkspace &W, void *stream) { return lw_run_batch(&c, 1, W, stream); }
 
 const float *lw_ncc_matrix(const LwWorkspace &W, int wh, int ww, int s, int k)
 {
@@ -886,6 +991,16 @@ int lw_write_nan(const int32_t *d_idx, int n, double *out, int32_t *out_ij, void
     return (int)hipGetLastError();
 }
 
+namespace {
+// one parameter record on the device for the single-point calls below (a small allocation of its own, freed by the caller's
+// synchronisation point: these entry points are synchronous adaptors)
+struct OneParam {
+    LwParams *d = nullptr;
+    int put(const LwParams &P) { if (hipMalloc(reinterpret_cast<void **>(&d), sizeof(LwParams)) != hipSuccess) return -1; return (int)hipMemcpy(d, &P, sizeof P, hipMemcpyHostToDevice); }
+    ~OneParam() { if (d) { (void)hipDeviceSynchronize(); (void)hipFree(d); } }
+};
+}  // namespace
+
 int lw_get_template(const uint8_t *d_img, int64_t stride, int64_t row0, int64_t col0, int64_t nrows, int64_t ncols, int64_t rows, int64_t cols,
                     double c, double r, const double *d_rot4, int s, int order, uint8_t *d_out, void *stream, const double *d_coef)
 {
@@ -895,8 +1010,10 @@ int lw_get_template(const uint8_t *d_img, int64_t stride, int64_t row0, int64_t 
     memset(&P, 0, sizeof P);
     P.img1 = d_img; P.rows1 = rows; P.cols1 = cols; P.stride1 = stride; P.row0 = row0; P.col0 = col0;
     P.s = s; P.K = 1; P.flags = (uint32_t)order << 3; P.c1 = c; P.r1 = r; P.rot = d_rot4; P.tmpl = d_out; P.coef = d_coef;
-    hipLaunchKernelGGL(lw_templates_kernel, dim3(1), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), P);
-    return (int)hipGetLastError();
+    OneParam one;
+    if (int rc = one.put(P)) return rc;
+    hipLaunchKernelGGL(lw_templates_kernel, dim3(1, 1), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), (const LwParams *)one.d);
+    return (int)hipGetLastError();                                     // (~OneParam waits for the kernel)
 }
 
 int lw_get_hessian(const float *d_ccm, int rh, int rw, uint32_t flags, const double gauss_w[5], float *d_hes, LwWorkspace &W, void *stream)
@@ -909,27 +1026,31 @@ int lw_get_hessian(const float *d_ccm, int rh, int rw, uint32_t flags, const dou
         ((flags & 2u) && (reserve(W, B_TMPA, np * 4) || reserve(W, B_TMPB, np * 4)))) return -1;
     LwParams P;
     memset(&P, 0, sizeof P);
-    P.rh = rh; P.rw = rw; P.flags = flags;
+    P.rh = rh; P.rw = rw; P.flags = flags; P.K = 1;
     for (int q = 0; q < 5; ++q) P.gw[q] = gauss_w[q];
     P.st = static_cast<LwState *>(W.buf[B_STATE]);
+    P.ncc = const_cast<float *>(d_ccm);                                // (read only: M_NCC with kbest = 0)
     P.tmpa = static_cast<float *>(W.buf[B_TMPA]); P.tmpb = static_cast<float *>(W.buf[B_TMPB]);
     P.partial = static_cast<double *>(W.buf[B_PART]); P.hes = d_hes;
     hipError_t e = hipMemsetAsync(P.st, 0, sizeof(LwState), st);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(lw_state_init_kernel, dim3(1), dim3(64), 0, st, P);
-    const float *src = d_ccm;
+    OneParam one;
+    if (int rc = one.put(P)) return rc;
+    const LwParams *Pv = one.d;
+    hipLaunchKernelGGL(lw_state_init_kernel, dim3(1), dim3(64), 0, st, Pv);
+    int src = M_NCC;
     if (flags & 2u) {
-        hipLaunchKernelGGL(lw_smooth_kernel, dim3((unsigned)nblk), dim3(256), 0, st, P, d_ccm, (size_t)0, P.tmpa, 0);
-        hipLaunchKernelGGL(lw_smooth_kernel, dim3((unsigned)nblk), dim3(256), 0, st, P, (const float *)P.tmpa, (size_t)0, P.tmpb, 1);
-        src = P.tmpb;
+        hipLaunchKernelGGL(lw_smooth_kernel, dim3((unsigned)nblk, 1), dim3(256), 0, st, Pv, (int)M_NCC, (int)M_TMPA, 0);
+        hipLaunchKernelGGL(lw_smooth_kernel, dim3((unsigned)nblk, 1), dim3(256), 0, st, Pv, (int)M_TMPA, (int)M_TMPB, 1);
+        src = M_TMPB;
     }
-    hipLaunchKernelGGL(lw_hessian_kernel, dim3((unsigned)nblk), dim3(256), 0, st, P, src, (size_t)0, d_hes, P.partial);
+    hipLaunchKernelGGL(lw_hessian_kernel, dim3((unsigned)nblk, 1), dim3(256), 0, st, Pv, src);
     if (flags & 1u) {
-        hipLaunchKernelGGL(lw_sums_final_kernel, dim3(1), dim3(256), 0, st, P, (const double *)P.partial, (int)nblk, 0);
-        launch_select(P, d_hes, 0, 0, st);
-        hipLaunchKernelGGL(lw_normalise_kernel, dim3((unsigned)nblk), dim3(256), 0, st, P, d_hes);
+        hipLaunchKernelGGL(lw_sums_final_kernel, dim3(1), dim3(256), 0, st, Pv, 0);
+        launch_select(Pv, 1, np, M_HES, 0, st);
+        hipLaunchKernelGGL(lw_normalise_kernel, dim3((unsigned)nblk, 1), dim3(256), 0, st, Pv);
     }
-    return (int)hipGetLastError();
+    return (int)hipGetLastError();                                     // (~OneParam waits for the kernels)
 }
 
 }  // namespace sid

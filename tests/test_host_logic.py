@@ -239,12 +239,12 @@ def test_launch_classes_and_costs_the_host_predicts():
         assert (np.diff(cost) > -1e-9).all(), cost                                  # a larger border never costs less
         assert 60.0 < cost[0] < 80.0 and 300.0 < cost[30] < 420.0                   # ns per point at borders 20 and 50 (profiles/r04_border_cost.json)
     # beyond one workgroup's LDS - borders above 111, template sides above 64 - the points run the large-window pipeline: a class
-    # of their own (SID_PM_CLASS_LARGE), priced at a fraction of a millisecond each
+    # of their own (SID_PM_CLASS_LARGE), priced at some ten microseconds each (in batches of 64: the launches of a batch are priced by sid_pm_estimate_run_time)
     big = _capi.estimate_residency([111.0, 112.0, 250.0], 34, 15)
     assert list(big) == [1 + 16 + 32, 1 + _capi.CLASS_LARGE, 1 + _capi.CLASS_LARGE]
     assert (_capi.estimate_residency(borders, 65, 15) == 1 + _capi.CLASS_LARGE).all()
     cost = _capi.estimate_cost([112.0, 250.0], 34, 15)
-    assert 1.5e5 < cost[0] < cost[1] < 4e5
+    assert 5e3 < cost[0] < cost[1] < 1e5                                          # (11 / 46 us measured in batches of 64)
     with pytest.raises(_capi.SidPmError):
         _capi.estimate_cost(borders, 256, 15)                                       # template sides beyond 255: unsupported, not estimated
     # the run-time estimate the shard cuts are made with: more than the sum of the costs (launch tails), the same rule as the launcher
