@@ -66,7 +66,7 @@ struct LwParams {
     double gw[5];
     LwState *st;
     uint8_t *tmpl; uint8_t *opA;
-    int32_t *hs1; u32 *hs2; int32_t *si; u32 *sii;
+    int32_t *hs1; u32 *hs2; int32_t *si; double *ri;                   // ri: 1 / sqrt(dI) per placement, -1 = OpenCV's low-variance rule (lw_colsums)
     float *ncc, *hes, *tmpa, *tmpb;
     double *partial;
     double *out5; int32_t *ij3;
@@ -338,30 +338,42 @@ __global__ __launch_bounds__(256) void lw_rowsums_kernel(const LwParams *Pv)
     }
 }
 
-// ... then down the columns: si[y][x] = sum_{i < s} hs1[y + i][x].  A thread owns 32 consecutive y of one column (coalesced in x).
+// ... then down the columns: si[y][x] = sum_{i < s} hs1[y + i][x], and at once the placement's share of the normalisation (DESIGN.md
+// section 3): dI = N sum w'^2 - (sum w')^2 exactly, OpenCV's low-variance rule, rI = 1 / sqrt(dI) in IEEE double - once per
+// placement here instead of once per placement AND k-group in lw_corr's epilogue (the IEEE square root and division were a
+// third of that kernel).  ri = -1 marks a low-variance placement.  A thread owns 32 consecutive y of one column (coalesced in x).
 __global__ __launch_bounds__(256) void lw_colsums_kernel(const LwParams *Pv)
 {
     const LwParams &P = Pv[blockIdx.z];
     const int x = blockIdx.x * 256 + threadIdx.x, y0 = blockIdx.y * 32;
     if (x >= P.rw || y0 >= P.rh) return;
     const size_t rw = (size_t)P.rw;
+    const double nd = (double)P.s * (double)P.s;
+    auto put = [&](size_t o, int a, u32 b) {
+        const double swd = (double)a, siid = (double)b;
+        const double dI = nd * siid - swd * swd;                           // exact
+        const double s2 = siid + 256.0 * swd + 16384.0 * nd;               // sum w^2 in the uint8 domain
+        const bool lowvar = (2.0 * dI <= nd) && (dI * 8388608.0 <= 10.0 * nd * s2);
+        P.si[o] = a;
+        P.ri[o] = lowvar ? -1.0 : 1.0 / sqrt(dI);
+    };
     int a = 0; u32 b = 0;
     for (int i = 0; i < P.s; ++i) { a += P.hs1[(size_t)(y0 + i) * rw + x]; b += P.hs2[(size_t)(y0 + i) * rw + x]; }
-    P.si[(size_t)y0 * rw + x] = a; P.sii[(size_t)y0 * rw + x] = b;
+    put((size_t)y0 * rw + x, a, b);
     for (int d = 1; d < 32 && y0 + d < P.rh; ++d) {
         a += P.hs1[(size_t)(y0 + d - 1 + P.s) * rw + x] - P.hs1[(size_t)(y0 + d - 1) * rw + x];
         b += P.hs2[(size_t)(y0 + d - 1 + P.s) * rw + x] - P.hs2[(size_t)(y0 + d - 1) * rw + x];
-        P.si[(size_t)(y0 + d) * rw + x] = a; P.sii[(size_t)(y0 + d) * rw + x] = b;
+        put((size_t)(y0 + d) * rw + x, a, b);
     }
 }
 
 // ---------------------------------------------------------------------------------------------- correlation + NCC
 // The specification's normalisation (oracle match_template_core): exact integers, then IEEE double with
 // one rounding per operation (this file is compiled with -ffp-contract=off like the others).
-__device__ __forceinline__ float lw_ncc(int acc, double swd, double dI, double rI, bool lowvar, double nd, double sT, double rT, bool constT)
+__device__ __forceinline__ float lw_ncc(int acc, double swd, double rI, double nd, double sT, double rT, bool constT)
 {
     if (constT) return 1.0f;
-    if (lowvar) return 0.0f;
+    if (rI < 0.0) return 0.0f;                                        // (low-variance placement: lw_colsums)
     const double numer = nd * (double)acc - swd * sT;                 // exact
     double q = numer * rI;
     q = q * rT;
@@ -406,8 +418,11 @@ __global__ __launch_bounds__(256) void lw_corr_kernel(const LwParams *Pv, int ng
     const uint8_t *bbase = smem + (4 * wv) * pitch + 16 * kg + (n & ~3);
     for (int jb = 0; jb < nJB; ++jb) {
         v4i a1 = v4i{0, 0, 0, 0}, a2 = a1, a3 = a1;                   // template rows rho - 1, rho - 2, rho - 3
-        for (int rho = 0; rho < s + 3; ++rho) {                       // window row of the band; output row yb pairs it with template row rho - yb
-            const v4i a0 = *reinterpret_cast<const v4i *>(opA + ((size_t)(rho + 3) * nJB + jb) * 1024);
+        // the A operands come from global memory (the table of a 50 px template is 56 KB: L2-resident, not LDS-sized): four steps
+        // ahead, so that their round trip is covered by the MFMAs of the steps in between (rows beyond s + 2: the last zero row)
+        const int last = s + 5;                                       // table row index of the last zero row
+        auto lda = [&](int rho) { const int r = rho + 3 < last ? rho + 3 : last; return *reinterpret_cast<const v4i *>(opA + ((size_t)r * nJB + jb) * 1024); };
+        auto step = [&](int rho, const v4i a0) {                      // window row rho of the band; output row yb pairs it with template row rho - yb
             const uint8_t *brow = bbase + rho * pitch + 64 * jb;
 #pragma unroll
             for (int xt = 0; xt < 4; ++xt) {
@@ -424,6 +439,18 @@ __global__ __launch_bounds__(256) void lw_corr_kernel(const LwParams *Pv, int ng
                 acc[3][xt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a3, b, acc[3][xt], 0, 0, 0);
             }
             a3 = a2; a2 = a1; a1 = a0;
+        };
+        v4i q0 = lda(0), q1 = lda(1), q2 = lda(2), q3 = lda(3);
+#ifdef LW_ABLATE_MAIN
+        const int nst = 1;
+#else
+        const int nst = s + 3;
+#endif
+        for (int rho = 0; rho < nst; rho += 4) {
+            step(rho, q0); q0 = lda(rho + 4);
+            if (rho + 1 < nst) { step(rho + 1, q1); q1 = lda(rho + 5); }
+            if (rho + 2 < nst) { step(rho + 2, q2); q2 = lda(rho + 6); }
+            if (rho + 3 < nst) { step(rho + 3, q3); q3 = lda(rho + 7); }
         }
     }
     // accumulator register r of lane (n, kg) = angle slot 4 kg + r at placement column n of its tile
@@ -439,6 +466,10 @@ __global__ __launch_bounds__(256) void lw_corr_kernel(const LwParams *Pv, int ng
         sT[r] = P.st->sT[kq]; rT[r] = P.st->rT[kq]; cT[r] = P.st->constT[kq] != 0;
     }
     u64 best[4] = {0ull, 0ull, 0ull, 0ull};
+#ifdef LW_ABLATE_EPI
+    if (acc[0][0][0] == 0x7fffffff) P.ncc[0] = 1.0f;
+    return;
+#endif
 #pragma unroll
     for (int yb = 0; yb < 4; ++yb) {
         const int y = y0 + 4 * wv + yb;
@@ -447,15 +478,11 @@ __global__ __launch_bounds__(256) void lw_corr_kernel(const LwParams *Pv, int ng
             const int x = x0 + 16 * xt + n;
             if (y < P.rh && x < P.rw) {
                 const size_t p = (size_t)y * P.rw + x;
-                const double swd = (double)P.si[p], siid = (double)P.sii[p];
-                const double dI = nd * siid - swd * swd;                           // exact
-                const double s2 = siid + 256.0 * swd + 16384.0 * nd;               // sum w^2 in the uint8 domain
-                const bool lowvar = (2.0 * dI <= nd) && (dI * 8388608.0 <= 10.0 * nd * s2);
-                const double rI = 1.0 / sqrt(dI);
+                const double swd = (double)P.si[p], rI = P.ri[p];
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
                     if (have[r]) {
-                        const float v = lw_ncc(acc[yb][xt][r], swd, dI, rI, lowvar, nd, sT[r], rT[r], cT[r]);
+                        const float v = lw_ncc(acc[yb][xt][r], swd, rI, nd, sT[r], rT[r], cT[r]);
                         P.ncc[(size_t)kk[r] * np + p] = v;
                         const u64 key = ((u64)f2key(v) << 32) | (u64)(0xffffffffu - (u32)p);
                         best[r] = key > best[r] ? key : best[r];
@@ -470,7 +497,9 @@ __global__ __launch_bounds__(256) void lw_corr_kernel(const LwParams *Pv, int ng
             const u64 o = (u64)__shfl_xor((unsigned long long)b, m, 64);
             b = o > b ? o : b;
         }
-        if (n == 0 && have[r] && b) atomicMax(&P.st->best[kk[r]], b);
+        // (a load first: once the maximum of an angle has been seen, almost no tile beats it - 10^6 atomics on one cache line
+        // were two thirds of this kernel's time)
+        if (n == 0 && have[r] && b && b > __hip_atomic_load(&P.st->best[kk[r]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&P.st->best[kk[r]], b);
     }
 }
 
@@ -720,7 +749,7 @@ __global__ void lw_nan_kernel(const int32_t *idx, int n, double *out, int32_t *o
 }
 
 // ---------------------------------------------------------------------------------------------- host
-enum { B_STATE = 0, B_TMPL, B_OPA, B_HS1, B_HS2, B_SI, B_SII, B_NCC, B_HES, B_TMPA, B_TMPB, B_PART, B_PARAMS };
+enum { B_STATE = 0, B_TMPL, B_OPA, B_HS1, B_HS2, B_SI, B_RI, B_NCC, B_HES, B_TMPA, B_TMPB, B_PART, B_PARAMS };
 constexpr int kLwBatch = 64;                       // points per batch of launches (one launch dimension)
 constexpr size_t kLwBatchBytes = (size_t)3 << 30;  // ... as long as their scratch stays below this
 
@@ -770,7 +799,7 @@ Need need_of(const LargeCall &c)
     return Need{up256((size_t)c.K * c.s * c.s), up256(opa_bytes(c.s, c.K)), up256((size_t)c.wh * rw * 4), up256(np * 4), up256((size_t)c.K * np * 4),
                 up256(((np + 255) / 256) * 16)};
 }
-size_t total_of(const Need &n, uint32_t flags) { return n.tmpl + n.opa + 2 * n.hs + 3 * n.s4 + n.ncc + n.part + ((flags & 2u) ? 2 * n.s4 : 0); }
+size_t total_of(const Need &n, uint32_t flags) { return n.tmpl + n.opa + 2 * n.hs + 4 * n.s4 + n.ncc + n.part + ((flags & 2u) ? 2 * n.s4 : 0); }   // (si, ri = 2 x, hes)
 
 }  // namespace
 
@@ -828,7 +857,7 @@ int lw_run_batch(const LargeCall *calls, int n, LwWorkspace &W, void *stream)
     hipError_t e = hipStreamSynchronize(st);
     if (e != hipSuccess) return (int)e;
     if (reserve(W, B_STATE, sizeof(LwState) * (size_t)kLwBatch) || reserve(W, B_TMPL, big.tmpl * gmax) || reserve(W, B_OPA, big.opa * gmax) ||
-        reserve(W, B_HS1, big_hs) || reserve(W, B_HS2, big_hs) || reserve(W, B_SI, big_s4) || reserve(W, B_SII, big_s4) || reserve(W, B_NCC, big_ncc) ||
+        reserve(W, B_HS1, big_hs) || reserve(W, B_HS2, big_hs) || reserve(W, B_SI, big_s4) || reserve(W, B_RI, 2 * big_s4) || reserve(W, B_NCC, big_ncc) ||
         reserve(W, B_HES, big_s4) || ((flags & 2u) && (reserve(W, B_TMPA, big_s4) || reserve(W, B_TMPB, big_s4))) || reserve(W, B_PART, big_part) ||
         reserve(W, B_PARAMS, sizeof(LwParams) * (size_t)n))
         return -1;
@@ -850,7 +879,7 @@ int lw_run_batch(const LargeCall *calls, int n, LwWorkspace &W, void *stream)
             P.st = static_cast<LwState *>(W.buf[B_STATE]) + g;
             P.tmpl = at(B_TMPL, big.tmpl * g); P.opA = at(B_OPA, big.opa * g);
             P.hs1 = reinterpret_cast<int32_t *>(at(B_HS1, off_hs[(size_t)i])); P.hs2 = reinterpret_cast<u32 *>(at(B_HS2, off_hs[(size_t)i]));
-            P.si = reinterpret_cast<int32_t *>(at(B_SI, off_s4[(size_t)i])); P.sii = reinterpret_cast<u32 *>(at(B_SII, off_s4[(size_t)i]));
+            P.si = reinterpret_cast<int32_t *>(at(B_SI, off_s4[(size_t)i])); P.ri = reinterpret_cast<double *>(at(B_RI, 2 * off_s4[(size_t)i]));
             P.ncc = reinterpret_cast<float *>(at(B_NCC, off_ncc[(size_t)i])); P.hes = reinterpret_cast<float *>(at(B_HES, off_s4[(size_t)i]));
             if (flags & 2u) { P.tmpa = reinterpret_cast<float *>(at(B_TMPA, off_s4[(size_t)i])); P.tmpb = reinterpret_cast<float *>(at(B_TMPB, off_s4[(size_t)i])); }
             P.partial = reinterpret_cast<double *>(at(B_PART, off_part[(size_t)i]));
