@@ -84,9 +84,9 @@ def test_recycled_blocks_survive_queue_evictions(angles, img_size, c_oracle, tmp
     oracle.  A process of its own, run before every other GPU test (conftest.py), with a hard timeout and one retry.
     A kernel of the library cannot hang on its free list any more - a popper's wait is bounded (ring_take: kRingSpinMax polls,
     then the point is REFUSED and sid_pm_sync raises) - so a soak that does not finish is either a stall of the driver's own
-    eviction / restore (seen on some boxes for minutes, with idle queues as well) or a defect of the library.  The CONTROL
-    tells them apart: the same process and evictor with no kernel of the library in flight.  Control stalls too: the box cannot
-    run this test (skip, with that evidence).  Control finishes: the library's kernels are what does not return - FAIL."""
+    eviction / restore or a defect of the library.  The CONTROL tells them apart: the same process, evictor and kernels with
+    exclusive blocks (SID_PM_NO_RECYCLE=1: no free list is touched).  Control stalls too: the box cannot run this test (skip,
+    with that evidence).  Control finishes: the free lists are what does not return - FAIL."""
     import json, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     dump = str(tmp_path / 'first_run.npz')
@@ -100,15 +100,19 @@ def test_recycled_blocks_survive_queue_evictions(angles, img_size, c_oracle, tmp
         except subprocess.TimeoutExpired:
             continue
     if p is None:
+        # CONTROL: the same process, evictor and kernels IN FLIGHT, but with exclusive blocks (SID_PM_NO_RECYCLE=1: the free lists
+        # are not used at all).  It stalls too -> the box's driver cannot restore evicted queues in time, with or without the free
+        # lists: skip, with that evidence.  It finishes -> the free lists are what does not return: FAIL.
+        env = dict(os.environ, SID_PM_NO_RECYCLE='1')
         try:
-            c = subprocess.run([sys.executable, tool, str(angles), str(img_size), '300', dump, 'control'],
-                               capture_output=True, text=True, timeout=90, cwd=root)
+            c = subprocess.run([sys.executable, tool, str(angles), str(img_size), '300', dump],
+                               capture_output=True, text=True, timeout=90, cwd=root, env=env)
         except subprocess.TimeoutExpired:
-            pytest.skip('queue evictions stall on this box with IDLE queues as well (control run: no kernel of the library in flight, '
-                        'no result within 90 s): the driver, not the free lists')
+            pytest.skip('queue evictions stall on this box with EXCLUSIVE blocks as well (control run: SID_PM_NO_RECYCLE=1, no result '
+                        'within 90 s): the driver, not the free lists')
         assert c.returncode == 0, c.stderr[-2000:]
-        pytest.fail('the eviction soak did not finish within 90 s, twice, while the control (same evictor, no kernel of the library '
-                    'in flight) finished: %s' % c.stdout.strip().splitlines()[-1])
+        pytest.fail('the eviction soak did not finish within 90 s, twice, while the control (same evictor and kernels, exclusive blocks '
+                    'instead of the free lists) finished: %s' % c.stdout.strip().splitlines()[-1])
     assert p.returncode == 0, p.stderr[-2000:]
     res = json.loads(p.stdout.strip().splitlines()[-1])
     assert res['bad'] == 0, '%d point results differed between repetitions (%d evictions provoked)' % (res['bad'], res['evictions'])
