@@ -462,6 +462,13 @@ __device__ __forceinline__ void take_better(Score &sc, float rv, int key)
 // region is free already) is fetched in the same round trip: its loads are issued before the window's.
 // PRIO >= 0: the wave priority of the phases up to the sweep, set here - inside a non-inlined phase - rather than in the kernel
 // body (pm_kernel_rp.inc: SID_SETPRIO_TS)
+// the image bytes of a point are read once by its workgroup (neighbouring points re-read the overlap within microseconds):
+// -DSID_IMG_NT loads them non-temporally, so that they do not push the recycled blocks' dirty lines out of L2 (round 6 experiment)
+#ifdef SID_IMG_NT
+#define SID_IMG_LOAD(p) __builtin_nontemporal_load(p)
+#else
+#define SID_IMG_LOAD(p) (*(p))
+#endif
 template <bool PATCH, int PRIO = -1, int KWIN = 10, int KPAT = 4>
 __device__ __noinline__ void ph_window_t(const uint8_t *img2, long long rows2, long long cols2, long long stride2,
                                          const uint8_t *img1, long long rows1, long long cols1, long long stride1)
@@ -490,8 +497,8 @@ __device__ __noinline__ void ph_window_t(const uint8_t *img2, long long rows2, l
             const u32 oa = o & ~3u;
             const u32 ob = oa + 4 <= plast ? oa + 4 : plast;
             psh[u] = o & 3u;
-            plo[u] = *reinterpret_cast<const u32 *>(porg4 + oa);
-            phi[u] = *reinterpret_cast<const u32 *>(porg4 + ob);
+            plo[u] = SID_IMG_LOAD(reinterpret_cast<const u32 *>(porg4 + oa));
+            phi[u] = SID_IMG_LOAD(reinterpret_cast<const u32 *>(porg4 + ob));
         }
     }
     uint8_t *win = smem + G.win_off;
@@ -525,8 +532,8 @@ __device__ __noinline__ void ph_window_t(const uint8_t *img2, long long rows2, l
             const u32 oa = o & ~3u;
             const u32 ob = oa + 4 <= last_off ? oa + 4 : last_off;
             shv[u] = o & 3u;
-            lo[u] = *reinterpret_cast<const u32 *>(org4 + oa);
-            hi[u] = *reinterpret_cast<const u32 *>(org4 + ob);
+            lo[u] = SID_IMG_LOAD(reinterpret_cast<const u32 *>(org4 + oa));
+            hi[u] = SID_IMG_LOAD(reinterpret_cast<const u32 *>(org4 + ob));
         }
 #pragma unroll
         for (int u = 0; u < kWin; ++u) {
